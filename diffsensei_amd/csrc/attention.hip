@@ -1,0 +1,456 @@
+// Attention cores for the DiffSensei UNet (head_dim 64, fp16 in / fp32 softmax / fp16 out).
+//
+//  self_attn_kernel   flash attention, replaces F.scaled_dot_product_attention at
+//                     reference src/models/attention_processor.py:76-78 (AttnProcessor2_0)
+//  ip_attn_kernel     ONE kernel for the whole MaskedIPAttnProcessor2_0 core, reference
+//                     src/models/attention_processor.py:235-258: text SDPA (77 keys) + region-masked IP SDPA
+//                     (16 dummy + 4x16 character keys) + `text + scale*ip`.  The additive mask the reference
+//                     materialises as [B,heads,N,80] every layer of every step (:115-169, a Python double loop
+//                     with a host sync per box) is evaluated analytically per query row from the 4 boxes.
+//
+// CDNA4 mapping (both kernels): a wave owns 32 query rows.  Scores are computed TRANSPOSED,
+// S^T = K * Q^T with v_mfma_f32_32x32x16_f16, so lane (l&31) holds one query row's scores in registers:
+// row max / row sum / the bbox test are lane-local (one cross-half exchange with lane^32).  The same
+// registers, exponentiated and packed to f16, are directly the B operand of O^T = V^T * P^T; V is kept
+// key-contiguous ("V transposed", produced that way by the projection GEMM) so its A fragments are
+// plain 8-byte LDS reads.  O^T keeps the query row on the lane as well, so the online-softmax rescale is
+// one multiply per accumulator register.
+#include "ds_common.h"
+#include "ds_kernels.h"
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float NEG_BIG = -1.0e30f;
+
+__device__ __forceinline__ int swz(int row, int chunk) { return ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+__device__ __forceinline__ h8 pack8(const f32x16& s, int base) {
+    h8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (half_t)s[base + e];
+    return o;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Flash self-attention.  grid = (ceil(Nq/128), B*heads), 256 threads, KV tile 64 keys, LDS 32 KiB.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void self_attn_kernel(const SelfAttnParams p) {
+    __shared__ __attribute__((aligned(16))) char sK[2][64 * 128];
+    __shared__ __attribute__((aligned(16))) char sV[2][64 * 128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int b = blockIdx.y / p.heads, h = blockIdx.y % p.heads;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+
+    // Q fragments (B operand of S^T): lane holds Q[q][kk*16 + lhi*8 .. +7]
+    const int qrow = min(q0 + l31, p.Nq - 1);
+    const half_t* qp = p.q + (long)b * p.sq + (long)qrow * p.ldq + h * 64 + lhi * 8;
+    h8 qf[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) qf[kk] = *reinterpret_cast<const h8*>(qp + kk * 16);
+
+    const half_t* kbase = p.k + (long)b * p.sk + h * 64;
+    const half_t* vbase = p.vt + ((long)(b * p.heads + h) * 64) * p.ldv;
+    const int c8 = tid & 7, r0 = tid >> 3;
+    const h8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    h8 rk[2], rv[2];
+    auto load_tile = [&](int t) {
+        const int key0 = t * 64;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = r0 + 32 * j;
+            const int key = key0 + row;
+            rk[j] = key < p.Nk ? *reinterpret_cast<const h8*>(kbase + (long)key * p.ldk + c8 * 8) : zero8;
+            const int kc = key0 + c8 * 8;  // row = d here
+            rv[j] = kc < p.Nk ? *reinterpret_cast<const h8*>(vbase + (long)row * p.ldv + kc) : zero8;
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = r0 + 32 * j;
+            *reinterpret_cast<h8*>(&sK[buf][row * 128 + swz(row, c8)]) = rk[j];
+            *reinterpret_cast<h8*>(&sV[buf][row * 128 + swz(row, c8)]) = rv[j];
+        }
+    };
+
+    f32x16 ot[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[d][r] = 0.f;
+    float m_run = NEG_BIG, l_part = 0.f;
+    const float c = p.scale * LOG2E;
+
+    const int nt = (p.Nk + 63) / 64;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nt) load_tile(t + 1);
+        // ---- S^T = K Q^T  (two 32-key blocks)
+        f32x16 st[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
+            const int row = kb * 32 + l31;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const h8 kf = *reinterpret_cast<const h8*>(&sK[buf][row * 128 + swz(row, kk * 2 + lhi)]);
+                st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[kk], st[kb], 0, 0, 0);
+            }
+        }
+        if (t * 64 + 64 > p.Nk) {  // ragged last tile: keys past Nk never contribute
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = t * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    if (key >= p.Nk) st[kb][r] = NEG_BIG;
+                }
+        }
+        // ---- online softmax, query row = lane&31 (the other 16 keys of each block live on lane^32)
+        float mloc = NEG_BIG;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, st[kb][r]);
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float m_new = fmaxf(m_run, mloc);
+        const float alpha = exp2f((m_run - m_new) * c);
+        m_run = m_new;
+        const float mc = m_new * c;
+        float psum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = exp2f(fmaf(st[kb][r], c, -mc));
+                st[kb][r] = e;
+                psum += e;
+            }
+        l_part = fmaf(l_part, alpha, psum);
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ot[d][r] *= alpha;
+        // ---- O^T += V^T P^T
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) {
+                const h8 pf = pack8(st[kb], hb * 8);
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const int row = db * 32 + l31;
+                    const int ch = kb * 4 + hb * 2;
+                    const h4 v0 = *reinterpret_cast<const h4*>(&sV[buf][row * 128 + swz(row, ch) + 8 * lhi]);
+                    const h4 v1 = *reinterpret_cast<const h4*>(&sV[buf][row * 128 + swz(row, ch + 1) + 8 * lhi]);
+                    h8 vf;
+                    vf[0] = v0[0]; vf[1] = v0[1]; vf[2] = v0[2]; vf[3] = v0[3];
+                    vf[4] = v1[0]; vf[5] = v1[1]; vf[6] = v1[2]; vf[7] = v1[3];
+                    ot[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, ot[db], 0, 0, 0);
+                }
+            }
+        if (t + 1 < nt) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+    const float l = l_part + __shfl_xor(l_part, 32, 64);
+    const float inv = 1.0f / l;
+    if (q0 + l31 < p.Nq) {
+        half_t* op = p.o + (long)b * p.so + (long)(q0 + l31) * p.ldo + h * 64;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                h4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (half_t)(ot[db][4 * g + e] * inv);
+                *reinterpret_cast<h4*>(op + db * 32 + 8 * g + 4 * lhi) = o;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Region test of the reference mask builder, evaluated per query token.
+// reference src/models/attention_processor.py:145-163: grid = torch.linspace(0,1,W) x linspace(0,1,H)
+// (inclusive end points), token idx -> (row idx / W, col idx % W); inside box k iff x1<=x<=x2 && y1<=y<=y2.
+// torch.linspace (fp32): step = 1/(n-1); v[i] = i<n/2 ? i*step : 1 - (n-1-i)*step  (no fma).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float linspace01(int i, int n) {
+    if (n <= 1) return 0.f;
+    const float step = __fdiv_rn(1.0f, (float)(n - 1));
+    return (i < n / 2) ? __fmul_rn(step, (float)i) : __fsub_rn(1.0f, __fmul_rn(step, (float)(n - 1 - i)));
+}
+// bit k set <=> token inside box k
+__device__ __forceinline__ unsigned region_flags(const float* __restrict__ bbox_b, int max_ips, int idx, int mh,
+                                                 int mw) {
+    const int yi = idx / mw, xi = idx - yi * mw;
+    const float x = linspace01(xi, mw), y = linspace01(yi, mh);
+    unsigned f = 0;
+    for (int k = 0; k < max_ips; ++k) {
+        const float x1 = bbox_b[4 * k + 0], y1 = bbox_b[4 * k + 1], x2 = bbox_b[4 * k + 2], y2 = bbox_b[4 * k + 3];
+        if (x >= x1 && x <= x2 && y >= y1 && y <= y2) f |= 1u << k;
+    }
+    return f;
+}
+
+__global__ void ip_region_flags_kernel(const float* bbox, uint8_t* flags, int B, int N, int max_ips, int mh, int mw) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * N) return;
+    const int b = i / N, idx = i - b * N;
+    flags[i] = (uint8_t)region_flags(bbox + (long)b * max_ips * 4, max_ips, idx, mh, mw);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused text + region-masked IP cross-attention.  Keys padded to LP = 96 rows (three 32-key blocks).
+// grid = (ceil(N/(128*qt)), B*heads); each block keeps the (b,h) text/IP K and V^T panels in LDS
+// (4 x 12 KiB) and walks `qt` 128-row query tiles.
+// ------------------------------------------------------------------------------------------------
+constexpr int LP = 96;
+constexpr int VSTR = 200;  // bytes per V^T row in LDS (96 keys * 2 B + 8 pad): conflict-free 8-byte reads
+
+__global__ __launch_bounds__(256, 2) void ip_attn_kernel(const IPAttnParams p, int qt) {
+    __shared__ __attribute__((aligned(16))) char sKt[LP * 128];
+    __shared__ __attribute__((aligned(16))) char sKi[LP * 128];
+    __shared__ __attribute__((aligned(16))) char sVt[64 * VSTR];
+    __shared__ __attribute__((aligned(16))) char sVi[64 * VSTR];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int b = blockIdx.y / p.heads, h = blockIdx.y % p.heads;
+
+    // ---- stage the four panels once
+    {
+        const half_t* ktp = p.kt + (long)b * LP * p.C + h * 64;
+        const half_t* kip = p.ki + (long)b * LP * p.C + h * 64;
+        for (int id = tid; id < LP * 8; id += 256) {
+            const int row = id >> 3, c = id & 7;
+            *reinterpret_cast<h8*>(&sKt[row * 128 + swz(row, c)]) =
+                *reinterpret_cast<const h8*>(ktp + (long)row * p.C + c * 8);
+            *reinterpret_cast<h8*>(&sKi[row * 128 + swz(row, c)]) =
+                *reinterpret_cast<const h8*>(kip + (long)row * p.C + c * 8);
+        }
+        const half_t* vtp = p.vtt + ((long)b * p.C + h * 64) * LP;
+        const half_t* vip = p.vti + ((long)b * p.C + h * 64) * LP;
+        for (int id = tid; id < 64 * 12; id += 256) {
+            const int row = id / 12, c = id - row * 12;
+            const h8 a = *reinterpret_cast<const h8*>(vtp + (long)row * LP + c * 8);
+            const h8 bb = *reinterpret_cast<const h8*>(vip + (long)row * LP + c * 8);
+            h4 lo, hi;
+            lo[0] = a[0]; lo[1] = a[1]; lo[2] = a[2]; lo[3] = a[3];
+            hi[0] = a[4]; hi[1] = a[5]; hi[2] = a[6]; hi[3] = a[7];
+            *reinterpret_cast<h4*>(&sVt[row * VSTR + c * 16]) = lo;
+            *reinterpret_cast<h4*>(&sVt[row * VSTR + c * 16 + 8]) = hi;
+            lo[0] = bb[0]; lo[1] = bb[1]; lo[2] = bb[2]; lo[3] = bb[3];
+            hi[0] = bb[4]; hi[1] = bb[5]; hi[2] = bb[6]; hi[3] = bb[7];
+            *reinterpret_cast<h4*>(&sVi[row * VSTR + c * 16]) = lo;
+            *reinterpret_cast<h4*>(&sVi[row * VSTR + c * 16 + 8]) = hi;
+        }
+    }
+    __syncthreads();
+
+    const float* bbox_b = p.bbox + (long)b * p.max_ips * 4;
+    const float ip_scale = p.ip_scale_ptr ? *p.ip_scale_ptr : p.ip_scale;
+    for (int it = 0; it < qt; ++it) {
+        const int q0 = (blockIdx.x * qt + it) * 128 + wave * 32;
+        if (q0 >= p.N) break;  // wave-uniform
+        const int qidx = min(q0 + l31, p.N - 1);
+        const half_t* qp = p.q + ((long)b * p.N + qidx) * p.ldq + h * 64 + lhi * 8;
+        h8 qf[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) qf[kk] = *reinterpret_cast<const h8*>(qp + kk * 16);
+        const unsigned inside = region_flags(bbox_b, p.max_ips, qidx, p.mask_h, p.mask_w);
+
+        f32x16 ot[2];
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ot[d][r] = 0.f;
+
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {  // 0: text keys, 1: IP keys
+            const char* sK = part ? sKi : sKt;
+            const char* sV = part ? sVi : sVt;
+            const int L = part ? p.Li : p.Lt;
+            f32x16 st[3];
+#pragma unroll
+            for (int kb = 0; kb < 3; ++kb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
+                const int row = kb * 32 + l31;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const h8 kf = *reinterpret_cast<const h8*>(sK + row * 128 + swz(row, kk * 2 + lhi));
+                    st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[kk], st[kb], 0, 0, 0);
+                }
+            }
+            // scale, additive region mask (-10000, like the reference), padding keys removed
+            float mloc = NEG_BIG;
+#pragma unroll
+            for (int kb = 0; kb < 3; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    float s = st[kb][r] * p.qk_scale;
+                    if (part) {
+                        bool masked;
+                        if (key < p.n_dummy) masked = inside != 0;                                  // dummy tokens
+                        else masked = ((inside >> ((key - p.n_dummy) / p.tok_per_ip)) & 1u) == 0;  // character tokens
+                        if (masked) s += -10000.0f;
+                    }
+                    if (key >= L) s = NEG_BIG;
+                    st[kb][r] = s;
+                    mloc = fmaxf(mloc, s);
+                }
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+            float psum = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 3; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float e = exp2f((st[kb][r] - mloc) * LOG2E);
+                    st[kb][r] = e;
+                    psum += e;
+                }
+            psum += __shfl_xor(psum, 32, 64);
+            const float w = (part ? ip_scale : 1.0f) / psum;
+#pragma unroll
+            for (int kb = 0; kb < 3; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[kb][r] *= w;
+            // O^T += V^T P^T
+#pragma unroll
+            for (int kb = 0; kb < 3; ++kb)
+#pragma unroll
+                for (int hb = 0; hb < 2; ++hb) {
+                    const h8 pf = pack8(st[kb], hb * 8);
+#pragma unroll
+                    for (int db = 0; db < 2; ++db) {
+                        const int row = db * 32 + l31;
+                        const int koff = (kb * 32 + hb * 16) * 2 + 8 * lhi;  // byte offset of this lane's first 4 keys
+                        const h4 v0 = *reinterpret_cast<const h4*>(sV + row * VSTR + koff);
+                        const h4 v1 = *reinterpret_cast<const h4*>(sV + row * VSTR + koff + 16);
+                        h8 vf;
+                        vf[0] = v0[0]; vf[1] = v0[1]; vf[2] = v0[2]; vf[3] = v0[3];
+                        vf[4] = v1[0]; vf[5] = v1[1]; vf[6] = v1[2]; vf[7] = v1[3];
+                        ot[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, ot[db], 0, 0, 0);
+                    }
+                }
+        }
+        if (q0 + l31 < p.N) {
+            half_t* op = p.o + ((long)b * p.N + q0 + l31) * p.ldo + h * 64;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    h4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (half_t)ot[db][4 * g + e];
+                    *reinterpret_cast<h4*>(op + db * 32 + 8 * g + 4 * lhi) = o;
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Generic small attention (any head_dim <= 128, any token counts) for the once-per-panel encoders:
+// CLIP ViT-H (257 tokens, head_dim 80), ViT-MAE, and the perceiver Resampler
+// (reference src/models/resampler.py:67-72: (q*s)(k*s)^T, fp32 softmax).  One wavefront per query row.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void small_attn_kernel(const half_t* __restrict__ q, const half_t* __restrict__ k,
+                                                         const half_t* __restrict__ v, half_t* __restrict__ o,
+                                                         long ldq, long ldk, long ldv, long ldo, long sq, long sk,
+                                                         long sv, long so, int B, int heads, int Nq, int Nk, int D,
+                                                         float scale) {
+    extern __shared__ float sp[];  // [4 waves][Nk]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    const int bh = blockIdx.y, b = bh / heads, h = bh % heads;
+    if (row >= Nq) return;
+    float* pw = sp + (size_t)wave * Nk;
+    const half_t* qp = q + b * sq + (long)row * ldq + h * D;
+    float mx = NEG_BIG;
+    for (int j = lane; j < Nk; j += 64) {
+        const half_t* kp = k + b * sk + (long)j * ldk + h * D;
+        float s = 0.f;
+        for (int d = 0; d < D; d += 8) {
+            const h8 a = *reinterpret_cast<const h8*>(qp + d);
+            const h8 c = *reinterpret_cast<const h8*>(kp + d);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s = fmaf((float)a[e], (float)c[e], s);
+        }
+        s *= scale;
+        pw[j] = s;
+        mx = fmaxf(mx, s);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j < Nk; j += 64) {
+        const float e = __expf(pw[j] - mx);
+        pw[j] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    __builtin_amdgcn_wave_barrier();  // same-wave LDS writes are ordered before its later reads
+    const float inv = 1.0f / sum;
+    for (int d = lane; d < D; d += 64) {
+        float acc = 0.f;
+        const half_t* vp = v + b * sv + h * D + d;
+        for (int j = 0; j < Nk; ++j) acc = fmaf((float)(half_t)(pw[j] * inv), (float)vp[(long)j * ldv], acc);
+        o[b * so + (long)row * ldo + h * D + d] = (half_t)acc;
+    }
+}
+
+}  // namespace
+
+int ds_launch_self_attn(const SelfAttnParams& p, hipStream_t stream) {
+    DS_REQUIRE(p.B > 0 && p.heads > 0 && p.Nq > 0 && p.Nk > 0, "self_attn: empty problem");
+    DS_REQUIRE(p.Nk % 8 == 0 && p.ldv % 8 == 0 && p.ldq % 8 == 0 && p.ldk % 8 == 0 && p.ldo % 4 == 0,
+               "self_attn: Nk/ld* alignment (Nk=%d)", p.Nk);
+    dim3 grid((p.Nq + 127) / 128, p.B * p.heads);
+    hipLaunchKernelGGL(self_attn_kernel, grid, dim3(256), 0, stream, p);
+    DS_LAUNCH_CHECK();
+    return 0;
+}
+
+int ds_launch_ip_attn(const IPAttnParams& p, hipStream_t stream) {
+    DS_REQUIRE(p.B > 0 && p.heads > 0 && p.N > 0, "ip_attn: empty problem");
+    DS_REQUIRE(p.LP == LP, "ip_attn: key panels must be padded to %d rows (got %d)", LP, p.LP);
+    DS_REQUIRE(p.Lt > 0 && p.Lt <= LP && p.Li > 0 && p.Li <= LP, "ip_attn: Lt=%d Li=%d exceed %d", p.Lt, p.Li, LP);
+    DS_REQUIRE(p.C == p.heads * 64, "ip_attn: head_dim must be 64 (C=%d heads=%d)", p.C, p.heads);
+    DS_REQUIRE(p.max_ips >= 1 && p.max_ips <= 8 && p.tok_per_ip > 0, "ip_attn: bad ip token layout");
+    DS_REQUIRE(p.n_dummy + p.max_ips * p.tok_per_ip == p.Li, "ip_attn: Li (%d) != n_dummy + max_ips*tok_per_ip", p.Li);
+    DS_REQUIRE(p.mask_h * p.mask_w == p.N, "ip_attn: mask grid %dx%d != N %d", p.mask_h, p.mask_w, p.N);
+    // walk several query tiles per block once there are plenty of blocks (amortises the K/V panel staging)
+    const int tiles = (p.N + 127) / 128;
+    int qt = 1;
+    while (qt < 4 && (long)((tiles + 2 * qt - 1) / (2 * qt)) * p.B * p.heads >= 1024) qt *= 2;
+    dim3 grid((tiles + qt - 1) / qt, p.B * p.heads);
+    hipLaunchKernelGGL(ip_attn_kernel, grid, dim3(256), 0, stream, p, qt);
+    DS_LAUNCH_CHECK();
+    return 0;
+}
+
+int ds_launch_ip_region_flags(const float* bbox, uint8_t* flags, int B, int N, int max_ips, int mask_h, int mask_w,
+                              hipStream_t stream) {
+    DS_REQUIRE(mask_h * mask_w == N, "region_flags: grid %dx%d != N %d", mask_h, mask_w, N);
+    hipLaunchKernelGGL(ip_region_flags_kernel, dim3((B * N + 255) / 256), dim3(256), 0, stream, bbox, flags, B, N,
+                       max_ips, mask_h, mask_w);
+    DS_LAUNCH_CHECK();
+    return 0;
+}
+
+int ds_launch_small_attn(const half_t* q, const half_t* k, const half_t* v, half_t* o, long ldq, long ldk, long ldv,
+                         long ldo, long sq, long sk, long sv, long so, int B, int heads, int Nq, int Nk, int D,
+                         float scale, hipStream_t stream) {
+    DS_REQUIRE(D % 8 == 0 && D <= 128, "small_attn: head_dim %d unsupported", D);
+    DS_REQUIRE(Nk * 4 * sizeof(float) <= 60000, "small_attn: Nk %d too large", Nk);
+    dim3 grid((Nq + 3) / 4, B * heads);
+    hipLaunchKernelGGL(small_attn_kernel, grid, dim3(256), (size_t)4 * Nk * sizeof(float), stream, q, k, v, o, ldq,
+                       ldk, ldv, ldo, sq, sk, sv, so, B, heads, Nq, Nk, D, scale);
+    DS_LAUNCH_CHECK();
+    return 0;
+}

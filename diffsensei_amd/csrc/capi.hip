@@ -1,0 +1,341 @@
+// C ABI (include/diffsensei_hip.h) over the kernel launchers, plus the plan executor: a flat launch list
+// that replays one UNet forward (+CFG+scheduler step) with no host arithmetic, eagerly or as a hipGraph.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/diffsensei_hip.h"
+#include "ds_common.h"
+#include "ds_kernels.h"
+
+static thread_local char g_err[512] = "";
+void ds_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+#define H(x) reinterpret_cast<const half_t*>(x)
+#define HM(x) reinterpret_cast<half_t*>(x)
+#define S(x) reinterpret_cast<hipStream_t>(x)
+
+extern "C" {
+
+const char* ds_last_error(void) { return g_err; }
+int ds_version(void) { return 100; }
+
+int ds_device_info(int* cu_count, int* lds_bytes, char* arch_name, int arch_name_len) {
+    int dev = 0;
+    DS_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    DS_HIP(hipGetDeviceProperties(&prop, dev));
+    if (cu_count) *cu_count = prop.multiProcessorCount;
+    if (lds_bytes) *lds_bytes = (int)prop.sharedMemPerBlock;
+    if (arch_name && arch_name_len > 0) {
+        strncpy(arch_name, prop.gcnArchName, arch_name_len - 1);
+        arch_name[arch_name_len - 1] = 0;
+    }
+    return 0;
+}
+
+int ds_gemm_f16(const void* x, int64_t ldx, const void* x2, int64_t ldx2, int k1, const void* w, int64_t ldw,
+                const void* bias, const void* residual, int64_t ldr, void* y, int64_t ldy, int M, int N, int K,
+                int geglu, void* stream) {
+    GemmParams p;
+    p.A = H(x); p.lda = ldx; p.A2 = H(x2); p.lda2 = ldx2; p.K1 = x2 ? k1 : K;
+    p.W = H(w); p.ldw = ldw; p.bias = H(bias); p.residual = H(residual); p.ldr = ldr;
+    p.C = HM(y); p.ldc = ldy; p.M = M; p.N = N; p.K = K; p.epi = geglu ? EPI_GEGLU : EPI_NONE;
+    return ds_launch_gemm(p, 1, S(stream));
+}
+
+int ds_gemm_f16_batched(const void* x, int64_t ldx, int64_t sx, const void* w, int64_t ldw, int64_t sw, void* y,
+                        int64_t ldy, int64_t sy, int M, int N, int K, int batch, void* stream) {
+    GemmParams p;
+    p.A = H(x); p.lda = ldx; p.sA = sx; p.K1 = K; p.W = H(w); p.ldw = ldw; p.sW = sw;
+    p.C = HM(y); p.ldc = ldy; p.sC = sy; p.M = M; p.N = N; p.K = K;
+    return ds_launch_gemm(p, batch, S(stream));
+}
+
+static int conv3x3_impl(const void* x, const void* w, const void* bias, const void* rowbias, int64_t rowbias_ld,
+                        const void* residual, void* y, int B, int H_, int W_, int Cin, int Cout, int stride,
+                        int upsample, hipStream_t stream) {
+    DS_REQUIRE(stride == 1 || stride == 2, "conv3x3: stride must be 1 or 2");
+    DS_REQUIRE(!(upsample && stride != 1), "conv3x3: upsample with stride 2 is not a thing");
+    GemmParams p;
+    p.conv = 1;
+    p.A = H(x); p.W = H(w); p.ldw = 9L * Cin; p.bias = H(bias); p.rowbias = H(rowbias); p.rowbias_ld = (int)rowbias_ld;
+    p.residual = H(residual); p.ldr = Cout; p.C = HM(y); p.ldc = Cout;
+    p.Hin = H_; p.Win = W_; p.Cin = Cin; p.cstride = stride; p.upsample = upsample;
+    p.Hout = upsample ? 2 * H_ : (stride == 2 ? (H_ + 1) / 2 : H_);
+    p.Wout = upsample ? 2 * W_ : (stride == 2 ? (W_ + 1) / 2 : W_);
+    p.M = B * p.Hout * p.Wout; p.N = Cout; p.K = 9 * Cin; p.K1 = p.K;
+    p.rows_per_group = p.Hout * p.Wout;
+    return ds_launch_gemm(p, 1, stream);
+}
+
+int ds_conv3x3_f16(const void* x, const void* w, const void* bias, const void* rowbias, int64_t rowbias_ld,
+                   const void* residual, void* y, int B, int H_, int W_, int Cin, int Cout, int stride, int upsample,
+                   void* stream) {
+    return conv3x3_impl(x, w, bias, rowbias, rowbias_ld, residual, y, B, H_, W_, Cin, Cout, stride, upsample, S(stream));
+}
+
+size_t ds_groupnorm_workspace_bytes(int B, int C) { return ds_groupnorm_ws_floats(B, C) * sizeof(float); }
+
+int ds_groupnorm_f16(const void* x1, const void* x2, void* y, const void* gamma, const void* beta, void* ws, int B,
+                     int HW, int C1, int C2, int groups, float eps, int silu, void* stream) {
+    GroupNormParams p;
+    p.x1 = H(x1); p.x2 = H(x2); p.y = HM(y); p.gamma = H(gamma); p.beta = H(beta); p.ws = reinterpret_cast<float*>(ws);
+    p.B = B; p.HW = HW; p.C1 = C1; p.C2 = x2 ? C2 : 0; p.groups = groups; p.eps = eps; p.silu = silu;
+    return ds_launch_groupnorm(p, S(stream));
+}
+
+int ds_layernorm_f16(const void* x, void* y, const void* gamma, const void* beta, int rows, int C, float eps,
+                     void* stream) {
+    return ds_launch_layernorm(H(x), HM(y), H(gamma), H(beta), rows, C, eps, S(stream));
+}
+
+int ds_self_attn_f16(const void* q, int64_t ldq, int64_t sq, const void* k, int64_t ldk, int64_t sk, const void* vt,
+                     int64_t ldv, void* o, int64_t ldo, int64_t so, int B, int heads, int Nq, int Nk, float scale,
+                     void* stream) {
+    SelfAttnParams p;
+    p.q = H(q); p.k = H(k); p.vt = H(vt); p.o = HM(o);
+    p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.sq = sq; p.sk = sk; p.so = so;
+    p.B = B; p.heads = heads; p.Nq = Nq; p.Nk = Nk; p.scale = scale;
+    return ds_launch_self_attn(p, S(stream));
+}
+
+int ds_masked_ip_attn_f16(const void* q, int64_t ldq, const void* kt, const void* vtt, const void* ki,
+                          const void* vti, const float* bbox, void* o, int64_t ldo, int B, int heads, int N, int Lt,
+                          int Li, int n_dummy, int tok_per_ip, int max_ips, int mask_h, int mask_w, float qk_scale,
+                          float ip_scale, const float* ip_scale_dev, void* stream) {
+    IPAttnParams p;
+    p.q = H(q); p.kt = H(kt); p.vtt = H(vtt); p.ki = H(ki); p.vti = H(vti); p.bbox = bbox; p.o = HM(o);
+    p.ldq = ldq; p.ldo = ldo; p.B = B; p.heads = heads; p.N = N; p.C = heads * 64;
+    p.Lt = Lt; p.Li = Li; p.LP = 96; p.n_dummy = n_dummy; p.tok_per_ip = tok_per_ip; p.max_ips = max_ips;
+    p.mask_h = mask_h; p.mask_w = mask_w; p.qk_scale = qk_scale; p.ip_scale = ip_scale; p.ip_scale_ptr = ip_scale_dev;
+    return ds_launch_ip_attn(p, S(stream));
+}
+
+int ds_ip_region_flags(const float* bbox, uint8_t* flags, int B, int N, int max_ips, int mask_h, int mask_w,
+                       void* stream) {
+    return ds_launch_ip_region_flags(bbox, flags, B, N, max_ips, mask_h, mask_w, S(stream));
+}
+
+int ds_small_attn_f16(const void* q, int64_t ldq, int64_t sq, const void* k, int64_t ldk, int64_t sk, const void* v,
+                      int64_t ldv, int64_t sv, void* o, int64_t ldo, int64_t so, int B, int heads, int Nq, int Nk,
+                      int D, float scale, void* stream) {
+    return ds_launch_small_attn(H(q), H(k), H(v), HM(o), ldq, ldk, ldv, ldo, sq, sk, sv, so, B, heads, Nq, Nk, D, scale,
+                                S(stream));
+}
+
+int ds_conv_in_dialog_f16(const void* x, const void* w, const void* bias, const int32_t* dialog_boxes,
+                          const void* dialog_emb, void* y, int B, int H_, int W_, int Cin, int Cout, int ndialog,
+                          void* stream) {
+    return ds_launch_conv_in(H(x), H(w), H(bias), dialog_boxes, H(dialog_emb), HM(y), B, H_, W_, Cin, Cout, ndialog,
+                             S(stream));
+}
+
+int ds_conv_out_f16(const void* x, const void* w, const void* bias, void* y, int B, int H_, int W_, int Cin, int Cout,
+                    void* stream) {
+    return ds_launch_conv_out(H(x), H(w), H(bias), HM(y), B, H_, W_, Cin, Cout, S(stream));
+}
+
+int ds_skinny_linear_f16(const void* x, const void* w, const void* bias, const void* addend, void* y, int M, int N,
+                         int K, int silu_in, int silu_out, void* stream) {
+    return ds_launch_skinny_linear(H(x), H(w), H(bias), H(addend), HM(y), M, N, K, silu_in, silu_out, S(stream));
+}
+
+int ds_timestep_embed_f16(const float* table, const int32_t* step_ctr, void* out, int B, int dim, int flip,
+                          float freq_shift, void* stream) {
+    return ds_launch_timestep_embed(table, step_ctr, HM(out), B, dim, flip, freq_shift, S(stream));
+}
+
+int ds_add_time_ids_f16(const void* text_embeds, const void* time_ids, void* out, int B, int pooled_dim, int n_ids,
+                        int dim, int flip, float freq_shift, void* stream) {
+    return ds_launch_add_time_ids(H(text_embeds), H(time_ids), HM(out), B, pooled_dim, n_ids, dim, flip, freq_shift,
+                                  S(stream));
+}
+
+int ds_cfg_sampler_step_f16(const void* eps, void* latents, void* model_in, const float* table,
+                            const int32_t* step_ctr, int ns, int HW, int kind, int do_cfg, void* stream) {
+    SamplerStepParams p;
+    p.eps = H(eps); p.latents = HM(latents); p.model_in = HM(model_in); p.coef = table;
+    p.ns = ns; p.HW = HW; p.kind = kind; p.do_cfg = do_cfg;
+    return ds_launch_sampler_step(p, step_ctr, S(stream));
+}
+
+int ds_prepare_model_input_f16(const void* latents, void* model_in, const float* table, const int32_t* step_ctr,
+                               int ns, int HW, int do_cfg, void* stream) {
+    return ds_launch_prepare_model_input(H(latents), HM(model_in), table, step_ctr, ns, HW, 4, do_cfg, S(stream));
+}
+
+int ds_nhwc_to_nchw_f16(const void* x, void* y, int B, int HW, int C, void* stream) {
+    return ds_launch_nhwc_to_nchw(H(x), HM(y), B, HW, C, S(stream));
+}
+int ds_nchw_to_nhwc_f16(const void* x, void* y, int B, int HW, int C, void* stream) {
+    return ds_launch_nchw_to_nhwc(H(x), HM(y), B, HW, C, S(stream));
+}
+int ds_pad_rows_f16(const void* x, void* y, int B, int rows_in, int rows_out, int row_off, int total_rows, int C,
+                    void* stream) {
+    return ds_launch_pad_rows(H(x), HM(y), B, rows_in, rows_out, row_off, total_rows, C, S(stream));
+}
+
+// ---------------------------------------------------------------------------------------- plan executor
+static int run_op(const ds_op& o, hipStream_t st) {
+    const int32_t* i = o.i;
+    const int64_t* l = o.l;
+    void* const* p = o.p;
+    switch (o.code) {
+        case DS_OP_GEMM: {
+            GemmParams g;
+            g.A = H(p[0]); g.A2 = H(p[1]); g.W = H(p[2]); g.C = HM(p[3]); g.bias = H(p[4]); g.rowbias = H(p[5]);
+            g.residual = H(p[6]);
+            g.lda = l[0]; g.lda2 = l[1]; g.ldw = l[2]; g.ldc = l[3]; g.ldr = l[4];
+            g.sA = l[5]; g.sA2 = l[6]; g.sW = l[7]; g.sC = l[8]; g.sR = l[9];
+            g.M = i[0]; g.N = i[1]; g.K = i[2]; g.K1 = g.A2 ? i[3] : i[2];
+            g.epi = i[4] ? EPI_GEGLU : EPI_NONE;
+            g.rowbias_ld = i[6]; g.rows_per_group = i[7] > 0 ? i[7] : 1;
+            return ds_launch_gemm(g, i[5] > 0 ? i[5] : 1, st);
+        }
+        case DS_OP_CONV3X3:
+            return conv3x3_impl(p[0], p[1], p[3], p[4], i[7], p[5], p[2], i[0], i[1], i[2], i[3], i[4], i[5], i[6], st);
+        case DS_OP_GROUPNORM: {
+            GroupNormParams g;
+            g.x1 = H(p[0]); g.x2 = H(p[1]); g.y = HM(p[2]); g.gamma = H(p[3]); g.beta = H(p[4]);
+            g.ws = reinterpret_cast<float*>(p[5]);
+            g.B = i[0]; g.HW = i[1]; g.C1 = i[2]; g.C2 = p[1] ? i[3] : 0; g.groups = i[4]; g.silu = i[5]; g.eps = o.f[0];
+            return ds_launch_groupnorm(g, st);
+        }
+        case DS_OP_LAYERNORM:
+            return ds_launch_layernorm(H(p[0]), HM(p[1]), H(p[2]), H(p[3]), i[0], i[1], o.f[0], st);
+        case DS_OP_SELF_ATTN: {
+            SelfAttnParams a;
+            a.q = H(p[0]); a.k = H(p[1]); a.vt = H(p[2]); a.o = HM(p[3]);
+            a.ldq = l[0]; a.ldk = l[1]; a.ldv = l[2]; a.ldo = l[3]; a.sq = l[4]; a.sk = l[5]; a.so = l[6];
+            a.B = i[0]; a.heads = i[1]; a.Nq = i[2]; a.Nk = i[3]; a.scale = o.f[0];
+            return ds_launch_self_attn(a, st);
+        }
+        case DS_OP_IP_ATTN: {
+            IPAttnParams a;
+            a.q = H(p[0]); a.kt = H(p[1]); a.vtt = H(p[2]); a.ki = H(p[3]); a.vti = H(p[4]);
+            a.bbox = reinterpret_cast<const float*>(p[5]); a.o = HM(p[6]);
+            a.ip_scale_ptr = reinterpret_cast<const float*>(p[7]);
+            a.ldq = l[0]; a.ldo = l[1];
+            a.B = i[0]; a.heads = i[1]; a.N = i[2]; a.C = i[1] * 64; a.Lt = i[3]; a.Li = i[4]; a.LP = 96;
+            a.n_dummy = i[5]; a.tok_per_ip = i[6]; a.max_ips = i[7]; a.mask_h = i[8]; a.mask_w = i[9];
+            a.qk_scale = o.f[0]; a.ip_scale = o.f[1];
+            return ds_launch_ip_attn(a, st);
+        }
+        case DS_OP_CONV_IN:
+            return ds_launch_conv_in(H(p[0]), H(p[1]), H(p[2]), reinterpret_cast<const int*>(p[3]), H(p[4]), HM(p[5]),
+                                     i[0], i[1], i[2], i[3], i[4], i[5], st);
+        case DS_OP_CONV_OUT:
+            return ds_launch_conv_out(H(p[0]), H(p[1]), H(p[2]), HM(p[3]), i[0], i[1], i[2], i[3], i[4], st);
+        case DS_OP_SKINNY:
+            return ds_launch_skinny_linear(H(p[0]), H(p[1]), H(p[2]), H(p[3]), HM(p[4]), i[0], i[1], i[2], i[3], i[4], st);
+        case DS_OP_TIMESTEP_EMBED:
+            return ds_launch_timestep_embed(reinterpret_cast<const float*>(p[0]), reinterpret_cast<const int*>(p[1]),
+                                            HM(p[2]), i[0], i[1], i[2], o.f[0], st);
+        case DS_OP_ADD_TIME_IDS:
+            return ds_launch_add_time_ids(H(p[0]), H(p[1]), HM(p[2]), i[0], i[1], i[2], i[3], i[4], o.f[0], st);
+        case DS_OP_SAMPLER_STEP: {
+            SamplerStepParams s;
+            s.eps = H(p[0]); s.latents = HM(p[1]); s.model_in = HM(p[2]); s.coef = reinterpret_cast<const float*>(p[3]);
+            s.ns = i[0]; s.HW = i[1]; s.kind = i[2]; s.do_cfg = i[3];
+            return ds_launch_sampler_step(s, reinterpret_cast<const int*>(p[4]), st);
+        }
+        case DS_OP_PREP_INPUT:
+            return ds_launch_prepare_model_input(H(p[0]), HM(p[1]), reinterpret_cast<const float*>(p[2]),
+                                                 reinterpret_cast<const int*>(p[3]), i[0], i[1], 4, i[2], st);
+        case DS_OP_ADVANCE:
+            return ds_launch_advance_counter(reinterpret_cast<int*>(p[0]), st);
+        case DS_OP_NHWC2NCHW:
+            return ds_launch_nhwc_to_nchw(H(p[0]), HM(p[1]), i[0], i[1], i[2], st);
+        case DS_OP_NCHW2NHWC:
+            return ds_launch_nchw_to_nhwc(H(p[0]), HM(p[1]), i[0], i[1], i[2], st);
+        case DS_OP_PAD_ROWS:
+            return ds_launch_pad_rows(H(p[0]), HM(p[1]), i[0], i[1], i[2], i[3], i[4], i[5], st);
+        case DS_OP_SMALL_ATTN:
+            return ds_launch_small_attn(H(p[0]), H(p[1]), H(p[2]), HM(p[3]), l[0], l[1], l[2], l[3], l[4], l[5], l[6],
+                                        l[7], i[0], i[1], i[2], i[3], i[4], o.f[0], st);
+        default:
+            ds_set_error("plan: unknown opcode %d", o.code);
+            return -4;
+    }
+}
+
+struct ds_plan {
+    std::vector<ds_op> ops;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+};
+
+int ds_op_run(const ds_op* op, void* stream) {
+    DS_REQUIRE(op != nullptr, "ds_op_run: null op");
+    return run_op(*op, S(stream));
+}
+
+int ds_plan_create(const ds_op* ops, int n_ops, ds_plan** out) {
+    DS_REQUIRE(ops && n_ops > 0 && out, "ds_plan_create: bad arguments");
+    ds_plan* pl = new ds_plan();
+    pl->ops.assign(ops, ops + n_ops);
+    *out = pl;
+    return 0;
+}
+
+int ds_plan_num_ops(const ds_plan* plan) { return plan ? (int)plan->ops.size() : -1; }
+
+int ds_plan_run(ds_plan* plan, void* stream) {
+    DS_REQUIRE(plan, "ds_plan_run: null plan");
+    for (size_t k = 0; k < plan->ops.size(); ++k) {
+        const int rc = run_op(plan->ops[k], S(stream));
+        if (rc != 0) {
+            char msg[600];
+            snprintf(msg, sizeof(msg), "plan op %zu (code %d): %s", k, plan->ops[k].code, g_err);
+            ds_set_error("%s", msg);
+            return rc;
+        }
+    }
+    return 0;
+}
+
+int ds_plan_capture(ds_plan* plan, void* stream) {
+    DS_REQUIRE(plan, "ds_plan_capture: null plan");
+    if (plan->exec) return 0;
+    hipStream_t st = S(stream);
+    DS_REQUIRE(st != nullptr, "ds_plan_capture: needs a non-default stream");
+    DS_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    const int rc = ds_plan_run(plan, stream);
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamEndCapture(st, &g);
+    if (rc != 0) {
+        if (g) hipGraphDestroy(g);
+        return rc;
+    }
+    if (e != hipSuccess) {
+        ds_set_error("hipStreamEndCapture failed: %s", hipGetErrorString(e));
+        return -2;
+    }
+    plan->graph = g;
+    DS_HIP(hipGraphInstantiate(&plan->exec, g, nullptr, nullptr, 0));
+    return 0;
+}
+
+int ds_plan_replay(ds_plan* plan, void* stream) {
+    DS_REQUIRE(plan && plan->exec, "ds_plan_replay: plan not captured");
+    DS_HIP(hipGraphLaunch(plan->exec, S(stream)));
+    return 0;
+}
+
+int ds_plan_destroy(ds_plan* plan) {
+    if (!plan) return 0;
+    if (plan->exec) hipGraphExecDestroy(plan->exec);
+    if (plan->graph) hipGraphDestroy(plan->graph);
+    delete plan;
+    return 0;
+}
+
+}  // extern "C"

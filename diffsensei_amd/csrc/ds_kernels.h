@@ -1,0 +1,110 @@
+// Internal launcher interface between the C-ABI layer / plan executor and the HIP kernels.
+#pragma once
+#include "ds_common.h"
+
+enum { EPI_NONE = 0, EPI_GEGLU = 1 };
+
+struct GemmParams {
+    const half_t* A = nullptr;   // plain: [M,K] rows (lda);  conv: NHWC input [B,Hin,Win,Cin]
+    const half_t* A2 = nullptr;  // plain only: second source for k >= K1 (channel concat without a copy)
+    const half_t* W = nullptr;   // [N,K] rows (ldw), K contiguous; conv: K = (ky*3+kx)*Cin + ci
+    half_t* C = nullptr;         // [M,N] rows (ldc)   (GEGLU: [M,N/2])
+    const half_t* bias = nullptr;      // [N]
+    const half_t* rowbias = nullptr;   // [M/rows_per_group, rowbias_ld]  (resnet time-embedding projection)
+    const half_t* residual = nullptr;  // [M,N] rows (ldr), added after rounding to f16
+    long lda = 0, lda2 = 0, ldw = 0, ldc = 0, ldr = 0;
+    long sA = 0, sA2 = 0, sW = 0, sC = 0, sR = 0;  // batch strides (elements), grid.z
+    int M = 0, N = 0, K = 0, K1 = 0;
+    int rowbias_ld = 0, rows_per_group = 1;
+    int epi = EPI_NONE;
+    int conv = 0;
+    int Hin = 0, Win = 0, Cin = 0, Hout = 0, Wout = 0, cstride = 1, upsample = 0;
+    int tiles_m = 0, tiles_n = 0;
+};
+int ds_launch_gemm(const GemmParams& p, int batch, hipStream_t stream);
+
+// ---- normalisation ---------------------------------------------------------------------------------
+struct GroupNormParams {
+    const half_t* x1 = nullptr;  // [B,HW,C1]
+    const half_t* x2 = nullptr;  // [B,HW,C2] or null  (channels C1..C1+C2)
+    half_t* y = nullptr;         // [B,HW,C1+C2]
+    const half_t* gamma = nullptr;
+    const half_t* beta = nullptr;
+    float* ws = nullptr;         // workspace, ds_groupnorm_ws_floats() floats
+    int B = 0, HW = 0, C1 = 0, C2 = 0, groups = 32;
+    float eps = 1e-5f;
+    int silu = 0;
+};
+size_t ds_groupnorm_ws_floats(int B, int C);
+int ds_launch_groupnorm(const GroupNormParams& p, hipStream_t stream);
+int ds_launch_layernorm(const half_t* x, half_t* y, const half_t* gamma, const half_t* beta, int rows, int C,
+                        float eps, hipStream_t stream);
+
+// ---- attention -------------------------------------------------------------------------------------
+struct SelfAttnParams {
+    const half_t* q = nullptr;   // [B,N,*] rows (ldq), head h at column h*64
+    const half_t* k = nullptr;   // [B,N,*] rows (ldk)
+    const half_t* vt = nullptr;  // [B,heads,64,ldv]  (V transposed: keys contiguous)
+    half_t* o = nullptr;         // [B,N,*] rows (ldo)
+    long ldq = 0, ldk = 0, ldv = 0, ldo = 0;
+    long sq = 0, sk = 0, so = 0;  // per-batch strides (elements)
+    int B = 0, heads = 0, Nq = 0, Nk = 0;
+    float scale = 0.125f;
+};
+int ds_launch_self_attn(const SelfAttnParams& p, hipStream_t stream);
+
+struct IPAttnParams {
+    const half_t* q = nullptr;     // [B,N,C] rows (ldq)
+    const half_t* kt = nullptr;    // text keys   [B,LP,C]      (rows >= Lt are padding)
+    const half_t* vtt = nullptr;   // text values [B,C,LP]      (transposed)
+    const half_t* ki = nullptr;    // ip keys     [B,LP,C]
+    const half_t* vti = nullptr;   // ip values   [B,C,LP]
+    const float* bbox = nullptr;   // [B,max_ips,4]
+    half_t* o = nullptr;           // [B,N,C] rows (ldo)
+    long ldq = 0, ldo = 0;
+    int B = 0, heads = 0, N = 0, C = 0;
+    int Lt = 77, Li = 80, LP = 96;
+    int n_dummy = 16, tok_per_ip = 16, max_ips = 4;
+    int mask_h = 0, mask_w = 0;    // grid the reference infers from (N, aspect_ratio)
+    float qk_scale = 0.125f, ip_scale = 1.0f;
+    const float* ip_scale_ptr = nullptr;  // device scalar; overrides ip_scale when set (graph-replay safe)
+};
+int ds_launch_ip_attn(const IPAttnParams& p, hipStream_t stream);
+int ds_launch_small_attn(const half_t* q, const half_t* k, const half_t* v, half_t* o, long ldq, long ldk, long ldv,
+                         long ldo, long sq, long sk, long sv, long so, int B, int heads, int Nq, int Nk, int D,
+                         float scale, hipStream_t stream);
+int ds_launch_ip_region_flags(const float* bbox, uint8_t* flags, int B, int N, int max_ips, int mask_h, int mask_w,
+                              hipStream_t stream);
+
+// ---- small / elementwise ------------------------------------------------------------------------------
+int ds_launch_conv_in(const half_t* x, const half_t* w, const half_t* bias, const int* dialog_boxes,
+                      const half_t* dialog_emb, half_t* y, int B, int H, int W, int Cin, int Cout, int ndialog,
+                      hipStream_t stream);
+int ds_launch_conv_out(const half_t* x, const half_t* w, const half_t* bias, half_t* y, int B, int H, int W, int Cin,
+                       int Cout, hipStream_t stream);
+int ds_launch_skinny_linear(const half_t* x, const half_t* w, const half_t* bias, const half_t* addend, half_t* y,
+                            int M, int N, int K, int act_in, int act_out, hipStream_t stream);
+// Per-step scalar table: row i (8 floats) = {timestep, c_in_div, k0, k1, k2, k3, c_in_div_next, guidance};
+// `ctr` is a device int selecting the row (null = row 0) so a captured hipGraph is step-independent.
+int ds_launch_timestep_embed(const float* table, const int* ctr, half_t* out, int B, int dim, int flip,
+                             float freq_shift, hipStream_t stream);
+int ds_launch_add_time_ids(const half_t* text_embeds, const half_t* time_ids, half_t* out, int B, int pooled_dim,
+                           int n_ids, int dim, int flip, float freq_shift, hipStream_t stream);
+
+struct SamplerStepParams {
+    const half_t* eps = nullptr;    // UNet output, NHWC [2*ns, HW, 4]: rows [0,ns) uncond, [ns,2ns) cond
+    half_t* latents = nullptr;      // NCHW [ns,4,H,W], updated in place (fp16 between steps, like the reference)
+    half_t* model_in = nullptr;     // NHWC [2*ns, HW, 4]: next step's scaled input (both CFG halves)
+    const float* coef = nullptr;    // per-step scalar table (see elementwise.hip)
+    int ns = 0, HW = 0, C = 4;
+    int kind = 0;                   // 0 Euler, 1 DDIM
+    int do_cfg = 1;
+};
+int ds_launch_sampler_step(const SamplerStepParams& p, const int* ctr, hipStream_t stream);
+int ds_launch_prepare_model_input(const half_t* latents, half_t* model_in, const float* table, const int* ctr, int ns,
+                                  int HW, int C, int do_cfg, hipStream_t stream);
+int ds_launch_advance_counter(int* ctr, hipStream_t stream);
+int ds_launch_nhwc_to_nchw(const half_t* x, half_t* y, int B, int HW, int C, hipStream_t stream);
+int ds_launch_nchw_to_nhwc(const half_t* x, half_t* y, int B, int HW, int C, hipStream_t stream);
+int ds_launch_pad_rows(const half_t* x, half_t* y, int B, int rows_in, int rows_out, int row_off, int total_rows,
+                       int C, hipStream_t stream);

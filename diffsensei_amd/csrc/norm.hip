@@ -1,0 +1,240 @@
+// GroupNorm(+SiLU) over NHWC fp16 activations and LayerNorm over token rows.  HBM-bound kernels:
+// every access is a 16-byte vector per lane, reductions are wavefront shuffles + one LDS pass.
+//
+// Replaces the diffusers GroupNorm/SiLU of ResnetBlock2D / Transformer2DModel / conv_norm_out reached from
+// reference src/models/unet.py:244-338 and the three LayerNorms of each BasicTransformerBlock [3P].
+//
+// GroupNorm is three launches: (1) per-(row-chunk, channel) partial sums, deterministic (no atomics);
+// (2) per-(batch, group) mean/rstd folded with gamma/beta into a per-(batch, channel) scale/shift table;
+// (3) y = silu(a*x + s).  The input may be the channel-concat of two tensors (UNet up-path skip joins,
+// reference src/models/unet.py:304-332 -> torch.cat in diffusers up blocks) — the concat is never
+// materialised un-normalised.
+#include "ds_common.h"
+#include "ds_kernels.h"
+
+namespace {
+
+constexpr int GN_MAX_CHUNKS = 128;
+
+__host__ __device__ inline int gn_chunks(int HW) {
+    int n = (HW + 7) / 8;
+    return n < GN_MAX_CHUNKS ? (n < 1 ? 1 : n) : GN_MAX_CHUNKS;
+}
+
+struct GnGeom {
+    int W, R, cc, c, row_start, row_end;
+    bool active;
+};
+__device__ __forceinline__ GnGeom gn_geom(int C, int HW) {
+    GnGeom g;
+    const int ncc = C >> 3;
+    const int slab0 = blockIdx.x * 256;
+    g.W = min(ncc - slab0, 256);
+    g.R = 256 / g.W;
+    const int t = threadIdx.x;
+    const int cw = t % g.W, r = t / g.W;
+    g.active = r < g.R;
+    g.cc = slab0 + cw;
+    g.c = g.cc * 8;
+    const int nch = gridDim.y;
+    const int rpc = (HW + nch - 1) / nch;
+    g.row_start = blockIdx.y * rpc + r;
+    g.row_end = min(HW, (int)(blockIdx.y + 1) * rpc);
+    return g;
+}
+
+__global__ __launch_bounds__(256) void gn_stats_kernel(GroupNormParams p) {
+    __shared__ float red[256 * 16];
+    const int C = p.C1 + p.C2;
+    const GnGeom g = gn_geom(C, p.HW);
+    const int b = blockIdx.z;
+    float s[8], ss[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = ss[e] = 0.f;
+    if (g.active) {
+        const bool first = g.c < p.C1;
+        const half_t* src = first ? p.x1 + (long)b * p.HW * p.C1 + g.c : p.x2 + (long)b * p.HW * p.C2 + (g.c - p.C1);
+        const int ld = first ? p.C1 : p.C2;
+        for (int row = g.row_start; row < g.row_end; row += g.R) {
+            const h8 v = *reinterpret_cast<const h8*>(src + (long)row * ld);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float f = (float)v[e];
+                s[e] += f;
+                ss[e] = fmaf(f, f, ss[e]);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        red[threadIdx.x * 16 + e] = s[e];
+        red[threadIdx.x * 16 + 8 + e] = ss[e];
+    }
+    __syncthreads();
+    if (threadIdx.x < g.W) {
+        float a[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) a[e] = 0.f;
+        for (int r = 0; r < g.R; ++r)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) a[e] += red[(r * g.W + threadIdx.x) * 16 + e];
+        // partial[b][chunk][c][2]
+        float* dst = p.ws + (((long)b * gridDim.y + blockIdx.y) * C + g.c) * 2;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            dst[2 * e] = a[e];
+            dst[2 * e + 1] = a[8 + e];
+        }
+    }
+}
+
+// one block per batch item; wave w handles groups w, w+4, ...
+__global__ __launch_bounds__(256) void gn_finalize_kernel(GroupNormParams p, int nchunks) {
+    const int C = p.C1 + p.C2;
+    const int b = blockIdx.x;
+    const int cpg = C / p.groups;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* part = p.ws + (long)b * nchunks * C * 2;
+    float* tabA = p.ws + (long)gridDim.x * nchunks * C * 2 + (long)b * C * 2;
+    float* tabS = tabA + C;
+    const float inv_n = 1.0f / ((float)cpg * (float)p.HW);
+    for (int g = wave; g < p.groups; g += 4) {
+        float s = 0.f, ss = 0.f;
+        const int items = nchunks * cpg;
+        for (int i = lane; i < items; i += 64) {
+            const int ch = i / cpg, cc = i - ch * cpg;
+            const float* q = part + ((long)ch * C + g * cpg + cc) * 2;
+            s += q[0];
+            ss += q[1];
+        }
+        s = wave_sum(s);
+        ss = wave_sum(ss);
+        const float mean = s * inv_n;
+        const float var = fmaxf(ss * inv_n - mean * mean, 0.f);
+        const float rstd = rsqrtf(var + p.eps);
+        for (int cc = lane; cc < cpg; cc += 64) {
+            const int c = g * cpg + cc;
+            const float a = rstd * (float)p.gamma[c];
+            tabA[c] = a;
+            tabS[c] = (float)p.beta[c] - mean * a;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(GroupNormParams p, int nchunks_stats) {
+    const int C = p.C1 + p.C2;
+    const GnGeom g = gn_geom(C, p.HW);
+    const int b = blockIdx.z;
+    if (!g.active) return;
+    const float* tabA = p.ws + (long)gridDim.z * nchunks_stats * C * 2 + (long)b * C * 2;
+    const float* tabS = tabA + C;
+    float a[8], s[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        a[e] = tabA[g.c + e];
+        s[e] = tabS[g.c + e];
+    }
+    const bool first = g.c < p.C1;
+    const half_t* src = first ? p.x1 + (long)b * p.HW * p.C1 + g.c : p.x2 + (long)b * p.HW * p.C2 + (g.c - p.C1);
+    const int ld = first ? p.C1 : p.C2;
+    half_t* dst = p.y + (long)b * p.HW * C + g.c;
+    for (int row = g.row_start; row < g.row_end; row += g.R) {
+        const h8 v = *reinterpret_cast<const h8*>(src + (long)row * ld);
+        h8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float f = fmaf(a[e], (float)v[e], s[e]);
+            if (p.silu) f = ds_silu(f);
+            o[e] = (half_t)f;
+        }
+        *reinterpret_cast<h8*>(dst + (long)row * C) = o;
+    }
+}
+
+// LayerNorm: one wavefront per row, the row lives in registers (two-pass variance, like torch).
+template <int MAXCH>
+__global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict__ x, half_t* __restrict__ y,
+                                                        const half_t* __restrict__ gamma,
+                                                        const half_t* __restrict__ beta, int rows, int C, float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= rows) return;
+    const int ncc = C >> 3;
+    const half_t* xr = x + (long)row * C;
+    h8 v[MAXCH];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+        const int cc = lane + 64 * i;
+        if (cc < ncc) {
+            v[i] = *reinterpret_cast<const h8*>(xr + cc * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += (float)v[i][e];
+        }
+    }
+    s = wave_sum(s);
+    const float mean = s / (float)C;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+        const int cc = lane + 64 * i;
+        if (cc < ncc) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = (float)v[i][e] - mean;
+                ss = fmaf(d, d, ss);
+            }
+        }
+    }
+    ss = wave_sum(ss);
+    const float rstd = rsqrtf(ss / (float)C + eps);
+    half_t* yr = y + (long)row * C;
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+        const int cc = lane + 64 * i;
+        if (cc < ncc) {
+            const h8 gv = *reinterpret_cast<const h8*>(gamma + cc * 8);
+            const h8 bv = *reinterpret_cast<const h8*>(beta + cc * 8);
+            h8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (half_t)(((float)v[i][e] - mean) * rstd * (float)gv[e] + (float)bv[e]);
+            *reinterpret_cast<h8*>(yr + cc * 8) = o;
+        }
+    }
+}
+
+}  // namespace
+
+size_t ds_groupnorm_ws_floats(int B, int C) { return (size_t)B * GN_MAX_CHUNKS * C * 2 + (size_t)B * C * 2; }
+
+int ds_launch_groupnorm(const GroupNormParams& p, hipStream_t stream) {
+    const int C = p.C1 + p.C2;
+    DS_REQUIRE(p.B > 0 && p.HW > 0 && C > 0, "groupnorm: empty input");
+    DS_REQUIRE(C % p.groups == 0, "groupnorm: C (%d) not divisible by groups (%d)", C, p.groups);
+    DS_REQUIRE(p.C1 % 8 == 0 && p.C2 % 8 == 0, "groupnorm: channel counts must be multiples of 8");
+    DS_REQUIRE(p.ws != nullptr, "groupnorm: workspace missing");
+    const int nch = gn_chunks(p.HW);
+    const int nslab = ((C >> 3) + 255) / 256;
+    dim3 grid(nslab, nch, p.B);
+    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(p.B), dim3(256), 0, stream, p, nch);
+    hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(256), 0, stream, p, nch);
+    DS_LAUNCH_CHECK();
+    return 0;
+}
+
+int ds_launch_layernorm(const half_t* x, half_t* y, const half_t* gamma, const half_t* beta, int rows, int C,
+                        float eps, hipStream_t stream) {
+    DS_REQUIRE(rows > 0 && C > 0 && C % 8 == 0, "layernorm: bad shape rows=%d C=%d", rows, C);
+    DS_REQUIRE(C <= 8 * 64 * 8, "layernorm: C (%d) > 4096 unsupported", C);
+    dim3 grid((rows + 3) / 4);
+    const int ncc = C >> 3;
+    if (ncc <= 64 * 2)
+        hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, stream, x, y, gamma, beta, rows, C, eps);
+    else if (ncc <= 64 * 4)
+        hipLaunchKernelGGL(layernorm_kernel<4>, grid, dim3(256), 0, stream, x, y, gamma, beta, rows, C, eps);
+    else
+        hipLaunchKernelGGL(layernorm_kernel<8>, grid, dim3(256), 0, stream, x, y, gamma, beta, rows, C, eps);
+    DS_LAUNCH_CHECK();
+    return 0;
+}

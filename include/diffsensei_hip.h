@@ -1,0 +1,172 @@
+/* diffsensei_hip.h — C ABI of the MI355X (gfx950) DiffSensei sampling kernels.
+ *
+ * This is the drop-in boundary for ONE path of jianzongwu/DiffSensei: the SDXL-UNet denoising loop with
+ * region-masked IP-Adapter cross-attention (reference src/pipelines/pipeline_diffsensei.py:310-337,
+ * src/models/unet.py:116-347, src/models/attention_processor.py, src/models/resampler.py).
+ * The reference has no FFI of its own (pure Python over torch/diffusers); these entry points are what a
+ * ctypes binding for that path binds (see INTEGRATION.md for the stub).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (e.g. torch.Tensor.data_ptr()); the library never
+ *     allocates or frees device memory and keeps no reference after the call returns (plans excepted: a plan
+ *     borrows every pointer baked into its ops until ds_plan_destroy);
+ *   - activations are fp16, channels-last: images [B, H*W, C], token matrices [rows, C];
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream); all work is
+ *     asynchronous on it, no hidden synchronisation;
+ *   - return value: 0 = ok, negative = error (message via ds_last_error()); nothing throws or aborts.
+ */
+#ifndef DIFFSENSEI_HIP_H
+#define DIFFSENSEI_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* ds_last_error(void);
+int ds_version(void);
+/* number of HIP devices visible / properties of the current one (sanity for loaders) */
+int ds_device_info(int* cu_count, int* lds_bytes, char* arch_name, int arch_name_len);
+
+/* ------------------------------------------------------------------------------------------------
+ * Operators.  Each replaces the torch call(s) named in its comment.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* y[M,N] = x[M,K] @ w[N,K]^T (+bias[N]) (+residual[M,N]);  geglu != 0: w rows are packed per 128-row tile as
+ * 64 "hidden" + 64 "gate" rows and y[M,N/2] = hidden * gelu(gate).
+ * replaces nn.Linear at reference src/models/attention_processor.py:56,63,64,84,207,225,226,245,246,261 and the
+ * diffusers GEGLU/FeedForward/proj_in/proj_out linears reached from src/models/unet.py:244-338.
+ * x2/k1: optional second A source for columns k >= k1 (channel concat of two tensors without a copy). */
+int ds_gemm_f16(const void* x, int64_t ldx, const void* x2, int64_t ldx2, int k1, const void* w, int64_t ldw,
+                const void* bias, const void* residual, int64_t ldr, void* y, int64_t ldy, int M, int N, int K,
+                int geglu, void* stream);
+
+/* batched variant: grid.z = batch with element strides (0 = shared operand); used for V^T = Wv @ X_b^T */
+int ds_gemm_f16_batched(const void* x, int64_t ldx, int64_t sx, const void* w, int64_t ldw, int64_t sw, void* y,
+                        int64_t ldy, int64_t sy, int M, int N, int K, int batch, void* stream);
+
+/* 3x3 convolution, pad 1, NHWC: y[B,Ho,Wo,Cout] = conv(x[B,H,W,Cin], w[Cout,3,3,Cin]) + bias
+ * (+ rowbias[b, :] per image — the resnet time_emb_proj term) (+ residual).  stride in {1,2};
+ * upsample != 0 fuses a nearest x2 upsample in front (diffusers Upsample2D).  Cin % 64 == 0.
+ * replaces ResnetBlock2D.conv1/conv2, Downsample2D.conv, Upsample2D.conv reached from src/models/unet.py:244-332. */
+int ds_conv3x3_f16(const void* x, const void* w, const void* bias, const void* rowbias, int64_t rowbias_ld,
+                   const void* residual, void* y, int B, int H, int W, int Cin, int Cout, int stride, int upsample,
+                   void* stream);
+
+/* GroupNorm (+SiLU) over NHWC; x2 (may be NULL) supplies channels C1..C1+C2 (skip concat).  ws: device scratch
+ * of ds_groupnorm_workspace_bytes(B, C1+C2) bytes. */
+size_t ds_groupnorm_workspace_bytes(int B, int C);
+int ds_groupnorm_f16(const void* x1, const void* x2, void* y, const void* gamma, const void* beta, void* ws, int B,
+                     int HW, int C1, int C2, int groups, float eps, int silu, void* stream);
+int ds_layernorm_f16(const void* x, void* y, const void* gamma, const void* beta, int rows, int C, float eps,
+                     void* stream);
+
+/* Flash self-attention, head_dim 64.  q,k: [B,N,ld] with head h at column h*64; vt: [B,heads,64,ldv] (V stored
+ * key-contiguous); o: [B,N,ldo].  replaces F.scaled_dot_product_attention at
+ * reference src/models/attention_processor.py:76-78. */
+int ds_self_attn_f16(const void* q, int64_t ldq, int64_t sq, const void* k, int64_t ldk, int64_t sk, const void* vt,
+                     int64_t ldv, void* o, int64_t ldo, int64_t so, int B, int heads, int Nq, int Nk, float scale,
+                     void* stream);
+
+/* Fused text + region-masked IP cross-attention core of MaskedIPAttnProcessor2_0
+ * (reference src/models/attention_processor.py:235-258 incl. prepare_attention_mask_ip :115-169):
+ *   o = softmax(q kt^T * s) vt  +  ip_scale * softmax(q ki^T * s + M(bbox)) vi
+ * kt/ki: [B,96,C] key panels (rows >= Lt / Li are padding), vtt/vti: [B,C,96] transposed value panels,
+ * bbox: [B,max_ips,4] fp32 relative boxes, (mask_h, mask_w): the grid the reference infers from (N, aspect_ratio).
+ * ip_scale_dev: optional device float overriding ip_scale (lets a captured graph follow set_ip_scale). */
+int ds_masked_ip_attn_f16(const void* q, int64_t ldq, const void* kt, const void* vtt, const void* ki,
+                          const void* vti, const float* bbox, void* o, int64_t ldo, int B, int heads, int N, int Lt,
+                          int Li, int n_dummy, int tok_per_ip, int max_ips, int mask_h, int mask_w, float qk_scale,
+                          float ip_scale, const float* ip_scale_dev, void* stream);
+/* debug/test hook: bit k of flags[b*N+i] = token i inside box k (the reference's inside_bbox_mask) */
+int ds_ip_region_flags(const float* bbox, uint8_t* flags, int B, int N, int max_ips, int mask_h, int mask_w,
+                       void* stream);
+
+/* generic small attention (head_dim <= 128, arbitrary lengths): encoders + perceiver resampler
+ * (reference src/models/resampler.py:67-72).  q/k/v/o: [B,N,ld] with head h at column h*D. */
+int ds_small_attn_f16(const void* q, int64_t ldq, int64_t sq, const void* k, int64_t ldk, int64_t sk, const void* v,
+                      int64_t ldv, int64_t sv, void* o, int64_t ldo, int64_t so, int B, int heads, int Nq, int Nk,
+                      int D, float scale, void* stream);
+
+/* conv_in (Cin=4) fused with UNetMangaModel.encode_dialog_bbox (reference src/models/unet.py:206-210, :88-114).
+ * dialog_boxes: int32 [B,ndialog,4] pixel boxes (x1,y1,x2,y2), already truncated/clamped like the reference. */
+int ds_conv_in_dialog_f16(const void* x, const void* w, const void* bias, const int32_t* dialog_boxes,
+                          const void* dialog_emb, void* y, int B, int H, int W, int Cin, int Cout, int ndialog,
+                          void* stream);
+/* conv_out (Cout=4) on an already GroupNorm+SiLU'd input (reference src/models/unet.py:335-338) */
+int ds_conv_out_f16(const void* x, const void* w, const void* bias, void* y, int B, int H, int W, int Cin, int Cout,
+                    void* stream);
+
+/* y[M,N] = act_out(act_in(x)[M,K] @ w[N,K]^T + bias + addend), M small (time-embedding MLPs, time_emb_proj) */
+int ds_skinny_linear_f16(const void* x, const void* w, const void* bias, const void* addend, void* y, int M, int N,
+                         int K, int silu_in, int silu_out, void* stream);
+
+/* Per-step scalar table (device, fp32, 8 floats per row):
+ *   {timestep, c_in_div, k0, k1, k2, k3, c_in_div_next, guidance_scale}
+ *   Euler: k0 = sigma_i, k1 = sigma_{i+1};  DDIM: k0..k3 = sqrt(a_t), sqrt(1-a_t), sqrt(a_prev), sqrt(1-a_prev)
+ * `step_ctr` (device int32, may be NULL = row 0) selects the row. */
+int ds_timestep_embed_f16(const float* table, const int32_t* step_ctr, void* out, int B, int dim, int flip_sin_to_cos,
+                          float freq_shift, void* stream);
+int ds_add_time_ids_f16(const void* text_embeds, const void* time_ids, void* out, int B, int pooled_dim, int n_ids,
+                        int dim, int flip_sin_to_cos, float freq_shift, void* stream);
+/* classifier-free guidance + scheduler.step + next scale_model_input in one launch
+ * (reference src/pipelines/pipeline_diffsensei.py:315-317, :333-337).  eps: NHWC [2ns,HW,4] (uncond first);
+ * latents: NCHW [ns,4,HW] updated in place; model_in: NHWC [2ns,HW,4].  kind: 0 Euler, 1 DDIM. */
+int ds_cfg_sampler_step_f16(const void* eps, void* latents, void* model_in, const float* table,
+                            const int32_t* step_ctr, int ns, int HW, int kind, int do_cfg, void* stream);
+int ds_prepare_model_input_f16(const void* latents, void* model_in, const float* table, const int32_t* step_ctr,
+                               int ns, int HW, int do_cfg, void* stream);
+int ds_nhwc_to_nchw_f16(const void* x, void* y, int B, int HW, int C, void* stream);
+int ds_nchw_to_nhwc_f16(const void* x, void* y, int B, int HW, int C, void* stream);
+int ds_pad_rows_f16(const void* x, void* y, int B, int rows_in, int rows_out, int row_off, int total_rows, int C,
+                    void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Plans: a static launch list (one UNet forward, or forward + CFG + scheduler step) built once by the host
+ * and replayed with zero host arithmetic — optionally as a captured hipGraph.
+ * ---------------------------------------------------------------------------------------------- */
+enum ds_opcode {
+    DS_OP_GEMM = 1,          /* p: x, x2, w, y, bias, rowbias, residual   l: ldx ldx2 ldw ldy ldr sx sx2 sw sy sr
+                                i: M N K K1 geglu batch rowbias_ld rows_per_group */
+    DS_OP_CONV3X3 = 2,       /* p: x, w, y, bias, rowbias, residual       i: B H W Cin Cout stride upsample rowbias_ld */
+    DS_OP_GROUPNORM = 3,     /* p: x1, x2, y, gamma, beta, ws             i: B HW C1 C2 groups silu   f: eps */
+    DS_OP_LAYERNORM = 4,     /* p: x, y, gamma, beta                      i: rows C                   f: eps */
+    DS_OP_SELF_ATTN = 5,     /* p: q, k, vt, o   l: ldq ldk ldv ldo sq sk so   i: B heads Nq Nk       f: scale */
+    DS_OP_IP_ATTN = 6,       /* p: q, kt, vtt, ki, vti, bbox, o, ip_scale_dev   l: ldq ldo
+                                i: B heads N Lt Li n_dummy tok_per_ip max_ips mask_h mask_w   f: qk_scale ip_scale */
+    DS_OP_CONV_IN = 7,       /* p: x, w, bias, boxes, demb, y             i: B H W Cin Cout ndialog */
+    DS_OP_CONV_OUT = 8,      /* p: x, w, bias, y                          i: B H W Cin Cout */
+    DS_OP_SKINNY = 9,        /* p: x, w, bias, addend, y                  i: M N K silu_in silu_out */
+    DS_OP_TIMESTEP_EMBED = 10, /* p: table, ctr, out                      i: B dim flip               f: freq_shift */
+    DS_OP_ADD_TIME_IDS = 11, /* p: text_embeds, time_ids, out             i: B pooled n_ids dim flip  f: freq_shift */
+    DS_OP_SAMPLER_STEP = 12, /* p: eps, latents, model_in, table, ctr     i: ns HW kind do_cfg */
+    DS_OP_PREP_INPUT = 13,   /* p: latents, model_in, table, ctr          i: ns HW do_cfg */
+    DS_OP_ADVANCE = 14,      /* p: ctr */
+    DS_OP_NHWC2NCHW = 15,    /* p: x, y                                   i: B HW C */
+    DS_OP_NCHW2NHWC = 16,    /* p: x, y                                   i: B HW C */
+    DS_OP_PAD_ROWS = 17,     /* p: x, y                                   i: B rows_in rows_out row_off total_rows C */
+    DS_OP_SMALL_ATTN = 18    /* p: q, k, v, o   l: ldq ldk ldv ldo sq sk sv so   i: B heads Nq Nk D   f: scale */
+};
+
+typedef struct ds_op {
+    int32_t code;
+    int32_t i[16];
+    float f[4];
+    int64_t l[12];
+    void* p[10];
+} ds_op;
+
+typedef struct ds_plan ds_plan;
+int ds_op_run(const ds_op* op, void* stream); /* run one op immediately */
+int ds_plan_create(const ds_op* ops, int n_ops, ds_plan** out);
+int ds_plan_num_ops(const ds_plan* plan);
+int ds_plan_run(ds_plan* plan, void* stream);            /* eager: one launch per op */
+int ds_plan_capture(ds_plan* plan, void* stream);        /* capture the launch list into a hipGraph (once) */
+int ds_plan_replay(ds_plan* plan, void* stream);         /* hipGraphLaunch of the captured graph */
+int ds_plan_destroy(ds_plan* plan);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIFFSENSEI_HIP_H */
