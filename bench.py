@@ -1,0 +1,248 @@
+#!/usr/bin/env python
+"""Headline benchmark: manga panels/sec at 50 denoise steps, 1024x1024, 2 character refs (BASELINE.json `metric`).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE `DiffSenseiPipeline.__call__` over a batch of `--num-samples` panels: character encoders
+(CLIP-H + Magi ViT-MAE + Resampler) -> 50 x (UNet forward on the CFG batch + CFG + scheduler step) on the HIP launch
+plan.  Inputs are synthetic and already resident in HBM where tensors are involved (prompt embeddings, character
+images are 224x224 uint8 that go through the reference's CPU image processors).  Weights: seeded random at the true
+SDXL / CLIP-H / ViT-MAE / Resampler shapes (no checkpoint is reachable offline; throughput is value independent).
+NOT in the timed region (SURVEY.md §8f "next", stated in `config.timed_region`): the two CLIP text encoders
+(prompt embeddings are inputs) and the VAE decode (latents are the output).
+
+N > 1: one process per GPU, weights broadcast from rank 0 over RCCL once (time reported, outside the timed region),
+each rank serves its own requests with no data-path collective -> "scaling": "weak".  Timing: barrier +
+synchronize on both sides, MAX over ranks; value = N * K * num_samples / t.
+
+Extra objects on the JSON line: `roofline` (dominant kernel of the UNet forward, algorithmic flops / HIP-event time
+vs the 2.5 PFLOP/s dense fp16 MFMA peak) and `cpu_baseline` (the fp32 CPU oracle on a bounded sample of
+BASELINE.json configs[0], rank 0 at N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+MFMA_PEAK_TFLOPS = 2500.0      # dense fp16/bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def build_pipeline(device, num_gpus, rank, seed=0):
+    """Reference construction recipe (scripts/demo/gradio_wo_mllm.py:161-200) with synthetic weights."""
+    from transformers import CLIPVisionConfig, CLIPVisionModel, ViTMAEConfig, ViTMAEModel
+    from diffsensei_amd.distributed import broadcast_tensors
+    from diffsensei_amd.encoders import ClipVisionEngine, ViTMAEEngine
+    from diffsensei_amd.pipeline import DiffSenseiPipeline
+    from diffsensei_amd.resampler import Resampler
+    from diffsensei_amd.schedulers import EulerDiscreteScheduler
+    from diffsensei_amd.unet import UNetMangaModel
+    from diffsensei_amd.unet_config import sdxl_config
+
+    t0 = time.perf_counter()
+    cfg = sdxl_config()
+    unet = UNetMangaModel(cfg, device=device).init_random(seed if rank == 0 else 1000 + rank)
+    torch.manual_seed(seed)
+    clip_cfg = CLIPVisionConfig(hidden_size=1280, intermediate_size=5120, num_hidden_layers=32, num_attention_heads=16,
+                                image_size=224, patch_size=14, hidden_act="gelu", projection_dim=1024)   # ViT-H/14
+    mae_cfg = ViTMAEConfig(hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
+                           image_size=224, patch_size=16, mask_ratio=0.0)                                  # Magi crop encoder
+    with torch.device("cpu"):
+        clip = ClipVisionEngine.from_transformers(CLIPVisionModel(clip_cfg).eval(), device)
+        magi = ViTMAEEngine.from_transformers(ViTMAEModel(mae_cfg).eval(), device)
+    resampler = Resampler(dim=1280, depth=4, dim_head=64, heads=20, num_queries=16, num_dummy_tokens=16,
+                          embedding_dim=1280, magi_embedding_dim=768, output_dim=cfg.cross_attention_dim, ff_mult=4,
+                          device=device).init_random(seed + 1)
+    t_init = time.perf_counter() - t0
+    bstats = {"bytes": 0, "seconds": 0.0, "buckets": 0}
+    if num_gpus > 1:
+        tensors = list(unet._sd.values()) + list(resampler._sd.values())
+        for eng in (clip, magi):
+            for L in eng.layers:
+                tensors += [getattr(L, s) for s in L.__slots__]
+            tensors += [eng.patch_w, eng.cls_row, eng.pos_patches] + [t for t in (eng.patch_b,) if t is not None]
+            for pair in (eng.pre_ln, eng.post_ln):
+                if pair is not None:
+                    tensors += list(pair)
+        dist.barrier()
+        bstats = broadcast_tensors(tensors, src=0)
+    pipe = DiffSenseiPipeline(vae=None, text_encoder=None, text_encoder_2=None, tokenizer=None, tokenizer_2=None,
+                              scheduler=EulerDiscreteScheduler(), unet=unet, image_encoder=clip)
+    pipe.register_manga_modules(magi_image_encoder=magi, image_proj_model=resampler)
+    return pipe, {"init_s": round(t_init, 2), "broadcast_bytes": bstats["bytes"],
+                  "broadcast_ms": round(bstats["seconds"] * 1e3, 2), "broadcast_buckets": bstats["buckets"]}
+
+
+def synthetic_request(device, size, seed):
+    import numpy as np
+    from PIL import Image
+    g = torch.Generator().manual_seed(seed)
+    rng = np.random.RandomState(seed)
+    imgs = [Image.fromarray(rng.randint(0, 256, (224, 224, 3), dtype=np.uint8)) for _ in range(2)]
+    return dict(
+        prompt="A young man with a surprised expression holding a baby on his back", height=size, width=size,
+        num_inference_steps=50, guidance_scale=7.5, ip_images=imgs,
+        ip_bbox=[[0.05, 0.10, 0.50, 0.95], [0.50, 0.10, 0.95, 0.95]], ip_scale=0.6,
+        dialog_bbox=[[0.05, 0.02, 0.30, 0.15], [0.65, 0.02, 0.95, 0.15]],
+        prompt_embeds=torch.randn(1, 77, 2048, generator=g).half().to(device),
+        pooled_prompt_embeds=torch.randn(1, 1280, generator=g).half().to(device),
+        generator=torch.Generator().manual_seed(seed), output_type="latent")
+
+
+def profile_forward_ops(pipe, reps=3):
+    """HIP-event time of every op of the UNet forward plan, on the stream the kernels are launched on; grouped by
+    the gfx950 kernel they dispatch to.  Returns (per-kernel table, forward_ms)."""
+    from diffsensei_amd import _lib
+    lib = _lib.load()
+    eng = next(iter(pipe.unet._engines.values()))
+    ops = eng.forward_ops
+    st = torch.cuda.Stream()
+    n = len(ops)
+    acc = [0.0] * n
+    with torch.cuda.stream(st):
+        for rep in range(reps + 1):
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+            evs[0].record(st)
+            for k, op in enumerate(ops):
+                rc = lib.ds_op_run(C.byref(op), st.cuda_stream)
+                assert rc == 0, lib.ds_last_error()
+                evs[k + 1].record(st)
+            st.synchronize()
+            if rep:  # first pass warms caches
+                for k in range(n):
+                    acc[k] += evs[k].elapsed_time(evs[k + 1])
+    table = {}
+    name = C.create_string_buffer(96)
+    fl, by = C.c_double(), C.c_double()
+    for k, op in enumerate(ops):
+        lib.ds_op_describe(C.byref(op), name, 96, C.byref(fl), C.byref(by))
+        d = table.setdefault(name.value.decode(), {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+        d["launches"] += 1
+        d["ms"] += acc[k] / reps
+        d["flops"] += fl.value
+        d["bytes"] += by.value
+    return table, sum(acc) / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--num-samples", type=int, default=int(os.environ.get("DS_BENCH_NUM_SAMPLES", "4")))
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    from diffsensei_amd.distributed import init_from_env
+    rank, world, local = init_from_env("nccl" if args.gpus > 1 else None)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    from diffsensei_amd import build as _build
+    if rank == 0:
+        _build.build(verbose=False)
+    if world > 1:
+        dist.barrier()
+
+    pipe, setup = build_pipeline(device, world, rank)
+    ns = args.num_samples
+    req = synthetic_request(device, args.size, seed=1234 + rank)
+
+    def one_step():
+        out = pipe(num_samples=ns, **req)
+        return out.images
+
+    for _ in range(args.warmup):
+        one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        lat = one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert torch.isfinite(lat.float()).all(), "non-finite latents"
+    panels = world * args.steps * ns
+    value = panels / dt
+
+    roofline = None
+    extra = {}
+    if rank == 0 and not args.no_roofline:
+        table, fwd_ms = profile_forward_ops(pipe)
+        dom = max(table.items(), key=lambda kv: kv[1]["ms"])
+        name, d = dom
+        ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None, "kernel": name,
+                    "launches_per_forward": d["launches"], "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 2),
+                    "algorithmic_tflop_per_forward": round(d["flops"] / 1e12, 3)}
+        tot_fl = sum(v["flops"] for v in table.values())
+        extra = {"unet_forward_ms_event_sum": round(fwd_ms, 3),
+                 "unet_forward_algorithmic_tflop": round(tot_fl / 1e12, 2),
+                 "unet_forward_tflops": round(tot_fl / (fwd_ms * 1e-3) / 1e12, 1),
+                 "per_kernel": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
+                                    "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1),
+                                    "gbs": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1)} for k, v in
+                                sorted(table.items(), key=lambda kv: -kv[1]["ms"])}}
+        log(json.dumps(extra, indent=1))
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from diffsensei_amd.unet_config import sdxl_config
+        from oracle.pipeline_ref import time_cpu_baseline
+        sd_cpu = {k: v.float().cpu() for k, v in pipe.unet._sd.items()}
+        cpu_baseline = time_cpu_baseline(sdxl_config(), sd_cpu, 512, 512, 20, budget_s=25.0)
+        cpu_baseline["value"] = round(cpu_baseline["value"], 6)
+
+    if rank == 0:
+        line = {
+            "metric": "manga panels/sec at 50 denoise steps, 1024x1024, 2 char refs",
+            "value": round(value, 4), "unit": "panels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"{args.size}x{args.size}, 50-step Euler, CFG 7.5, 2 character refs (padded to 4) + "
+                                   f"2 dialog boxes, num_samples={ns} per call (UNet batch {2 * ns}), one call per step",
+                       "timed_region": "CLIP-H + ViT-MAE + Resampler character encoding, 50 x (UNet + CFG + scheduler "
+                                       "step); text encoders and VAE decode excluded (inputs: prompt embeddings, "
+                                       "output: latents)",
+                       "num_samples": ns, "unet_batch": 2 * ns, "hipgraph": pipe.last_run_info.get("graph"),
+                       "kernel_launches_per_denoise_step": pipe.last_run_info.get("ops_per_step"),
+                       "weights": "seeded random at SDXL/CLIP-H/ViT-MAE/Resampler shapes", **setup},
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+        }
+        if extra:
+            line["unet_forward"] = {k: extra[k] for k in ("unet_forward_ms_event_sum", "unet_forward_algorithmic_tflop",
+                                                          "unet_forward_tflops")}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,93 @@
+"""ctypes binding of include/diffsensei_hip.h.
+
+The library is the product: if it cannot be loaded this module raises — there is no PyTorch/CPU fallback
+anywhere in `diffsensei_amd` (a silent fallback would void every parity and performance claim).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdiffsensei_hip.so")
+
+vp, i32, i64, f32, sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+
+
+class DsOp(C.Structure):
+    _fields_ = [("code", C.c_int32), ("i", C.c_int32 * 16), ("f", C.c_float * 4), ("l", C.c_int64 * 12),
+                ("p", C.c_void_p * 10)]
+
+
+# opcode values of enum ds_opcode
+OP = dict(GEMM=1, CONV3X3=2, GROUPNORM=3, LAYERNORM=4, SELF_ATTN=5, IP_ATTN=6, CONV_IN=7, CONV_OUT=8, SKINNY=9,
+          TIMESTEP_EMBED=10, ADD_TIME_IDS=11, SAMPLER_STEP=12, PREP_INPUT=13, ADVANCE=14, NHWC2NCHW=15, NCHW2NHWC=16,
+          PAD_ROWS=17, SMALL_ATTN=18)
+
+# name -> (restype, argtypes).  Every symbol declared in include/diffsensei_hip.h appears here;
+# tests/test_capi_symbols.py checks the two lists against each other.
+SIGNATURES = {
+    "ds_last_error": (C.c_char_p, []),
+    "ds_version": (i32, []),
+    "ds_device_info": (i32, [C.POINTER(i32), C.POINTER(i32), C.c_char_p, i32]),
+    "ds_gemm_f16": (i32, [vp, i64, vp, i64, i32, vp, i64, vp, vp, i64, vp, i64, i32, i32, i32, i32, vp]),
+    "ds_gemm_f16_batched": (i32, [vp, i64, i64, vp, i64, i64, vp, i64, i64, i32, i32, i32, i32, vp]),
+    "ds_conv3x3_f16": (i32, [vp, vp, vp, vp, i64, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "ds_groupnorm_workspace_bytes": (sz, [i32, i32]),
+    "ds_groupnorm_f16": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp]),
+    "ds_layernorm_f16": (i32, [vp, vp, vp, vp, i32, i32, f32, vp]),
+    "ds_self_attn_f16": (i32, [vp, i64, i64, vp, i64, i64, vp, i64, vp, i64, i64, i32, i32, i32, i32, f32, vp]),
+    "ds_masked_ip_attn_f16": (i32, [vp, i64, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32,
+                                    i32, f32, f32, vp, i64, i64, i64, vp]),
+    "ds_ip_region_flags": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    "ds_small_attn_f16": (i32, [vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, i32, i32, i32, i32, i32, f32,
+                                vp]),
+    "ds_conv_in_dialog_f16": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "ds_conv_out_f16": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "ds_skinny_linear_f16": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "ds_timestep_embed_f16": (i32, [vp, vp, vp, i32, i32, i32, f32, vp]),
+    "ds_add_time_ids_f16": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, f32, vp]),
+    "ds_cfg_sampler_step_f16": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "ds_prepare_model_input_f16": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
+    "ds_nhwc_to_nchw_f16": (i32, [vp, vp, i32, i32, i32, vp]),
+    "ds_nchw_to_nhwc_f16": (i32, [vp, vp, i32, i32, i32, vp]),
+    "ds_pad_rows_f16": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "ds_op_run": (i32, [C.POINTER(DsOp), vp]),
+    "ds_op_describe": (i32, [C.POINTER(DsOp), C.c_char_p, i32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "ds_plan_create": (i32, [C.POINTER(DsOp), i32, C.POINTER(vp)]),
+    "ds_plan_num_ops": (i32, [vp]),
+    "ds_plan_run": (i32, [vp, vp]),
+    "ds_plan_capture": (i32, [vp, vp]),
+    "ds_plan_replay": (i32, [vp, vp]),
+    "ds_plan_destroy": (i32, [vp]),
+}
+
+_lib = None
+
+
+class DiffSenseiHipError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load libdiffsensei_hip.so (built by `python -m diffsensei_amd.build`); raise loudly when absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DiffSenseiHipError(
+            f"{LIB_PATH} is missing: the HIP kernel library is the only execution path of diffsensei_amd. "
+            f"Build it with `python -m diffsensei_amd.build` (hipcc, --offload-arch=gfx950).")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch, also loud
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().ds_last_error().decode(errors="replace")
+        raise DiffSenseiHipError(f"{what or 'diffsensei_hip'} failed (rc={rc}): {msg}")

@@ -224,17 +224,17 @@ __global__ __launch_bounds__(256, 2) void ip_attn_kernel(const IPAttnParams p, i
 
     // ---- stage the four panels once
     {
-        const half_t* ktp = p.kt + (long)b * LP * p.C + h * 64;
-        const half_t* kip = p.ki + (long)b * LP * p.C + h * 64;
+        const half_t* ktp = p.kt + (long)b * p.sk + h * 64;
+        const half_t* kip = p.ki + (long)b * p.sk + h * 64;
         for (int id = tid; id < LP * 8; id += 256) {
             const int row = id >> 3, c = id & 7;
             *reinterpret_cast<h8*>(&sKt[row * 128 + swz(row, c)]) =
-                *reinterpret_cast<const h8*>(ktp + (long)row * p.C + c * 8);
+                *reinterpret_cast<const h8*>(ktp + (long)row * p.ldk + c * 8);
             *reinterpret_cast<h8*>(&sKi[row * 128 + swz(row, c)]) =
-                *reinterpret_cast<const h8*>(kip + (long)row * p.C + c * 8);
+                *reinterpret_cast<const h8*>(kip + (long)row * p.ldk + c * 8);
         }
-        const half_t* vtp = p.vtt + ((long)b * p.C + h * 64) * LP;
-        const half_t* vip = p.vti + ((long)b * p.C + h * 64) * LP;
+        const half_t* vtp = p.vtt + (long)b * p.sv + (long)(h * 64) * LP;
+        const half_t* vip = p.vti + (long)b * p.sv + (long)(h * 64) * LP;
         for (int id = tid; id < 64 * 12; id += 256) {
             const int row = id / 12, c = id - row * 12;
             const h8 a = *reinterpret_cast<const h8*>(vtp + (long)row * LP + c * 8);
@@ -416,7 +416,12 @@ int ds_launch_self_attn(const SelfAttnParams& p, hipStream_t stream) {
     return 0;
 }
 
-int ds_launch_ip_attn(const IPAttnParams& p, hipStream_t stream) {
+int ds_launch_ip_attn(const IPAttnParams& p0, hipStream_t stream) {
+    IPAttnParams p = p0;
+    if (p.ldk == 0) p.ldk = p.C;
+    if (p.sk == 0) p.sk = (long)LP * p.C;
+    if (p.sv == 0) p.sv = (long)LP * p.C;
+    DS_REQUIRE(p.ldk % 8 == 0 && p.sk % 8 == 0 && p.sv % 8 == 0, "ip_attn: key/value panel strides must be multiples of 8");
     DS_REQUIRE(p.B > 0 && p.heads > 0 && p.N > 0, "ip_attn: empty problem");
     DS_REQUIRE(p.LP == LP, "ip_attn: key panels must be padded to %d rows (got %d)", LP, p.LP);
     DS_REQUIRE(p.Lt > 0 && p.Lt <= LP && p.Li > 0 && p.Li <= LP, "ip_attn: Lt=%d Li=%d exceed %d", p.Lt, p.Li, LP);

@@ -43,11 +43,11 @@ int ds_device_info(int* cu_count, int* lds_bytes, char* arch_name, int arch_name
 
 int ds_gemm_f16(const void* x, int64_t ldx, const void* x2, int64_t ldx2, int k1, const void* w, int64_t ldw,
                 const void* bias, const void* residual, int64_t ldr, void* y, int64_t ldy, int M, int N, int K,
-                int geglu, void* stream) {
+                int epilogue, void* stream) {
     GemmParams p;
     p.A = H(x); p.lda = ldx; p.A2 = H(x2); p.lda2 = ldx2; p.K1 = x2 ? k1 : K;
     p.W = H(w); p.ldw = ldw; p.bias = H(bias); p.residual = H(residual); p.ldr = ldr;
-    p.C = HM(y); p.ldc = ldy; p.M = M; p.N = N; p.K = K; p.epi = geglu ? EPI_GEGLU : EPI_NONE;
+    p.C = HM(y); p.ldc = ldy; p.M = M; p.N = N; p.K = K; p.epi = epilogue;
     return ds_launch_gemm(p, 1, S(stream));
 }
 
@@ -110,8 +110,10 @@ int ds_self_attn_f16(const void* q, int64_t ldq, int64_t sq, const void* k, int6
 int ds_masked_ip_attn_f16(const void* q, int64_t ldq, const void* kt, const void* vtt, const void* ki,
                           const void* vti, const float* bbox, void* o, int64_t ldo, int B, int heads, int N, int Lt,
                           int Li, int n_dummy, int tok_per_ip, int max_ips, int mask_h, int mask_w, float qk_scale,
-                          float ip_scale, const float* ip_scale_dev, void* stream) {
+                          float ip_scale, const float* ip_scale_dev, int64_t ldk, int64_t sk, int64_t sv,
+                          void* stream) {
     IPAttnParams p;
+    p.ldk = ldk; p.sk = sk; p.sv = sv;
     p.q = H(q); p.kt = H(kt); p.vtt = H(vtt); p.ki = H(ki); p.vti = H(vti); p.bbox = bbox; p.o = HM(o);
     p.ldq = ldq; p.ldo = ldo; p.B = B; p.heads = heads; p.N = N; p.C = heads * 64;
     p.Lt = Lt; p.Li = Li; p.LP = 96; p.n_dummy = n_dummy; p.tok_per_ip = tok_per_ip; p.max_ips = max_ips;
@@ -196,7 +198,7 @@ static int run_op(const ds_op& o, hipStream_t st) {
             g.lda = l[0]; g.lda2 = l[1]; g.ldw = l[2]; g.ldc = l[3]; g.ldr = l[4];
             g.sA = l[5]; g.sA2 = l[6]; g.sW = l[7]; g.sC = l[8]; g.sR = l[9];
             g.M = i[0]; g.N = i[1]; g.K = i[2]; g.K1 = g.A2 ? i[3] : i[2];
-            g.epi = i[4] ? EPI_GEGLU : EPI_NONE;
+            g.epi = i[4];
             g.rowbias_ld = i[6]; g.rows_per_group = i[7] > 0 ? i[7] : 1;
             return ds_launch_gemm(g, i[5] > 0 ? i[5] : 1, st);
         }
@@ -223,7 +225,7 @@ static int run_op(const ds_op& o, hipStream_t st) {
             a.q = H(p[0]); a.kt = H(p[1]); a.vtt = H(p[2]); a.ki = H(p[3]); a.vti = H(p[4]);
             a.bbox = reinterpret_cast<const float*>(p[5]); a.o = HM(p[6]);
             a.ip_scale_ptr = reinterpret_cast<const float*>(p[7]);
-            a.ldq = l[0]; a.ldo = l[1];
+            a.ldq = l[0]; a.ldo = l[1]; a.ldk = l[2]; a.sk = l[3]; a.sv = l[4];
             a.B = i[0]; a.heads = i[1]; a.N = i[2]; a.C = i[1] * 64; a.Lt = i[3]; a.Li = i[4]; a.LP = 96;
             a.n_dummy = i[5]; a.tok_per_ip = i[6]; a.max_ips = i[7]; a.mask_h = i[8]; a.mask_w = i[9];
             a.qk_scale = o.f[0]; a.ip_scale = o.f[1];
@@ -265,6 +267,61 @@ static int run_op(const ds_op& o, hipStream_t st) {
             ds_set_error("plan: unknown opcode %d", o.code);
             return -4;
     }
+}
+
+// Static description of one op for roofline accounting: the gfx950 kernel it dispatches to (same spelling as the
+// rocprofv3 kernel trace), its ALGORITHMIC flops (2*MAC) and its algorithmic HBM bytes (each operand once).
+int ds_op_describe(const ds_op* op, char* name, int name_len, double* flops, double* bytes) {
+    DS_REQUIRE(op != nullptr, "ds_op_describe: null op");
+    const int32_t* i = op->i;
+    const char* nm = "other";
+    double fl = 0, by = 0;
+    switch (op->code) {
+        case DS_OP_GEMM: {
+            GemmParams g;
+            g.M = i[0]; g.N = i[1]; g.K = i[2];
+            const int batch = i[5] > 0 ? i[5] : 1;
+            nm = ds_gemm_uses_small_tile(g, batch) ? "gemm_f16_kernel<64,false>" : "gemm_f16_kernel<128,false>";
+            fl = 2.0 * i[0] * (double)i[1] * i[2] * batch;
+            by = 2.0 * batch * ((double)i[0] * i[2] + (double)i[1] * i[2] + (double)i[0] * (i[4] == 1 ? i[1] / 2 : i[1]));
+            break;
+        }
+        case DS_OP_CONV3X3: {
+            GemmParams g;
+            const int Ho = i[6] ? 2 * i[1] : (i[5] == 2 ? (i[1] + 1) / 2 : i[1]);
+            const int Wo = i[6] ? 2 * i[2] : (i[5] == 2 ? (i[2] + 1) / 2 : i[2]);
+            g.M = i[0] * Ho * Wo; g.N = i[4]; g.K = 9 * i[3];
+            nm = ds_gemm_uses_small_tile(g, 1) ? "gemm_f16_kernel<64,true>" : "gemm_f16_kernel<128,true>";
+            fl = 2.0 * g.M * (double)g.N * g.K;
+            by = 2.0 * ((double)i[0] * i[1] * i[2] * i[3] + (double)g.N * g.K + (double)g.M * g.N);
+            break;
+        }
+        case DS_OP_GROUPNORM: nm = "groupnorm(3 kernels)"; by = 2.0 * 2.0 * i[0] * (double)i[1] * (i[2] + i[3]); break;
+        case DS_OP_LAYERNORM: nm = "layernorm_kernel"; by = 2.0 * 2.0 * i[0] * (double)i[1]; break;
+        case DS_OP_SELF_ATTN:
+            nm = "self_attn_kernel";
+            fl = 4.0 * i[0] * (double)i[1] * i[2] * (double)i[3] * 64;
+            by = 2.0 * i[0] * (double)i[1] * 64 * (2.0 * i[2] + 2.0 * i[3]);
+            break;
+        case DS_OP_IP_ATTN:
+            nm = "ip_attn_kernel";
+            fl = 4.0 * i[0] * (double)i[1] * i[2] * (double)(i[3] + i[4]) * 64;
+            by = 2.0 * i[0] * (double)i[1] * 64 * (2.0 * i[2] + 2.0 * (i[3] + i[4]));
+            break;
+        case DS_OP_SMALL_ATTN: nm = "small_attn_kernel"; fl = 4.0 * i[0] * (double)i[1] * i[2] * (double)i[3] * i[4]; break;
+        case DS_OP_CONV_IN: nm = "conv_in_kernel"; fl = 2.0 * i[0] * (double)i[1] * i[2] * 9 * i[3] * i[4]; break;
+        case DS_OP_CONV_OUT: nm = "conv_out_kernel"; fl = 2.0 * i[0] * (double)i[1] * i[2] * 9 * i[3] * i[4]; break;
+        case DS_OP_SKINNY: nm = "skinny_linear_kernel"; fl = 2.0 * i[0] * (double)i[1] * i[2]; by = 2.0 * i[1] * (double)i[2]; break;
+        case DS_OP_SAMPLER_STEP: nm = "sampler_step_kernel"; break;
+        default: break;
+    }
+    if (name && name_len > 0) {
+        strncpy(name, nm, name_len - 1);
+        name[name_len - 1] = 0;
+    }
+    if (flops) *flops = fl;
+    if (bytes) *bytes = by;
+    return 0;
 }
 
 struct ds_plan {

@@ -2,7 +2,7 @@
 #pragma once
 #include "ds_common.h"
 
-enum { EPI_NONE = 0, EPI_GEGLU = 1 };
+enum { EPI_NONE = 0, EPI_GEGLU = 1, EPI_GELU = 2, EPI_QUICK_GELU = 3 };
 
 struct GemmParams {
     const half_t* A = nullptr;   // plain: [M,K] rows (lda);  conv: NHWC input [B,Hin,Win,Cin]
@@ -22,6 +22,7 @@ struct GemmParams {
     int tiles_m = 0, tiles_n = 0;
 };
 int ds_launch_gemm(const GemmParams& p, int batch, hipStream_t stream);
+bool ds_gemm_uses_small_tile(const GemmParams& p, int batch);
 
 // ---- normalisation ---------------------------------------------------------------------------------
 struct GroupNormParams {
@@ -62,6 +63,8 @@ struct IPAttnParams {
     const float* bbox = nullptr;   // [B,max_ips,4]
     half_t* o = nullptr;           // [B,N,C] rows (ldo)
     long ldq = 0, ldo = 0;
+    long ldk = 0, sk = 0;          // key panels: row stride / batch stride (elements); 0 -> dense [B,LP,C]
+    long sv = 0;                   // value panels: batch stride (elements); 0 -> dense [B,C,LP]
     int B = 0, heads = 0, N = 0, C = 0;
     int Lt = 77, Li = 80, LP = 96;
     int n_dummy = 16, tok_per_ip = 16, max_ips = 4;

@@ -243,6 +243,16 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const GemmParams p) {
             const int m = m0 + row, n = n0 + c * 8;
             if (m < p.M && n < p.N) {
                 h8 v = *reinterpret_cast<const h8*>(sC + row * CS_STRIDE + c * 16);
+                if (p.epi == EPI_GELU) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (half_t)ds_gelu_erf((float)v[e]);
+                } else if (p.epi == EPI_QUICK_GELU) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float f = (float)v[e];
+                        v[e] = (half_t)(f / (1.0f + __expf(-1.702f * f)));
+                    }
+                }
                 if (Rg) {
                     const h8 rv = *reinterpret_cast<const h8*>(Rg + (long)m * p.ldr + n);
 #pragma unroll
@@ -274,6 +284,12 @@ int launch(const GemmParams& p0, int batch, hipStream_t stream) {
 
 }  // namespace
 
+// pick BM: small problems get 64-row tiles so the grid covers the 256 CUs
+bool ds_gemm_uses_small_tile(const GemmParams& p, int batch) {
+    const long tiles128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * batch;
+    return tiles128 < 384 || p.M <= 64;
+}
+
 int ds_launch_gemm(const GemmParams& p, int batch, hipStream_t stream) {
     DS_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "gemm: empty problem M=%d N=%d K=%d", p.M, p.N, p.K);
     DS_REQUIRE(p.N % 8 == 0 && p.K % 8 == 0, "gemm: N (%d) and K (%d) must be multiples of 8", p.N, p.K);
@@ -288,9 +304,7 @@ int ds_launch_gemm(const GemmParams& p, int batch, hipStream_t stream) {
         DS_REQUIRE(p.A2 == nullptr || (p.K1 % 64 == 0 && p.lda2 % 8 == 0), "gemm: split-A needs K1 %% 64 == 0");
     }
     if (p.epi == EPI_GEGLU) DS_REQUIRE(p.N % 128 == 0, "geglu: packed N (%d) must be a multiple of 128", p.N);
-    // pick BM: small problems get 64-row tiles so the grid covers the 256 CUs
-    const long tiles128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * batch;
-    const bool small = tiles128 < 384 || p.M <= 64;
+    const bool small = ds_gemm_uses_small_tile(p, batch);
     if (conv) return small ? launch<64, true>(p, batch, stream) : launch<128, true>(p, batch, stream);
     return small ? launch<64, false>(p, batch, stream) : launch<128, false>(p, batch, stream);
 }

@@ -1,0 +1,534 @@
+"""UNet launch-plan builder: packs the diffusers-layout state dict for the HIP kernels and emits the flat
+op list (`ds_op[]`) that the C++ plan executor replays for one `UNetMangaModel.forward`
+(reference src/models/unet.py:185-338) and, for sampling, forward + CFG + scheduler step
+(reference src/pipelines/pipeline_diffsensei.py:310-337).
+
+Host work happens ONCE per (batch, height, width) bucket; the steady state is `ds_plan_run/replay`.
+Per-request constants are hoisted out of the step loop (the reference recomputes them every layer of every
+step): text/IP key and value projections for all cross-attention layers (4 stacked GEMMs), the `text_time`
+added-condition embedding, and the region-mask geometry.
+
+HBM layout: activations fp16 channels-last [B*H*W, C] (a conv output IS the token matrix of the following
+transformer); conv weights [Cout, 3*3*Cin]; V operands of attention stored key-contiguous.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import OP, DsOp, check
+from .attention_processor import mask_grid_size
+from .unet_config import AttnSpec, ResnetSpec, UNetMangaConfig, build_topology
+
+Tensor = torch.Tensor
+LP = 96  # padded key-panel length of the fused cross-attention kernel
+
+
+# ------------------------------------------------------------------------------------------ weight packing
+def pack_conv3x3(w: Tensor) -> Tensor:
+    """[Cout,Cin,3,3] -> [Cout, 9*Cin] with k = (ky*3+kx)*Cin + ci (matches the NHWC implicit-GEMM gather)."""
+    return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
+
+
+def pack_geglu(w: Tensor, b: Tensor) -> Tuple[Tensor, Tensor]:
+    """GEGLU proj [8C,C]: rows [0,4C) 'hidden', [4C,8C) 'gate' -> per 128-row tile 64 hidden rows + their 64 gate rows."""
+    half = w.shape[0] // 2
+    assert half % 64 == 0, "GEGLU inner dim must be a multiple of 64"
+    t = half // 64
+    wp = torch.stack([w[:half].reshape(t, 64, -1), w[half:].reshape(t, 64, -1)], dim=1).reshape(2 * half, -1)
+    bp = torch.stack([b[:half].reshape(t, 64), b[half:].reshape(t, 64)], dim=1).reshape(2 * half)
+    return wp.contiguous(), bp.contiguous()
+
+
+class PackedUNet:
+    """Device-resident fp16 weights in kernel layout.  `names` follow the diffusers state dict."""
+
+    def __init__(self, cfg: UNetMangaConfig, sd: Dict[str, Tensor], device: torch.device):
+        self.cfg = cfg
+        self.device = device
+        self.topo = build_topology(cfg)
+        self.w: Dict[str, Tensor] = {}
+        f16 = lambda t: t.detach().to(device=device, dtype=torch.float16).contiguous()
+
+        def put(name, t):
+            self.w[name] = f16(t)
+
+        resnets: List[ResnetSpec] = []
+        attns: List[AttnSpec] = []
+        for blk in self.topo.down:
+            resnets += blk["resnets"]
+            attns += blk["attns"]
+        resnets += self.topo.mid["resnets"]
+        attns += self.topo.mid["attns"]
+        for blk in self.topo.up:
+            resnets += blk["resnets"]
+            attns += blk["attns"]
+        self.resnets, self.attns = resnets, attns
+
+        put("conv_in.weight", pack_conv3x3(sd["conv_in.weight"]))
+        put("conv_in.bias", sd["conv_in.bias"])
+        put("conv_out.weight", pack_conv3x3(sd["conv_out.weight"]))
+        put("conv_out.bias", sd["conv_out.bias"])
+        for n in ("conv_norm_out.weight", "conv_norm_out.bias", "dialog_bbox_embedding",
+                  "time_embedding.linear_1.weight", "time_embedding.linear_1.bias",
+                  "time_embedding.linear_2.weight", "time_embedding.linear_2.bias",
+                  "add_embedding.linear_1.weight", "add_embedding.linear_1.bias",
+                  "add_embedding.linear_2.weight", "add_embedding.linear_2.bias"):
+            put(n, sd[n])
+        # resnets; all time_emb_proj stacked into one [sum Cout, temb] matrix (one skinny GEMM per forward)
+        tw, tb, off = [], [], 0
+        self.temb_off: Dict[str, int] = {}
+        for r in resnets:
+            p = r.prefix
+            for n in ("norm1", "norm2"):
+                put(f"{p}.{n}.weight", sd[f"{p}.{n}.weight"])
+                put(f"{p}.{n}.bias", sd[f"{p}.{n}.bias"])
+            put(f"{p}.conv1.weight", pack_conv3x3(sd[f"{p}.conv1.weight"]))
+            put(f"{p}.conv1.bias", sd[f"{p}.conv1.bias"])
+            put(f"{p}.conv2.weight", pack_conv3x3(sd[f"{p}.conv2.weight"]))
+            put(f"{p}.conv2.bias", sd[f"{p}.conv2.bias"])
+            if r.has_shortcut:
+                put(f"{p}.conv_shortcut.weight", sd[f"{p}.conv_shortcut.weight"].reshape(r.cout, r.cin))
+                put(f"{p}.conv_shortcut.bias", sd[f"{p}.conv_shortcut.bias"])
+            tw.append(sd[f"{p}.time_emb_proj.weight"])
+            tb.append(sd[f"{p}.time_emb_proj.bias"])
+            self.temb_off[p] = off
+            off += r.cout
+        self.temb_total = off
+        put("temb_all.weight", torch.cat([t.to(device) for t in tw], 0))
+        put("temb_all.bias", torch.cat([t.to(device) for t in tb], 0))
+        for blk in self.topo.down:
+            if blk["downsample"]:
+                put(blk["downsample"] + ".weight", pack_conv3x3(sd[blk["downsample"] + ".weight"]))
+                put(blk["downsample"] + ".bias", sd[blk["downsample"] + ".bias"])
+        for blk in self.topo.up:
+            if blk["upsample"]:
+                put(blk["upsample"] + ".weight", pack_conv3x3(sd[blk["upsample"] + ".weight"]))
+                put(blk["upsample"] + ".bias", sd[blk["upsample"] + ".bias"])
+        # transformers; cross-attention K/V projections of ALL layers stacked (hoisted out of the step loop)
+        kt, vt, ki, vi, off = [], [], [], [], 0
+        self.kv_off: Dict[str, int] = {}
+        for a in attns:
+            p = a.prefix
+            for n in ("norm.weight", "norm.bias", "proj_in.weight", "proj_in.bias", "proj_out.weight", "proj_out.bias"):
+                put(f"{p}.{n}", sd[f"{p}.{n}"])
+            for k in range(a.depth):
+                t = f"{p}.transformer_blocks.{k}"
+                for n in ("norm1", "norm2", "norm3"):
+                    put(f"{t}.{n}.weight", sd[f"{t}.{n}.weight"])
+                    put(f"{t}.{n}.bias", sd[f"{t}.{n}.bias"])
+                put(f"{t}.attn1.qk.weight", torch.cat([sd[f"{t}.attn1.to_q.weight"].to(device),
+                                                       sd[f"{t}.attn1.to_k.weight"].to(device)], 0))
+                put(f"{t}.attn1.to_v.weight", sd[f"{t}.attn1.to_v.weight"])
+                put(f"{t}.attn1.to_out.0.weight", sd[f"{t}.attn1.to_out.0.weight"])
+                put(f"{t}.attn1.to_out.0.bias", sd[f"{t}.attn1.to_out.0.bias"])
+                put(f"{t}.attn2.to_q.weight", sd[f"{t}.attn2.to_q.weight"])
+                put(f"{t}.attn2.to_out.0.weight", sd[f"{t}.attn2.to_out.0.weight"])
+                put(f"{t}.attn2.to_out.0.bias", sd[f"{t}.attn2.to_out.0.bias"])
+                kt.append(sd[f"{t}.attn2.to_k.weight"])
+                vt.append(sd[f"{t}.attn2.to_v.weight"])
+                ki.append(sd[f"{t}.attn2.processor.to_k_ip.weight"])
+                vi.append(sd[f"{t}.attn2.processor.to_v_ip.weight"])
+                self.kv_off[t] = off
+                off += a.channels
+                wp, bp = pack_geglu(sd[f"{t}.ff.net.0.proj.weight"].to(device), sd[f"{t}.ff.net.0.proj.bias"].to(device))
+                put(f"{t}.ff.net.0.proj.weight", wp)
+                put(f"{t}.ff.net.0.proj.bias", bp)
+                put(f"{t}.ff.net.2.weight", sd[f"{t}.ff.net.2.weight"])
+                put(f"{t}.ff.net.2.bias", sd[f"{t}.ff.net.2.bias"])
+        self.kv_total = off
+        for name, lst in (("xattn.k_text", kt), ("xattn.v_text", vt), ("xattn.k_ip", ki), ("xattn.v_ip", vi)):
+            put(name, torch.cat([t.to(device) for t in lst], 0))
+
+    def nbytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in self.w.values())
+
+    def all_tensors(self) -> List[Tensor]:
+        return list(self.w.values())
+
+
+# ------------------------------------------------------------------------------------------ op helpers
+def _ptr(x) -> Optional[int]:
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return x
+    return x.data_ptr()
+
+
+def make_op(code: str, i=(), f=(), l=(), p=()) -> DsOp:
+    op = DsOp()
+    op.code = OP[code]
+    for k, v in enumerate(i):
+        op.i[k] = int(v)
+    for k, v in enumerate(f):
+        op.f[k] = float(v)
+    for k, v in enumerate(l):
+        op.l[k] = int(v)
+    for k, v in enumerate(p):
+        op.p[k] = _ptr(v)
+    return op
+
+
+class Plan:
+    """Owns a ds_plan* plus every tensor whose pointer is baked into it."""
+
+    def __init__(self, ops: List[DsOp], keep: list):
+        self.lib = _lib.load()
+        self.n = len(ops)
+        arr = (DsOp * self.n)(*ops)
+        h = C.c_void_p()
+        check(self.lib.ds_plan_create(arr, self.n, C.byref(h)), "ds_plan_create")
+        self.handle = h
+        self.keep = keep
+        self.captured = False
+
+    def run(self, stream: Optional[int] = None):
+        s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        check(self.lib.ds_plan_run(self.handle, s), "ds_plan_run")
+
+    def capture(self, stream: int):
+        check(self.lib.ds_plan_capture(self.handle, stream), "ds_plan_capture")
+        self.captured = True
+
+    def replay(self, stream: Optional[int] = None):
+        s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        check(self.lib.ds_plan_replay(self.handle, s), "ds_plan_replay")
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.ds_plan_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+# ------------------------------------------------------------------------------------------ the engine
+class UNetEngine:
+    """Static-shape execution state for one (batch, latent H, latent W) bucket."""
+
+    def __init__(self, packed: PackedUNet, batch: int, height: int, width: int, aspect_ratio: Optional[float] = None):
+        cfg = packed.cfg
+        if height % 4 or width % 4:
+            raise ValueError(f"latent size {height}x{width}: both sides must be multiples of 4 (image multiples of 32)")
+        self.pk, self.cfg = packed, cfg
+        self.B, self.H, self.W = batch, height, width
+        self.dev = packed.device
+        self.aspect_ratio = aspect_ratio if aspect_ratio is not None else height / width
+        nlev = len(cfg.block_out_channels)
+        self.hw = [(height >> l, width >> l) for l in range(nlev)]
+        for l in range(1, nlev):
+            if (self.hw[l][0] * self.hw[l][1]) % 8:
+                raise ValueError(f"latent {height}x{width}: level {l} has {self.hw[l][0] * self.hw[l][1]} tokens; the "
+                                 f"attention kernels need a multiple of 8 (use image sides that are multiples of 64)")
+        self.keep: list = []
+        B = batch
+        E = lambda *shape, dtype=torch.float16: self._alloc(shape, dtype)
+        c0 = cfg.block_out_channels[0]
+        temb = cfg.time_embed_dim
+        n_txt, n_ip = cfg.num_text_tokens, cfg.num_ip_tokens
+        xdim = cfg.cross_attention_dim
+        # ---- request-level inputs (written by the host before `prepare`)
+        self.enc = E(B, n_txt + n_ip, xdim)                     # encoder_hidden_states = [text | dummy+ip]
+        self.text_embeds = E(B, cfg.projection_class_embeddings_input_dim - 6 * cfg.addition_time_embed_dim)
+        self.time_ids = E(B, 6)
+        self.bbox = E(B, cfg.max_num_ips, 4, dtype=torch.float32)
+        self.dialog_boxes = E(B, cfg.max_num_dialogs, 4, dtype=torch.int32)
+        self.dialog_boxes.zero_()
+        self.ip_scale = E(1, dtype=torch.float32)
+        self.ip_scale.fill_(1.0)
+        self.table = E(1024, 8, dtype=torch.float32)            # per-step scalars (see include/diffsensei_hip.h)
+        self.table.zero_()
+        self.ctr = E(1, dtype=torch.int32)
+        self.ctr.zero_()
+        # ---- request-level derived tensors
+        self.enc_txt = E(B, LP, xdim)
+        self.enc_ip = E(B, LP, xdim)
+        kvt = packed.kv_total
+        self.k_txt = E(B * LP, kvt)
+        self.k_ip = E(B * LP, kvt)
+        self.v_txt = E(B, kvt, LP)
+        self.v_ip = E(B, kvt, LP)
+        self.add_in = E(B, cfg.projection_class_embeddings_input_dim)
+        self.add_h = E(B, temb)
+        self.aug = E(B, temb)
+        # ---- per-forward small tensors
+        self.t_sin = E(B, c0)
+        self.t_h = E(B, temb)
+        self.emb = E(B, temb)
+        self.temb_all = E(B, packed.temb_total)
+        # ---- activations
+        self.x_in = E(B, height * width, cfg.in_channels)
+        self.eps = E(B, height * width, cfg.out_channels)
+        self.gn_ws = self._alloc((_lib.load().ds_groupnorm_workspace_bytes(B, 4 * cfg.block_out_channels[-1]),),
+                                 torch.uint8)
+        self.scratch: Dict[Tuple[str, int], Tensor] = {}
+        self.prepare_plan = self._build_prepare()
+        self.forward_ops = self._build_forward()
+        self.forward_plan = Plan(self.forward_ops, self.keep)
+
+    # -- memory
+    def _alloc(self, shape, dtype) -> Tensor:
+        t = torch.empty(tuple(int(s) for s in shape), dtype=dtype, device=self.dev)
+        self.keep.append(t)
+        return t
+
+    def _buf(self, role: str, level: int, rows: int, cols: int) -> Tensor:
+        """Role-keyed scratch, sized to the largest request per (role, level)."""
+        key = (role, level)
+        need = rows * cols
+        t = self.scratch.get(key)
+        if t is None or t.numel() < need:
+            t = self._alloc((need,), torch.float16)
+            self.scratch[key] = t
+        return t
+
+    def nbytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in self.keep)
+
+    # -- request-level plan: everything that does not depend on the timestep
+    def _build_prepare(self) -> Plan:
+        cfg, pk, B = self.cfg, self.pk, self.B
+        w = pk.w
+        n_txt, n_ip, xdim = cfg.num_text_tokens, cfg.num_ip_tokens, cfg.cross_attention_dim
+        kvt = pk.kv_total
+        ops = [
+            make_op("PAD_ROWS", i=(B, n_txt, LP, 0, n_txt + n_ip, xdim), p=(self.enc, self.enc_txt)),
+            make_op("PAD_ROWS", i=(B, n_ip, LP, n_txt, n_txt + n_ip, xdim), p=(self.enc, self.enc_ip)),
+        ]
+        for enc, wk, wv, kout, vout in ((self.enc_txt, w["xattn.k_text"], w["xattn.v_text"], self.k_txt, self.v_txt),
+                                        (self.enc_ip, w["xattn.k_ip"], w["xattn.v_ip"], self.k_ip, self.v_ip)):
+            # K panels of every layer: [B*96, sumC] = enc_pad @ Wk_all^T
+            ops.append(make_op("GEMM", i=(B * LP, kvt, xdim, xdim, 0, 1, 0, 1), l=(xdim, 0, xdim, kvt, 0),
+                               p=(enc, None, wk, kout)))
+            # V^T panels: per image [sumC, 96] = Wv_all @ enc_pad[b]^T
+            ops.append(make_op("GEMM", i=(kvt, LP, xdim, xdim, 0, B, 0, 1),
+                               l=(xdim, 0, xdim, LP, 0, 0, 0, LP * xdim, kvt * LP, 0), p=(wv, None, enc, vout)))
+        pooled = self.text_embeds.shape[1]
+        ops += [
+            make_op("ADD_TIME_IDS", i=(B, pooled, 6, cfg.addition_time_embed_dim, int(cfg.flip_sin_to_cos)),
+                    f=(cfg.freq_shift,), p=(self.text_embeds, self.time_ids, self.add_in)),
+            make_op("SKINNY", i=(B, cfg.time_embed_dim, self.add_in.shape[1], 0, 1),
+                    p=(self.add_in, w["add_embedding.linear_1.weight"], w["add_embedding.linear_1.bias"], None, self.add_h)),
+            make_op("SKINNY", i=(B, cfg.time_embed_dim, cfg.time_embed_dim, 0, 0),
+                    p=(self.add_h, w["add_embedding.linear_2.weight"], w["add_embedding.linear_2.bias"], None, self.aug)),
+        ]
+        return Plan(ops, self.keep)
+
+    # -- building blocks of the forward plan
+    def _gn(self, ops, x1, x2, y, gamma, beta, HW, C1, C2, eps, silu):
+        ops.append(make_op("GROUPNORM", i=(self.B, HW, C1, C2, self.cfg.norm_num_groups, int(silu)), f=(eps,),
+                           p=(x1, x2, y, gamma, beta, self.gn_ws)))
+
+    def _conv(self, ops, x, wname, y, H, W, Cin, Cout, stride=1, upsample=0, rowbias=None, residual=None):
+        w = self.pk.w
+        ops.append(make_op("CONV3X3", i=(self.B, H, W, Cin, Cout, stride, upsample, self.pk.temb_total),
+                           p=(x, w[wname + ".weight"], y, w[wname + ".bias"], rowbias, residual)))
+
+    def _gemm(self, ops, x, wt, y, M, N, K, bias=None, residual=None, geglu=False, x2=None, K1=0):
+        n_out = N // 2 if geglu else N
+        ops.append(make_op("GEMM", i=(M, N, K, K1 if x2 is not None else K, int(geglu), 1, 0, 1),
+                           l=(K1 if x2 is not None else K, (K - K1) if x2 is not None else 0, K, n_out, n_out),
+                           p=(x, x2, wt, y, bias, None, residual)))
+
+    def _resnet(self, ops, r: ResnetSpec, x1: Tensor, x2: Optional[Tensor], c1: int, c2: int, out: Tensor):
+        cfg, w = self.cfg, self.pk.w
+        H, W = self.hw[r.level]
+        HW, M = H * W, self.B * H * W
+        p = r.prefix
+        gn = self._buf("gn", r.level, M, max(r.cin, r.cout))
+        t1 = self._buf("res_t1", r.level, M, r.cout)
+        self._gn(ops, x1, x2, gn, w[p + ".norm1.weight"], w[p + ".norm1.bias"], HW, c1, c2, cfg.norm_eps, True)
+        rowbias = self.temb_all.data_ptr() + 2 * self.pk.temb_off[p]
+        self._conv(ops, gn, p + ".conv1", t1, H, W, r.cin, r.cout, rowbias=rowbias)
+        self._gn(ops, t1, None, gn, w[p + ".norm2.weight"], w[p + ".norm2.bias"], HW, r.cout, 0, cfg.norm_eps, True)
+        if r.has_shortcut:
+            sc = self._buf("res_sc", r.level, M, r.cout)
+            self._gemm(ops, x1, w[p + ".conv_shortcut.weight"], sc, M, r.cout, r.cin, bias=w[p + ".conv_shortcut.bias"],
+                       x2=x2, K1=c1)
+            res = sc
+        else:
+            assert x2 is None
+            res = x1
+        self._conv(ops, gn, p + ".conv2", out, H, W, r.cout, r.cout, residual=res)
+
+    def _transformer(self, ops, a: AttnSpec, x: Tensor, out: Tensor):
+        cfg, w, B = self.cfg, self.pk.w, self.B
+        H, W = self.hw[a.level]
+        N, Cc = H * W, a.channels
+        M = B * N
+        p = a.prefix
+        tn = self._buf("t_norm", a.level, M, Cc)
+        h = self._buf("t_hidden", a.level, M, Cc)
+        qk = self._buf("t_qk", a.level, M, 2 * Cc)
+        vt = self._buf("t_vt", a.level, M, Cc)
+        ao = self._buf("t_attn", a.level, M, Cc)
+        q2 = self._buf("t_q2", a.level, M, Cc)
+        ff = self._buf("t_ff", a.level, M, 4 * Cc)
+        mh, mw = mask_grid_size(N, self.aspect_ratio)
+        kvt = self.pk.kv_total
+        scale = 1.0 / (Cc // a.heads) ** 0.5
+        self._gn(ops, x, None, tn, w[p + ".norm.weight"], w[p + ".norm.bias"], N, Cc, 0, 1e-6, False)
+        self._gemm(ops, tn, w[p + ".proj_in.weight"], h, M, Cc, Cc, bias=w[p + ".proj_in.bias"])
+        for k in range(a.depth):
+            t = f"{p}.transformer_blocks.{k}"
+            # ---- attn1 (AttnProcessor2_0): q|k projection, V^T projection, flash attention, out-proj + residual
+            ops.append(make_op("LAYERNORM", i=(M, Cc), f=(1e-5,), p=(h, tn, w[t + ".norm1.weight"], w[t + ".norm1.bias"])))
+            self._gemm(ops, tn, w[t + ".attn1.qk.weight"], qk, M, 2 * Cc, Cc)
+            ops.append(make_op("GEMM", i=(Cc, N, Cc, Cc, 0, B, 0, 1), l=(Cc, 0, Cc, N, 0, 0, 0, N * Cc, Cc * N, 0),
+                               p=(w[t + ".attn1.to_v.weight"], None, tn, vt)))
+            ops.append(make_op("SELF_ATTN", i=(B, a.heads, N, N), f=(scale,),
+                               l=(2 * Cc, 2 * Cc, N, Cc, N * 2 * Cc, N * 2 * Cc, N * Cc),
+                               p=(qk, qk.data_ptr() + 2 * Cc, vt, ao)))
+            self._gemm(ops, ao, w[t + ".attn1.to_out.0.weight"], h, M, Cc, Cc, bias=w[t + ".attn1.to_out.0.bias"],
+                       residual=h)
+            # ---- attn2 (MaskedIPAttnProcessor2_0): q projection, fused text+masked-IP attention, out-proj + residual
+            ops.append(make_op("LAYERNORM", i=(M, Cc), f=(1e-5,), p=(h, tn, w[t + ".norm2.weight"], w[t + ".norm2.bias"])))
+            self._gemm(ops, tn, w[t + ".attn2.to_q.weight"], q2, M, Cc, Cc)
+            off = self.pk.kv_off[t]
+            ops.append(make_op(
+                "IP_ATTN",
+                i=(B, a.heads, N, cfg.num_text_tokens, cfg.num_ip_tokens, cfg.num_vision_tokens, cfg.num_vision_tokens,
+                   cfg.max_num_ips, mh, mw),
+                f=(scale, 1.0), l=(Cc, Cc, kvt, LP * kvt, kvt * LP),
+                p=(q2, self.k_txt.data_ptr() + 2 * off, self.v_txt.data_ptr() + 2 * off * LP,
+                   self.k_ip.data_ptr() + 2 * off, self.v_ip.data_ptr() + 2 * off * LP, self.bbox, ao, self.ip_scale)))
+            self._gemm(ops, ao, w[t + ".attn2.to_out.0.weight"], h, M, Cc, Cc, bias=w[t + ".attn2.to_out.0.bias"],
+                       residual=h)
+            # ---- GEGLU feed-forward + residual
+            ops.append(make_op("LAYERNORM", i=(M, Cc), f=(1e-5,), p=(h, tn, w[t + ".norm3.weight"], w[t + ".norm3.bias"])))
+            self._gemm(ops, tn, w[t + ".ff.net.0.proj.weight"], ff, M, 8 * Cc, Cc, bias=w[t + ".ff.net.0.proj.bias"],
+                       geglu=True)
+            self._gemm(ops, ff, w[t + ".ff.net.2.weight"], h, M, Cc, 4 * Cc, bias=w[t + ".ff.net.2.bias"], residual=h)
+        self._gemm(ops, h, w[p + ".proj_out.weight"], out, M, Cc, Cc, bias=w[p + ".proj_out.bias"], residual=x)
+
+    def _build_forward(self) -> List[DsOp]:
+        cfg, pk, B = self.cfg, self.pk, self.B
+        w = pk.w
+        topo = pk.topo
+        ops: List[DsOp] = []
+        c0, temb = cfg.block_out_channels[0], cfg.time_embed_dim
+        H, W = self.hw[0]
+        # ---- 1. time embedding (reference src/models/unet.py:190-199)
+        ops.append(make_op("TIMESTEP_EMBED", i=(B, c0, int(cfg.flip_sin_to_cos)), f=(cfg.freq_shift,),
+                           p=(self.table, self.ctr, self.t_sin)))
+        ops.append(make_op("SKINNY", i=(B, temb, c0, 0, 1),
+                           p=(self.t_sin, w["time_embedding.linear_1.weight"], w["time_embedding.linear_1.bias"], None,
+                              self.t_h)))
+        ops.append(make_op("SKINNY", i=(B, temb, temb, 0, 0),
+                           p=(self.t_h, w["time_embedding.linear_2.weight"], w["time_embedding.linear_2.bias"], self.aug,
+                              self.emb)))
+        ops.append(make_op("SKINNY", i=(B, pk.temb_total, temb, 1, 0),
+                           p=(self.emb, w["temb_all.weight"], w["temb_all.bias"], None, self.temb_all)))
+        # ---- 2. conv_in + dialog-box embedding (:206-210)
+        skips: List[Tuple[Tensor, int, int]] = []  # (tensor, channels, level)
+
+        def new_act(level, ch, tag):
+            h_, w_ = self.hw[level]
+            return self._alloc((B * h_ * w_, ch), torch.float16)
+
+        x = new_act(0, c0, "conv_in")
+        ops.append(make_op("CONV_IN", i=(B, H, W, cfg.in_channels, c0, cfg.max_num_dialogs),
+                           p=(self.x_in, w["conv_in.weight"], w["conv_in.bias"], self.dialog_boxes,
+                              w["dialog_bbox_embedding"], x)))
+        skips.append((x, c0, 0))
+        cur, cur_c = x, c0
+        # ---- 3. down (:244-265)
+        for blk in topo.down:
+            lvl = blk["level"]
+            for j, r in enumerate(blk["resnets"]):
+                out = new_act(lvl, r.cout, r.prefix)
+                self._resnet(ops, r, cur, None, cur_c, 0, out)
+                cur, cur_c = out, r.cout
+                if blk["attns"]:
+                    out2 = new_act(lvl, r.cout, blk["attns"][j].prefix)
+                    self._transformer(ops, blk["attns"][j], cur, out2)
+                    cur = out2
+                skips.append((cur, cur_c, lvl))
+            if blk["downsample"]:
+                h_, w_ = self.hw[lvl]
+                out = new_act(lvl + 1, cur_c, blk["downsample"])
+                self._conv(ops, cur, blk["downsample"], out, h_, w_, cur_c, cur_c, stride=2)
+                cur = out
+                skips.append((cur, cur_c, lvl + 1))
+        # ---- 4. mid (:279-290)
+        mid = topo.mid
+        lvl = mid["level"]
+        out = new_act(lvl, cur_c, "mid0")
+        self._resnet(ops, mid["resnets"][0], cur, None, cur_c, 0, out)
+        out2 = new_act(lvl, cur_c, "mid_attn")
+        self._transformer(ops, mid["attns"][0], out, out2)
+        out3 = new_act(lvl, cur_c, "mid1")
+        self._resnet(ops, mid["resnets"][1], out2, None, cur_c, 0, out3)
+        cur = out3
+        # ---- 5. up (:304-332): the skip concat is never materialised (dual-source GroupNorm / shortcut GEMM)
+        for blk in topo.up:
+            lvl = blk["level"]
+            for j, r in enumerate(blk["resnets"]):
+                sk, sk_c, sk_l = skips.pop()
+                assert sk_l == lvl and cur_c + sk_c == r.cin, (r.prefix, cur_c, sk_c, r.cin)
+                out = new_act(lvl, r.cout, r.prefix)
+                self._resnet(ops, r, cur, sk, cur_c, sk_c, out)
+                cur, cur_c = out, r.cout
+                if blk["attns"]:
+                    out2 = new_act(lvl, r.cout, blk["attns"][j].prefix)
+                    self._transformer(ops, blk["attns"][j], cur, out2)
+                    cur = out2
+            if blk["upsample"]:
+                h_, w_ = self.hw[lvl]
+                out = new_act(lvl - 1, cur_c, blk["upsample"])
+                self._conv(ops, cur, blk["upsample"], out, h_, w_, cur_c, cur_c, upsample=1)
+                cur = out
+        assert not skips
+        # ---- 6. out (:335-338)
+        gn = self._buf("gn", 0, B * H * W, c0)
+        self._gn(ops, cur, None, gn, w["conv_norm_out.weight"], w["conv_norm_out.bias"], H * W, c0, 0, cfg.norm_eps, True)
+        ops.append(make_op("CONV_OUT", i=(B, H, W, c0, cfg.out_channels),
+                           p=(gn, w["conv_out.weight"], w["conv_out.bias"], self.eps)))
+        return ops
+
+    # -- sampling: forward + CFG + scheduler step + counter advance as ONE replayable plan
+    def build_sampler(self, ns: int, kind: int, do_cfg: bool = True):
+        """reference src/pipelines/pipeline_diffsensei.py:310-337, one loop iteration per `step_plan.run()`."""
+        if self.B != (2 * ns if do_cfg else ns):
+            raise ValueError(f"engine batch {self.B} does not match num_samples {ns} (cfg={do_cfg})")
+        key = (ns, kind, do_cfg)
+        if getattr(self, "_sampler_key", None) == key:
+            return
+        HW = self.H * self.W
+        self.latents = self._alloc((ns, self.cfg.in_channels, self.H, self.W), torch.float16)
+        self.prep_plan = Plan([make_op("PREP_INPUT", i=(ns, HW, int(do_cfg)),
+                                       p=(self.latents, self.x_in, self.table, self.ctr))], self.keep)
+        step_ops = list(self.forward_ops) + [
+            make_op("SAMPLER_STEP", i=(ns, HW, kind, int(do_cfg)),
+                    p=(self.eps, self.latents, self.x_in, self.table, self.ctr)),
+            make_op("ADVANCE", p=(self.ctr,)),
+        ]
+        self.step_plan = Plan(step_ops, self.keep)
+        self._sampler_key = key
+
+    def load_schedule(self, table_rows: Tensor):
+        """table_rows: fp32 [n_steps, 8] (see include/diffsensei_hip.h); resets the device step counter."""
+        n = table_rows.shape[0]
+        if n > self.table.shape[0]:
+            raise ValueError("too many steps for the scalar table")
+        self.table[:n].copy_(table_rows.to(self.dev, torch.float32))
+        self.ctr.zero_()
+
+    # -- host-side setters (tiny H2D copies; never inside a captured graph)
+    def set_request(self, encoder_hidden_states: Tensor, text_embeds: Tensor, time_ids: Tensor, bbox: Tensor,
+                    dialog_boxes: Optional[Tensor], ip_scale: float):
+        self.enc.copy_(encoder_hidden_states.to(self.dev, torch.float16).reshape(self.enc.shape))
+        self.text_embeds.copy_(text_embeds.to(self.dev, torch.float16).reshape(self.text_embeds.shape))
+        self.time_ids.copy_(time_ids.to(self.dev, torch.float16).reshape(self.time_ids.shape))
+        self.bbox.copy_(bbox.to(self.dev, torch.float32).reshape(self.bbox.shape))
+        if dialog_boxes is None:
+            self.dialog_boxes.zero_()
+        else:
+            self.dialog_boxes.copy_(dialog_boxes.to(self.dev, torch.int32).reshape(self.dialog_boxes.shape))
+        self.ip_scale.fill_(float(ip_scale))
+        self.prepare_plan.run()

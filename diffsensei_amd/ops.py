@@ -1,0 +1,260 @@
+"""Thin torch-tensor wrappers over the C ABI (one function per entry point of include/diffsensei_hip.h).
+
+PyTorch is plumbing here: device memory and the current HIP stream.  No arithmetic happens in this file;
+every function checks devices/dtypes, hands raw pointers to the library and raises on a non-zero status.
+Layouts: activations fp16 channels-last — images [B, H*W, C] (or [B,H,W,C]), token matrices [rows, C].
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import check
+
+Tensor = torch.Tensor
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _chk(*ts: Optional[Tensor], dtype=torch.float16) -> None:
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise _lib.DiffSenseiHipError("diffsensei_amd ops need CUDA(HIP) tensors — there is no CPU path")
+        if dtype is not None and t.dtype != dtype:
+            raise _lib.DiffSenseiHipError(f"expected {dtype}, got {t.dtype}")
+        if not t.is_contiguous():
+            raise _lib.DiffSenseiHipError("tensor must be contiguous")
+
+
+_EPILOGUES = {None: 0, "geglu": 1, "gelu": 2, "quick_gelu": 3}
+
+
+def gemm(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, residual: Optional[Tensor] = None,
+         geglu: bool = False, out: Optional[Tensor] = None, x2: Optional[Tensor] = None,
+         act: Optional[str] = None) -> Tensor:
+    """y = act(cat([x, x2], -1) @ w.T + bias) (+residual);  geglu: w/bias packed by `pack_geglu`, y = h*gelu(g)."""
+    _chk(x, w, bias, residual, x2)
+    epi = 1 if geglu else _EPILOGUES[act]
+    M, K1 = x.shape
+    K = K1 + (x2.shape[1] if x2 is not None else 0)
+    N = w.shape[0]
+    assert w.shape[1] == K
+    n_out = N // 2 if geglu else N
+    if out is None:
+        out = torch.empty((M, n_out), dtype=torch.float16, device=x.device)
+    L = _lib.load()
+    check(L.ds_gemm_f16(_p(x), K1, _p(x2), 0 if x2 is None else x2.shape[1], K1, _p(w), K, _p(bias), _p(residual),
+                        n_out, _p(out), n_out, M, N, K, epi, _stream()), "ds_gemm_f16")
+    return out
+
+
+def gemm_batched_nt(a: Tensor, b: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    """out[z] = a[z or shared] @ b[z].T ; a: [M,K] or [Z,M,K], b: [Z,N,K] -> [Z,M,N]."""
+    _chk(a, b)
+    Z, N, K = b.shape
+    M = a.shape[-2]
+    sa = 0 if a.dim() == 2 else M * K
+    if out is None:
+        out = torch.empty((Z, M, N), dtype=torch.float16, device=b.device)
+    L = _lib.load()
+    check(L.ds_gemm_f16_batched(_p(a), K, sa, _p(b), K, N * K, _p(out), N, M * N, M, N, K, Z, _stream()),
+          "ds_gemm_f16_batched")
+    return out
+
+
+def conv3x3(x: Tensor, w: Tensor, bias: Optional[Tensor], stride: int = 1, upsample: bool = False,
+            rowbias: Optional[Tensor] = None, residual: Optional[Tensor] = None) -> Tensor:
+    """x: [B,H,W,Cin] NHWC, w: [Cout,3,3,Cin] -> [B,Ho,Wo,Cout]; rowbias: [B,Cout] per-image bias."""
+    _chk(x, w, bias, rowbias, residual)
+    B, H, W, Cin = x.shape
+    Cout = w.shape[0]
+    Ho, Wo = (2 * H, 2 * W) if upsample else ((H + stride - 1) // stride, (W + stride - 1) // stride)
+    y = torch.empty((B, Ho, Wo, Cout), dtype=torch.float16, device=x.device)
+    L = _lib.load()
+    check(L.ds_conv3x3_f16(_p(x), _p(w), _p(bias), _p(rowbias), 0 if rowbias is None else rowbias.shape[1],
+                           _p(residual), _p(y), B, H, W, Cin, Cout, stride, int(upsample), _stream()),
+          "ds_conv3x3_f16")
+    return y
+
+
+def groupnorm(x: Tensor, gamma: Tensor, beta: Tensor, groups: int, eps: float, silu: bool,
+              x2: Optional[Tensor] = None) -> Tensor:
+    """x: [B,HW,C1] (+ x2 [B,HW,C2] concatenated on channels) -> [B,HW,C1+C2]."""
+    _chk(x, gamma, beta, x2)
+    B, HW, C1 = x.shape
+    C2 = 0 if x2 is None else x2.shape[2]
+    L = _lib.load()
+    ws = torch.empty(L.ds_groupnorm_workspace_bytes(B, C1 + C2), dtype=torch.uint8, device=x.device)
+    y = torch.empty((B, HW, C1 + C2), dtype=torch.float16, device=x.device)
+    check(L.ds_groupnorm_f16(_p(x), _p(x2), _p(y), _p(gamma), _p(beta), _p(ws), B, HW, C1, C2, groups, eps, int(silu),
+                             _stream()), "ds_groupnorm_f16")
+    return y
+
+
+def layernorm(x: Tensor, gamma: Tensor, beta: Tensor, eps: float = 1e-5) -> Tensor:
+    _chk(x, gamma, beta)
+    C = x.shape[-1]
+    y = torch.empty_like(x)
+    check(_lib.load().ds_layernorm_f16(_p(x), _p(y), _p(gamma), _p(beta), x.numel() // C, C, eps, _stream()),
+          "ds_layernorm_f16")
+    return y
+
+
+def self_attention(q: Tensor, k: Tensor, vt: Tensor, heads: int, scale: Optional[float] = None) -> Tensor:
+    """q,k: [B,N,heads*64]; vt: [B,heads,64,Nk] (V transposed) -> [B,N,heads*64]."""
+    _chk(q, k, vt)
+    B, Nq, Cc = q.shape
+    Nk = k.shape[1]
+    o = torch.empty_like(q)
+    check(_lib.load().ds_self_attn_f16(_p(q), Cc, Nq * Cc, _p(k), Cc, Nk * Cc, _p(vt), vt.shape[-1], _p(o), Cc, Nq * Cc,
+                                       B, heads, Nq, Nk, scale if scale is not None else 0.125, _stream()),
+          "ds_self_attn_f16")
+    return o
+
+
+def masked_ip_attention(q: Tensor, kt: Tensor, vtt: Tensor, ki: Tensor, vti: Tensor, bbox: Tensor, heads: int,
+                        mask_hw: Tuple[int, int], ip_scale: float, Lt: int = 77, Li: int = 80, n_dummy: int = 16,
+                        tok_per_ip: int = 16, qk_scale: float = 0.125) -> Tensor:
+    """q: [B,N,C]; kt/ki: [B,96,C]; vtt/vti: [B,C,96]; bbox: [B,max_ips,4] fp32."""
+    _chk(q, kt, vtt, ki, vti)
+    _chk(bbox, dtype=torch.float32)
+    B, N, Cc = q.shape
+    o = torch.empty_like(q)
+    check(_lib.load().ds_masked_ip_attn_f16(_p(q), Cc, _p(kt), _p(vtt), _p(ki), _p(vti), _p(bbox), _p(o), Cc, B, heads,
+                                            N, Lt, Li, n_dummy, tok_per_ip, bbox.shape[1], mask_hw[0], mask_hw[1],
+                                            qk_scale, ip_scale, None, 0, 0, 0, _stream()), "ds_masked_ip_attn_f16")
+    return o
+
+
+def ip_region_flags(bbox: Tensor, N: int, mask_hw: Tuple[int, int]) -> Tensor:
+    _chk(bbox, dtype=torch.float32)
+    B = bbox.shape[0]
+    flags = torch.empty((B, N), dtype=torch.uint8, device=bbox.device)
+    check(_lib.load().ds_ip_region_flags(_p(bbox), _p(flags), B, N, bbox.shape[1], mask_hw[0], mask_hw[1], _stream()),
+          "ds_ip_region_flags")
+    return flags
+
+
+def small_attention(q: Tensor, k: Tensor, v: Tensor, heads: int, scale: float) -> Tensor:
+    """q: [B,Nq,heads*D], k/v: [B,Nk,heads*D] (any D<=128 multiple of 8); k/v may be column-slice views."""
+    _chk(q)
+    for t in (k, v):
+        if not t.is_cuda or t.dtype != torch.float16 or t.stride(2) != 1:
+            raise _lib.DiffSenseiHipError("small_attention: k/v must be fp16 device tensors with unit inner stride")
+    B, Nq, Cc = q.shape
+    Nk = k.shape[1]
+    o = torch.empty_like(q)
+    check(_lib.load().ds_small_attn_f16(_p(q), Cc, Nq * Cc, _p(k), k.stride(1), k.stride(0), _p(v), v.stride(1),
+                                        v.stride(0), _p(o), Cc, Nq * Cc, B, heads, Nq, Nk, Cc // heads, scale,
+                                        _stream()), "ds_small_attn_f16")
+    return o
+
+
+def conv_in_dialog(x: Tensor, w: Tensor, bias: Tensor, boxes: Optional[Tensor], demb: Optional[Tensor]) -> Tensor:
+    """x: [B,H,W,4]; w: [Cout,3,3,4]; boxes: int32 [B,nd,4] pixel boxes or None."""
+    _chk(x, w, bias, demb)
+    B, H, W, Cin = x.shape
+    Cout = w.shape[0]
+    nd = 0 if boxes is None else boxes.shape[1]
+    if boxes is not None:
+        _chk(boxes, dtype=torch.int32)
+    y = torch.empty((B, H, W, Cout), dtype=torch.float16, device=x.device)
+    check(_lib.load().ds_conv_in_dialog_f16(_p(x), _p(w), _p(bias), _p(boxes), _p(demb), _p(y), B, H, W, Cin, Cout, nd,
+                                            _stream()), "ds_conv_in_dialog_f16")
+    return y
+
+
+def conv_out(x: Tensor, w: Tensor, bias: Tensor) -> Tensor:
+    _chk(x, w, bias)
+    B, H, W, Cin = x.shape
+    Cout = w.shape[0]
+    y = torch.empty((B, H, W, Cout), dtype=torch.float16, device=x.device)
+    check(_lib.load().ds_conv_out_f16(_p(x), _p(w), _p(bias), _p(y), B, H, W, Cin, Cout, _stream()), "ds_conv_out_f16")
+    return y
+
+
+def skinny_linear(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, addend: Optional[Tensor] = None,
+                  silu_in: bool = False, silu_out: bool = False) -> Tensor:
+    _chk(x, w, bias, addend)
+    M, K = x.shape
+    N = w.shape[0]
+    y = torch.empty((M, N), dtype=torch.float16, device=x.device)
+    check(_lib.load().ds_skinny_linear_f16(_p(x), _p(w), _p(bias), _p(addend), _p(y), M, N, K, int(silu_in),
+                                           int(silu_out), _stream()), "ds_skinny_linear_f16")
+    return y
+
+
+def timestep_embed(table: Tensor, B: int, dim: int, flip: bool = True, freq_shift: float = 0.0,
+                   ctr: Optional[Tensor] = None) -> Tensor:
+    _chk(table, dtype=torch.float32)
+    out = torch.empty((B, dim), dtype=torch.float16, device=table.device)
+    check(_lib.load().ds_timestep_embed_f16(_p(table), _p(ctr), _p(out), B, dim, int(flip), freq_shift, _stream()),
+          "ds_timestep_embed_f16")
+    return out
+
+
+def add_time_ids(text_embeds: Tensor, time_ids: Tensor, dim: int, flip: bool = True, freq_shift: float = 0.0) -> Tensor:
+    _chk(text_embeds, time_ids)
+    B, P = text_embeds.shape
+    n = time_ids.shape[1]
+    out = torch.empty((B, P + n * dim), dtype=torch.float16, device=text_embeds.device)
+    check(_lib.load().ds_add_time_ids_f16(_p(text_embeds), _p(time_ids), _p(out), B, P, n, dim, int(flip), freq_shift,
+                                          _stream()), "ds_add_time_ids_f16")
+    return out
+
+
+def cfg_sampler_step(eps: Tensor, latents: Tensor, model_in: Tensor, table: Tensor, kind: int, do_cfg: bool = True,
+                     ctr: Optional[Tensor] = None) -> None:
+    """eps: [2ns,HW,4] NHWC; latents: [ns,4,H,W] NCHW (in place); model_in: [2ns,HW,4]."""
+    _chk(eps, latents, model_in)
+    _chk(table, dtype=torch.float32)
+    ns = latents.shape[0]
+    HW = latents.shape[2] * latents.shape[3]
+    check(_lib.load().ds_cfg_sampler_step_f16(_p(eps), _p(latents), _p(model_in), _p(table), _p(ctr), ns, HW, kind,
+                                              int(do_cfg), _stream()), "ds_cfg_sampler_step_f16")
+
+
+def prepare_model_input(latents: Tensor, model_in: Tensor, table: Tensor, do_cfg: bool = True,
+                        ctr: Optional[Tensor] = None) -> None:
+    _chk(latents, model_in)
+    ns = latents.shape[0]
+    HW = latents.shape[2] * latents.shape[3]
+    check(_lib.load().ds_prepare_model_input_f16(_p(latents), _p(model_in), _p(table), _p(ctr), ns, HW, int(do_cfg),
+                                                 _stream()), "ds_prepare_model_input_f16")
+
+
+def nhwc_to_nchw(x: Tensor) -> Tensor:
+    """[B,HW,C] -> [B,C,HW]"""
+    _chk(x)
+    B, HW, Cc = x.shape
+    y = torch.empty((B, Cc, HW), dtype=torch.float16, device=x.device)
+    check(_lib.load().ds_nhwc_to_nchw_f16(_p(x), _p(y), B, HW, Cc, _stream()), "ds_nhwc_to_nchw_f16")
+    return y
+
+
+def nchw_to_nhwc(x: Tensor) -> Tensor:
+    """[B,C,HW] -> [B,HW,C]"""
+    _chk(x)
+    B, Cc, HW = x.shape
+    y = torch.empty((B, HW, Cc), dtype=torch.float16, device=x.device)
+    check(_lib.load().ds_nchw_to_nhwc_f16(_p(x), _p(y), B, HW, Cc, _stream()), "ds_nchw_to_nhwc_f16")
+    return y
+
+
+def pad_rows(x: Tensor, row_off: int, rows_in: int, rows_out: int) -> Tensor:
+    """x: [B,total_rows,C] -> [B,rows_out,C] = x[:, row_off:row_off+rows_in] zero-padded."""
+    _chk(x)
+    B, T, Cc = x.shape
+    y = torch.empty((B, rows_out, Cc), dtype=torch.float16, device=x.device)
+    check(_lib.load().ds_pad_rows_f16(_p(x), _p(y), B, rows_in, rows_out, row_off, T, Cc, _stream()), "ds_pad_rows_f16")
+    return y

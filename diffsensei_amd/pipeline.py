@@ -1,0 +1,309 @@
+"""Host mirror of reference src/pipelines/pipeline_diffsensei.py `DiffSenseiPipeline`.
+
+Same constructor, `register_manga_modules`, `check_inputs`, `prepare_ip_image_embeds`, `prepare_dialog_bbox`,
+`set_ip_scale` and `__call__` signature (reference :43-57, :73-79, :81-102, :104-154, :156-170, :172-178, :181-203;
+extra TRAILING keyword arguments only).  Returns an object with `.images`.
+
+What runs where
+  * denoising loop (UNet + CFG + scheduler step): C++ launch plan over the HIP kernels, one `step_plan` run (or
+    hipGraph replay) per step, zero host arithmetic and zero host<->device syncs inside the loop;
+  * character encoders (CLIP-H, Magi ViT-MAE) + Resampler: HIP engines (`encoders.py`, `resampler.py`);
+  * text encoders and the VAE decoder are NOT part of this path (SURVEY.md §8f "next"): any object with the
+    transformers / diffusers call protocol can be passed in, or the caller supplies `prompt_embeds` and asks for
+    `output_type="latent"`.
+"""
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass
+from typing import Any, List, Optional, Tuple, Union
+
+import torch
+
+from .encoders import ClipVisionEngine, ViTMAEEngine
+from .unet import UNetMangaModel, dialog_pixel_boxes
+
+Tensor = torch.Tensor
+
+
+@dataclass
+class StableDiffusionXLPipelineOutput:
+    images: Any
+
+
+def _black_image():
+    from PIL import Image
+    return Image.new("RGB", (224, 224), (0, 0, 0))
+
+
+class DiffSenseiPipeline:
+    def __init__(self, vae, text_encoder, text_encoder_2, tokenizer, tokenizer_2, scheduler, unet: UNetMangaModel,
+                 image_encoder, feature_extractor=None, force_zeros_for_empty_prompt: bool = True):
+        self.vae, self.text_encoder, self.text_encoder_2 = vae, text_encoder, text_encoder_2
+        self.tokenizer, self.tokenizer_2 = tokenizer, tokenizer_2
+        self.scheduler, self.unet = scheduler, unet
+        self.image_encoder = self._as_clip_engine(image_encoder)
+        self.feature_extractor = feature_extractor
+        self.force_zeros_for_empty_prompt = force_zeros_for_empty_prompt
+        self.vae_scale_factor = 8
+        self.default_sample_size = unet.config.sample_size
+        self.progress_bar_config = {"disable": True}
+        self.magi_image_encoder = None
+        self.image_proj_model = None
+        self._clip_proc = None
+        self._magi_proc = None
+        self._guidance_scale = 1.0
+        self._stream = None
+        self.use_graph = os.environ.get("DIFFSENSEI_GRAPH", "1") != "0"
+        self.last_run_info = {}
+
+    # ---- plumbing
+    @property
+    def _execution_device(self):
+        return self.unet.device
+
+    @property
+    def device(self):
+        return self.unet.device
+
+    @property
+    def guidance_scale(self):
+        return self._guidance_scale
+
+    @property
+    def do_classifier_free_guidance(self):
+        return self._guidance_scale > 1
+
+    def to(self, device=None, dtype=None, **kw):
+        self.unet.to(device=device, dtype=dtype)
+        if self.image_proj_model is not None:
+            self.image_proj_model.to(device=device, dtype=dtype)
+        return self
+
+    def _as_clip_engine(self, m):
+        if m is None or isinstance(m, ClipVisionEngine):
+            return m
+        return ClipVisionEngine.from_transformers(m, self.unet.device)
+
+    def _as_magi_engine(self, m):
+        if m is None or isinstance(m, ViTMAEEngine):
+            return m
+        return ViTMAEEngine.from_transformers(m, self.unet.device)
+
+    def register_manga_modules(self, magi_image_encoder, image_proj_model):
+        """reference :73-79"""
+        self.magi_image_encoder = self._as_magi_engine(magi_image_encoder)
+        self.image_proj_model = image_proj_model
+
+    # ---- reference :81-102 (same checks, same messages)
+    def check_inputs(self, prompt, prompt_2, ip_images, ip_image_embeds, ip_bbox):
+        if prompt is None:
+            raise ValueError(f"`prompt` has to be of type `str` but is {type(prompt)}")
+        elif prompt is not None and not isinstance(prompt, str):
+            raise ValueError(f"`prompt` has to be of type `str` but is {type(prompt)}")
+        elif prompt_2 is not None and not isinstance(prompt_2, str):
+            raise ValueError(f"`prompt_2` has to be of type `str` but is {type(prompt_2)}")
+        if len(ip_images) > 0 and ip_image_embeds is not None:
+            raise ValueError(f"`ip_images` and `ip_image_embeds` can not be input together!")
+        num_ips = len(ip_image_embeds) if ip_image_embeds is not None else len(ip_images)
+        if num_ips != len(ip_bbox):
+            raise ValueError(f"`ip_images` must have the same length as `ip_bbox`. But they are in length {num_ips} "
+                             f"and {len(ip_bbox)}!")
+
+    def _processors(self):
+        if self._clip_proc is None:
+            from transformers import CLIPImageProcessor, ViTImageProcessor
+            self._clip_proc, self._magi_proc = CLIPImageProcessor(), ViTImageProcessor()
+        return self._clip_proc, self._magi_proc
+
+    # ---- reference :104-154
+    def prepare_ip_image_embeds(self, ip_images, ip_image_embeds, ip_bbox, num_samples):
+        cfg = self.unet.config
+        dev = self._execution_device
+        max_num_ips = cfg.max_num_ips
+        ip_images = list(ip_images)[:max_num_ips]
+        if ip_image_embeds is not None:
+            ip_image_embeds = ip_image_embeds[:max_num_ips]
+        ip_bbox = [list(b) for b in ip_bbox][:max_num_ips]
+        num_ips = len(ip_images)
+        while len(ip_images) < max_num_ips:
+            ip_images.append(_black_image())
+        while len(ip_bbox) < max_num_ips:
+            ip_bbox.append([0.0, 0.0, 0.0, 0.0])
+        clip_proc, magi_proc = self._processors()
+        clip_px = clip_proc(images=ip_images, return_tensors="pt").pixel_values
+        magi_px = magi_proc(images=ip_images, return_tensors="pt").pixel_values
+        clip_embeds = self.image_encoder.penultimate_hidden(clip_px).unsqueeze(0)          # [1,4,257,1280]
+        magi_embeds = self.magi_image_encoder.cls_embedding(magi_px).unsqueeze(0)           # [1,4,768]
+        clip_embeds[0, num_ips:] = 0
+        magi_embeds[0, num_ips:] = 0
+        image_embeds = self.image_proj_model(clip_embeds, magi_embeds)
+        negative_image_embeds = self.image_proj_model(torch.zeros_like(clip_embeds), torch.zeros_like(magi_embeds))
+        bbox = torch.tensor(ip_bbox, dtype=torch.float32).unsqueeze(0).to(dev)
+        negative_bbox = torch.zeros_like(bbox)
+        nv = cfg.num_vision_tokens
+        image_embeds = image_embeds.view(1, nv + max_num_ips * nv, image_embeds.shape[-1])
+        if ip_image_embeds is not None:
+            n_e, _, dim = ip_image_embeds.shape
+            image_embeds[0, nv:(1 + n_e) * nv, :] = ip_image_embeds.to(image_embeds).view(1, -1, dim)
+        negative_image_embeds = negative_image_embeds.view(1, nv + max_num_ips * nv, image_embeds.shape[-1])
+        image_embeds = image_embeds.repeat(num_samples, 1, 1).to(torch.float16)
+        negative_image_embeds = negative_image_embeds.repeat(num_samples, 1, 1).to(torch.float16)
+        return (negative_image_embeds, image_embeds, negative_bbox.repeat(num_samples, 1, 1),
+                bbox.repeat(num_samples, 1, 1))
+
+    # ---- reference :156-170
+    def prepare_dialog_bbox(self, dialog_bbox, num_samples):
+        max_num_dialogs = self.unet.config.max_num_dialogs
+        dialog_bbox = [list(b) for b in dialog_bbox][:max_num_dialogs]
+        while len(dialog_bbox) < max_num_dialogs:
+            dialog_bbox.append([0.0, 0.0, 0.0, 0.0])
+        db = torch.tensor(dialog_bbox, dtype=torch.float32).unsqueeze(0).to(dtype=self.unet.dtype)
+        db = db.repeat(num_samples, 1, 1)
+        return torch.zeros_like(db), db
+
+    # ---- reference :172-178
+    def set_ip_scale(self, scale):
+        for attn_processor in self.unet.attn_processors.values():
+            if hasattr(attn_processor, "scale"):
+                attn_processor.scale = scale
+
+    # ---- text encoding (transformers modules, not on this path; diffusers SDXL `encode_prompt` semantics [3P])
+    def encode_prompt(self, prompt, prompt_2, device, num_images_per_prompt, do_cfg, negative_prompt, negative_prompt_2):
+        if self.text_encoder is None or self.tokenizer is None:
+            raise ValueError("no text encoders registered: pass prompt_embeds / negative_prompt_embeds / "
+                             "pooled_prompt_embeds / negative_pooled_prompt_embeds")
+        prompts = [prompt, prompt_2 or prompt]
+        negs = [negative_prompt or "", negative_prompt_2 or negative_prompt or ""]
+        toks, encs = [self.tokenizer, self.tokenizer_2], [self.text_encoder, self.text_encoder_2]
+
+        def enc(texts):
+            embs, pooled = [], None
+            for text, tok, te in zip(texts, toks, encs):
+                ids = tok(text, padding="max_length", max_length=tok.model_max_length, truncation=True,
+                          return_tensors="pt").input_ids.to(next(te.parameters()).device)
+                out = te(ids, output_hidden_states=True)
+                pooled = out[0]
+                embs.append(out.hidden_states[-2])
+            return torch.cat(embs, dim=-1), pooled
+
+        with torch.no_grad():
+            pe, pp = enc(prompts)
+            if do_cfg and negative_prompt is None and self.force_zeros_for_empty_prompt:
+                ne, npool = torch.zeros_like(pe), torch.zeros_like(pp)
+            else:
+                ne, npool = enc(negs)
+        rep = lambda t: t.repeat_interleave(num_images_per_prompt, dim=0).to(device, torch.float16)
+        return rep(pe), rep(ne), rep(pp), rep(npool)
+
+    def prepare_latents(self, batch_size, num_channels, height, width, dtype, device, generator, latents=None):
+        shape = (batch_size, num_channels, int(height) // self.vae_scale_factor, int(width) // self.vae_scale_factor)
+        if latents is None:
+            gdev = generator.device if generator is not None and not isinstance(generator, list) else torch.device(device)
+            latents = torch.randn(shape, generator=generator, device=gdev, dtype=dtype).to(device)
+        else:
+            latents = latents.to(device=device, dtype=dtype)
+        return latents * self.scheduler.init_noise_sigma
+
+    # ---- reference :180-372
+    @torch.no_grad()
+    def __call__(self, prompt: str, prompt_2: str = None, height: Optional[int] = None, width: Optional[int] = None,
+                 num_inference_steps: int = 40, guidance_scale: float = 5.0,
+                 negative_prompt: Optional[Union[str, List[str]]] = None,
+                 negative_prompt_2: Optional[Union[str, List[str]]] = None, num_samples: Optional[int] = 1,
+                 generator: Optional[Union[torch.Generator, List[torch.Generator]]] = None,
+                 original_size: Optional[Tuple[int, int]] = None, crops_coords_top_left: Tuple[int, int] = (0, 0),
+                 target_size: Optional[Tuple[int, int]] = None, min_size_step: Optional[int] = 8,
+                 ip_images=[], ip_image_embeds: Optional[Tensor] = None, ip_bbox: Optional[List[List[float]]] = [],
+                 ip_scale: Optional[int] = 1.0, dialog_bbox: Optional[List[List[float]]] = [],
+                 # ---- trailing extensions (not in the reference signature)
+                 latents: Optional[Tensor] = None, prompt_embeds: Optional[Tensor] = None,
+                 negative_prompt_embeds: Optional[Tensor] = None, pooled_prompt_embeds: Optional[Tensor] = None,
+                 negative_pooled_prompt_embeds: Optional[Tensor] = None, output_type: str = "pil"):
+        height = height or self.default_sample_size * self.vae_scale_factor
+        width = width or self.default_sample_size * self.vae_scale_factor
+        original_size = original_size or (height, width)
+        target_size = target_size or (height, width)
+        self.check_inputs(prompt, prompt_2, ip_images, ip_image_embeds, ip_bbox)
+        self._guidance_scale = guidance_scale
+        device = self._execution_device
+        self.set_ip_scale(ip_scale)
+        do_cfg = self.do_classifier_free_guidance
+
+        if prompt_embeds is None:
+            prompt_embeds, negative_prompt_embeds, pooled_prompt_embeds, negative_pooled_prompt_embeds = \
+                self.encode_prompt(prompt, prompt_2, device, num_samples, do_cfg, negative_prompt, negative_prompt_2)
+        else:
+            f = lambda t: None if t is None else t.to(device, torch.float16)
+            prompt_embeds, pooled_prompt_embeds = f(prompt_embeds), f(pooled_prompt_embeds)
+            negative_prompt_embeds = f(negative_prompt_embeds) if negative_prompt_embeds is not None \
+                else torch.zeros_like(prompt_embeds)
+            negative_pooled_prompt_embeds = f(negative_pooled_prompt_embeds) if negative_pooled_prompt_embeds is not None \
+                else torch.zeros_like(pooled_prompt_embeds)
+            if prompt_embeds.shape[0] == 1 and num_samples > 1:
+                prompt_embeds = prompt_embeds.repeat(num_samples, 1, 1)
+                negative_prompt_embeds = negative_prompt_embeds.repeat(num_samples, 1, 1)
+                pooled_prompt_embeds = pooled_prompt_embeds.repeat(num_samples, 1)
+                negative_pooled_prompt_embeds = negative_pooled_prompt_embeds.repeat(num_samples, 1)
+
+        self.scheduler.set_timesteps(num_inference_steps, device=device)
+        lat = self.prepare_latents(num_samples, self.unet.config.in_channels, height, width, torch.float16, device,
+                                   generator, latents)
+        neg_img, img, neg_bbox, bbox = self.prepare_ip_image_embeds(ip_images, ip_image_embeds, list(ip_bbox), num_samples)
+        H, W = lat.shape[-2], lat.shape[-1]
+        aspect_ratio = H / W
+        add_time_ids = torch.tensor([list(original_size) + list(crops_coords_top_left) + list(target_size)],
+                                    dtype=torch.float16, device=device)
+        neg_dialog, dialog = self.prepare_dialog_bbox(list(dialog_bbox), num_samples)
+        add_text_embeds = pooled_prompt_embeds
+        if do_cfg:
+            prompt_embeds = torch.cat([negative_prompt_embeds, prompt_embeds], dim=0)
+            add_text_embeds = torch.cat([negative_pooled_prompt_embeds, add_text_embeds], dim=0)
+            add_time_ids = torch.cat([add_time_ids, add_time_ids], dim=0)
+            img = torch.cat([neg_img, img], dim=0)
+            dialog = torch.cat([neg_dialog, dialog], dim=0)
+            bbox = torch.cat([neg_bbox, bbox], dim=0)
+        add_time_ids = add_time_ids.repeat(num_samples, 1)
+        enc = torch.cat([prompt_embeds.to(device), img.to(device)], dim=1)
+
+        # ---- denoising loop: one plan replay per step
+        B = enc.shape[0]
+        eng = self.unet.engine(B, H, W, aspect_ratio)
+        eng.build_sampler(num_samples, self.scheduler.kind, do_cfg)
+        eng.set_request(enc, add_text_embeds, add_time_ids, bbox, dialog_pixel_boxes(dialog, H, W), float(ip_scale))
+        eng.load_schedule(torch.from_numpy(self.scheduler.coef_table(float(guidance_scale))))
+        eng.latents.copy_(lat)
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device=device)
+        st = self._stream
+        st.wait_stream(torch.cuda.current_stream(device))
+        graph = False
+        with torch.cuda.stream(st):
+            eng.prep_plan.run(st.cuda_stream)
+            n0 = 0
+            if self.use_graph:
+                if not eng.step_plan.captured:
+                    eng.step_plan.run(st.cuda_stream)          # first step eager (also warms lazy kernel state)
+                    n0 = 1
+                    eng.step_plan.capture(st.cuda_stream)
+                graph = True
+            for _ in range(n0, num_inference_steps):
+                if graph:
+                    eng.step_plan.replay(st.cuda_stream)
+                else:
+                    eng.step_plan.run(st.cuda_stream)
+        torch.cuda.current_stream(device).wait_stream(st)
+        self.last_run_info = {"graph": graph, "ops_per_step": eng.step_plan.n, "batch": B, "latent_hw": (H, W)}
+        out_latents = eng.latents.clone()
+
+        if output_type == "latent" or self.vae is None:
+            if output_type != "latent" and self.vae is None:
+                raise ValueError("no VAE registered: call with output_type='latent'")
+            return StableDiffusionXLPipelineOutput(images=out_latents)
+        scaling = getattr(getattr(self.vae, "config", None), "scaling_factor", 0.13025)
+        image = self.vae.decode(out_latents.float() / scaling, return_dict=False)[0]
+        if output_type == "pt":
+            return StableDiffusionXLPipelineOutput(images=image)
+        image = (image / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1).float().cpu().numpy()
+        from PIL import Image
+        return StableDiffusionXLPipelineOutput(images=[Image.fromarray((im * 255).round().astype("uint8")) for im in image])

@@ -257,6 +257,33 @@ def param_shapes(cfg: UNetMangaConfig) -> "OrderedDict[str, Tuple[int, ...]]":
     return p
 
 
+def random_state_dict(cfg: UNetMangaConfig, seed: int = 0, device="cpu", dtype=None):
+    """Seeded synthetic weights at the configured shapes (no checkpoint is reachable offline).  Scales keep fp16
+    activations O(1): fan-in normal for matrices (half gain on the residual-branch outputs), near-identity norms.
+    Generated on `device` with that device's generator; weight VALUES never affect throughput."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    sd = {}
+    for name, shp in param_shapes(cfg).items():
+        if name.endswith("norm.weight") or ".norm1.weight" in name or ".norm2.weight" in name \
+                or ".norm3.weight" in name or name == "conv_norm_out.weight":
+            t = 1.0 + 0.1 * torch.randn(shp, generator=g, device=device)
+        elif name.endswith(".bias"):
+            t = 0.05 * torch.randn(shp, generator=g, device=device)
+        elif name == "dialog_bbox_embedding":
+            t = torch.randn(shp, generator=g, device=device)
+        else:
+            fan_in = 1
+            for s in shp[1:]:
+                fan_in *= s
+            gain = 0.5 if (name.endswith("to_out.0.weight") or name.endswith("ff.net.2.weight")
+                           or name.endswith("proj_out.weight") or name.endswith("conv2.weight")) else 1.0
+            t = torch.randn(shp, generator=g, device=device) * (gain / fan_in ** 0.5)
+        sd[name] = t if dtype is None else t.to(dtype)
+    return sd
+
+
 def attn_processor_names(cfg: UNetMangaConfig) -> List[str]:
     """Keys of `unet.attn_processors` in diffusers order (reference iterates them at src/models/unet.py:58)."""
     names = []

@@ -33,14 +33,14 @@ int ds_device_info(int* cu_count, int* lds_bytes, char* arch_name, int arch_name
  * Operators.  Each replaces the torch call(s) named in its comment.
  * ---------------------------------------------------------------------------------------------- */
 
-/* y[M,N] = x[M,K] @ w[N,K]^T (+bias[N]) (+residual[M,N]);  geglu != 0: w rows are packed per 128-row tile as
- * 64 "hidden" + 64 "gate" rows and y[M,N/2] = hidden * gelu(gate).
+/* y[M,N] = act(x[M,K] @ w[N,K]^T + bias[N]) (+residual[M,N]).  epilogue: 0 none, 2 GELU(erf), 3 quick-GELU,
+ * 1 GEGLU: w rows are packed per 128-row tile as 64 "hidden" + 64 "gate" rows and y[M,N/2] = hidden * gelu(gate).
  * replaces nn.Linear at reference src/models/attention_processor.py:56,63,64,84,207,225,226,245,246,261 and the
  * diffusers GEGLU/FeedForward/proj_in/proj_out linears reached from src/models/unet.py:244-338.
  * x2/k1: optional second A source for columns k >= k1 (channel concat of two tensors without a copy). */
 int ds_gemm_f16(const void* x, int64_t ldx, const void* x2, int64_t ldx2, int k1, const void* w, int64_t ldw,
                 const void* bias, const void* residual, int64_t ldr, void* y, int64_t ldy, int M, int N, int K,
-                int geglu, void* stream);
+                int epilogue, void* stream);
 
 /* batched variant: grid.z = batch with element strides (0 = shared operand); used for V^T = Wv @ X_b^T */
 int ds_gemm_f16_batched(const void* x, int64_t ldx, int64_t sx, const void* w, int64_t ldw, int64_t sw, void* y,
@@ -74,11 +74,14 @@ int ds_self_attn_f16(const void* q, int64_t ldq, int64_t sq, const void* k, int6
  *   o = softmax(q kt^T * s) vt  +  ip_scale * softmax(q ki^T * s + M(bbox)) vi
  * kt/ki: [B,96,C] key panels (rows >= Lt / Li are padding), vtt/vti: [B,C,96] transposed value panels,
  * bbox: [B,max_ips,4] fp32 relative boxes, (mask_h, mask_w): the grid the reference infers from (N, aspect_ratio).
- * ip_scale_dev: optional device float overriding ip_scale (lets a captured graph follow set_ip_scale). */
+ * ip_scale_dev: optional device float overriding ip_scale (lets a captured graph follow set_ip_scale).
+ * ldk/sk: row / batch stride of the key panels, sv: batch stride of the value panels (elements; 0 = dense) —
+ * the engine projects the text/IP tokens for all 70 layers with one stacked GEMM and hands out column slices. */
 int ds_masked_ip_attn_f16(const void* q, int64_t ldq, const void* kt, const void* vtt, const void* ki,
                           const void* vti, const float* bbox, void* o, int64_t ldo, int B, int heads, int N, int Lt,
                           int Li, int n_dummy, int tok_per_ip, int max_ips, int mask_h, int mask_w, float qk_scale,
-                          float ip_scale, const float* ip_scale_dev, void* stream);
+                          float ip_scale, const float* ip_scale_dev, int64_t ldk, int64_t sk, int64_t sv,
+                          void* stream);
 /* debug/test hook: bit k of flags[b*N+i] = token i inside box k (the reference's inside_bbox_mask) */
 int ds_ip_region_flags(const float* bbox, uint8_t* flags, int B, int N, int max_ips, int mask_h, int mask_w,
                        void* stream);
@@ -128,12 +131,12 @@ int ds_pad_rows_f16(const void* x, void* y, int B, int rows_in, int rows_out, in
  * ---------------------------------------------------------------------------------------------- */
 enum ds_opcode {
     DS_OP_GEMM = 1,          /* p: x, x2, w, y, bias, rowbias, residual   l: ldx ldx2 ldw ldy ldr sx sx2 sw sy sr
-                                i: M N K K1 geglu batch rowbias_ld rows_per_group */
+                                i: M N K K1 epilogue batch rowbias_ld rows_per_group */
     DS_OP_CONV3X3 = 2,       /* p: x, w, y, bias, rowbias, residual       i: B H W Cin Cout stride upsample rowbias_ld */
     DS_OP_GROUPNORM = 3,     /* p: x1, x2, y, gamma, beta, ws             i: B HW C1 C2 groups silu   f: eps */
     DS_OP_LAYERNORM = 4,     /* p: x, y, gamma, beta                      i: rows C                   f: eps */
     DS_OP_SELF_ATTN = 5,     /* p: q, k, vt, o   l: ldq ldk ldv ldo sq sk so   i: B heads Nq Nk       f: scale */
-    DS_OP_IP_ATTN = 6,       /* p: q, kt, vtt, ki, vti, bbox, o, ip_scale_dev   l: ldq ldo
+    DS_OP_IP_ATTN = 6,       /* p: q, kt, vtt, ki, vti, bbox, o, ip_scale_dev   l: ldq ldo ldk sk sv
                                 i: B heads N Lt Li n_dummy tok_per_ip max_ips mask_h mask_w   f: qk_scale ip_scale */
     DS_OP_CONV_IN = 7,       /* p: x, w, bias, boxes, demb, y             i: B H W Cin Cout ndialog */
     DS_OP_CONV_OUT = 8,      /* p: x, w, bias, y                          i: B H W Cin Cout */
@@ -159,6 +162,8 @@ typedef struct ds_op {
 
 typedef struct ds_plan ds_plan;
 int ds_op_run(const ds_op* op, void* stream); /* run one op immediately */
+/* roofline accounting: kernel the op dispatches to (rocprofv3 spelling), algorithmic flops (2*MAC) and HBM bytes */
+int ds_op_describe(const ds_op* op, char* name, int name_len, double* flops, double* bytes);
 int ds_plan_create(const ds_op* ops, int n_ops, ds_plan** out);
 int ds_plan_num_ops(const ds_plan* plan);
 int ds_plan_run(ds_plan* plan, void* stream);            /* eager: one launch per op */

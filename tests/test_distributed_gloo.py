@@ -1,0 +1,80 @@
+"""CPU, world_size 2 over gloo: the N>1 path of the serving layer — bucketed weight broadcast from rank 0,
+deterministic request sharding with no data-path collective, result gather."""
+import os
+import socket
+import sys
+
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from diffsensei_amd.distributed import PanelRequest, broadcast_tensors, init_from_env, run_sharded
+    r, w, _ = init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    # weights: rank 0 holds the seeded values, everyone else garbage -> identical after the broadcast
+    g = torch.Generator().manual_seed(0)
+    shapes = [(320, 4, 3, 3), (1280,), (640, 640), (10240, 1280), (17,)]
+    ws = [torch.randn(s, generator=g).half() if rank == 0 else torch.full(s, float(rank)).half() for s in shapes]
+    ws.append(torch.arange(6, dtype=torch.float32) if rank == 0 else torch.zeros(6))
+    stats = broadcast_tensors(ws, src=0, bucket_bytes=1 << 20)
+    g2 = torch.Generator().manual_seed(0)
+    ok = all(torch.equal(t, torch.randn(s, generator=g2).half()) for t, s in zip(ws[:-1], shapes))
+    ok = ok and torch.equal(ws[-1], torch.arange(6, dtype=torch.float32)) and stats["buckets"] >= 2
+    reqs = [PanelRequest(i, s, s, 50, 1 + (i % 2)) for i, s in enumerate([512, 768, 1024, 1536, 1024, 512, 768, 1024])]
+    seen = []
+
+    def work(req):
+        seen.append(req.request_id)
+        return (rank, req.height)
+
+    out = run_sharded(reqs, work, gather=True)
+    dist.barrier()
+    q.put((rank, ok, seen, out))
+    dist.destroy_process_group()
+
+
+def test_broadcast_and_sharding_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, ok0, seen0, out0), (r1, ok1, seen1, out1) = res
+    assert ok0 and ok1
+    assert sorted(seen0 + seen1) == list(range(8)) and not set(seen0) & set(seen1)
+    assert out1 is None and sorted(out0) == list(range(8))
+    assert all(out0[i][0] == (0 if i in seen0 else 1) for i in range(8))
+
+
+def test_shard_requests_balanced_and_deterministic():
+    from diffsensei_amd.distributed import PanelRequest, shard_requests
+    reqs = [PanelRequest(i, s, s) for i, s in enumerate([512, 768, 1024, 1536] * 8)]
+    a = shard_requests(reqs, 8)
+    b = shard_requests(list(reversed(reqs)), 8)
+    assert [[r.request_id for r in s] for s in a] == [[r.request_id for r in s] for s in b]
+    loads = [sum(r.cost() for r in s) for s in a]
+    assert max(loads) / min(loads) < 1.25
+    assert sum(len(s) for s in a) == 32
+    for s in a:
+        assert [(r.height, r.width) for r in s] == sorted((r.height, r.width) for r in s)
+    assert shard_requests([], 4) == [[], [], [], []]
