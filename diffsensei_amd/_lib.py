@@ -30,6 +30,7 @@ SIGNATURES = {
     "ds_last_error": (C.c_char_p, []),
     "ds_version": (i32, []),
     "ds_device_info": (i32, [C.POINTER(i32), C.POINTER(i32), C.c_char_p, i32]),
+    "ds_set_option": (i32, [C.c_char_p, i32]),
     "ds_gemm_f16": (i32, [vp, i64, vp, i64, i32, vp, i64, vp, vp, i64, vp, i64, i32, i32, i32, i32, vp]),
     "ds_gemm_f16_batched": (i32, [vp, i64, i64, vp, i64, i64, vp, i64, i64, i32, i32, i32, i32, vp]),
     "ds_conv3x3_f16": (i32, [vp, vp, vp, vp, i64, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),

@@ -41,6 +41,17 @@ int ds_device_info(int* cu_count, int* lds_bytes, char* arch_name, int arch_name
     return 0;
 }
 
+int ds_set_option(const char* key, int value) {
+    DS_REQUIRE(key != nullptr, "ds_set_option: null key");
+    if (strcmp(key, "gemm_variant") == 0) {
+        DS_REQUIRE(value >= 0 && value <= 3, "gemm_variant must be 0..3");
+        ds_gemm_set_variant(value);
+        return 0;
+    }
+    ds_set_error("ds_set_option: unknown key '%s'", key);
+    return -1;
+}
+
 int ds_gemm_f16(const void* x, int64_t ldx, const void* x2, int64_t ldx2, int k1, const void* w, int64_t ldw,
                 const void* bias, const void* residual, int64_t ldr, void* y, int64_t ldy, int M, int N, int K,
                 int epilogue, void* stream) {
@@ -281,7 +292,7 @@ int ds_op_describe(const ds_op* op, char* name, int name_len, double* flops, dou
             GemmParams g;
             g.M = i[0]; g.N = i[1]; g.K = i[2];
             const int batch = i[5] > 0 ? i[5] : 1;
-            nm = ds_gemm_uses_small_tile(g, batch) ? "gemm_f16_kernel<64,false>" : "gemm_f16_kernel<128,false>";
+            nm = ds_gemm_kernel_name(g, batch);
             fl = 2.0 * i[0] * (double)i[1] * i[2] * batch;
             by = 2.0 * batch * ((double)i[0] * i[2] + (double)i[1] * i[2] + (double)i[0] * (i[4] == 1 ? i[1] / 2 : i[1]));
             break;
@@ -291,7 +302,8 @@ int ds_op_describe(const ds_op* op, char* name, int name_len, double* flops, dou
             const int Ho = i[6] ? 2 * i[1] : (i[5] == 2 ? (i[1] + 1) / 2 : i[1]);
             const int Wo = i[6] ? 2 * i[2] : (i[5] == 2 ? (i[2] + 1) / 2 : i[2]);
             g.M = i[0] * Ho * Wo; g.N = i[4]; g.K = 9 * i[3];
-            nm = ds_gemm_uses_small_tile(g, 1) ? "gemm_f16_kernel<64,true>" : "gemm_f16_kernel<128,true>";
+            g.conv = 1;
+            nm = ds_gemm_kernel_name(g, 1);
             fl = 2.0 * g.M * (double)g.N * g.K;
             by = 2.0 * ((double)i[0] * i[1] * i[2] * i[3] + (double)g.N * g.K + (double)g.M * g.N);
             break;

@@ -22,7 +22,8 @@ struct GemmParams {
     int tiles_m = 0, tiles_n = 0;
 };
 int ds_launch_gemm(const GemmParams& p, int batch, hipStream_t stream);
-bool ds_gemm_uses_small_tile(const GemmParams& p, int batch);
+const char* ds_gemm_kernel_name(const GemmParams& p, int batch);  // the instantiation ds_launch_gemm dispatches to
+void ds_gemm_set_variant(int v);  // 0 auto, 1 register staging only, 2 glds (BM <= 128), 3 glds, BM = 256 when large
 
 // ---- normalisation ---------------------------------------------------------------------------------
 struct GroupNormParams {

@@ -1,4 +1,4 @@
-// fp16 MFMA GEMM  C[M,N] = A[M,K] * W[N,K]^T  (+bias, +row-group bias, +residual, GEGLU) and the
+// fp16 MFMA GEMM  C[M,N] = A[M,K] * W[N,K]^T  (+bias, +row-group bias, +residual, GEGLU/GELU) and the
 // implicit-GEMM 3x3 convolution over NHWC activations that shares its main loop.
 //
 // Replaces, on the DiffSensei UNet hot path (reference src/models/unet.py:206,244-338 -> diffusers blocks):
@@ -7,14 +7,22 @@
 //   * every 3x3 conv of ResnetBlock2D / Downsample2D / Upsample2D and the 1x1 conv_shortcut
 //
 // CDNA4 design: 256 threads = 4 waves (2x2), block tile BM x 128 x 64, v_mfma_f32_32x32x16_f16 with the
-// operands swapped (D[n][m]) so each lane ends with 4 consecutive output columns of one row; tiles are
-// staged global -> VGPR -> LDS (issue-early / write-late) into two LDS buffers whose 16-byte chunks are
-// XOR-swizzled (chunk ^= (row>>1)&7) so every ds_read_b128 lane group hits 16 distinct slots; the
-// epilogue is staged through LDS so global stores are full 16 B/lane rows.  Convolution gathers its A
-// tile straight from the NHWC tensor (zero-filled halo, optional stride 2, optional fused nearest x2
-// upsample) — no im2col buffer ever exists in HBM.
+// operands swapped (D[n][m]) so each lane ends with 4 consecutive output columns of one row.  LDS tiles are
+// [rows][64 k] with the eight 16-byte chunks of a row XOR-swizzled (chunk ^= (row>>1)&7) so every
+// ds_read_b128 lane group hits 16 distinct slots.  Two staging pipelines:
+//   * gemm_glds_kernel   (K % 64 == 0, the hot path): global_load_lds_dwordx4 straight into LDS — no VGPR round
+//     trip, no ds_write pass; the swizzle is applied to each lane's SOURCE address (the DMA destination is
+//     lane-linear); two LDS buffers, one barrier per k-tile, tile t+1 in flight under the MFMAs of tile t.
+//     Convolution halo / ragged rows are served from a zero page / clamped rows.
+//   * gemm_f16_kernel    (any K % 8 == 0): global -> VGPR -> LDS, predicated loads; generic fallback.
+// The epilogue is staged through LDS so global stores are full 16 B/lane rows.  Convolution gathers its A tile
+// straight from the NHWC tensor (zero halo, optional stride 2, optional fused nearest x2 upsample) — no im2col
+// buffer ever exists in HBM.
 #include "ds_common.h"
 #include "ds_kernels.h"
+
+static int g_gemm_variant = 0;  // 0 auto, 1 force register staging, 2 glds BM<=128, 3 glds prefer BM=256
+void ds_gemm_set_variant(int v) { g_gemm_variant = v; }
 
 namespace {
 
@@ -22,8 +30,257 @@ constexpr int BN = 128;
 constexpr int BK = 64;
 constexpr int CS_STRIDE = 272;  // bytes per row of the epilogue staging tile (128 f16 + 8 pad)
 
+__device__ __attribute__((aligned(256))) char g_zero_page[256];  // zero-initialised: conv halo source
+
 __device__ __forceinline__ int swz(int row, int chunk) { return ((chunk ^ ((row >> 1) & 7)) << 4); }
 
+// ---------------------------------------------------------------------------------------------- MFMA over one k-tile
+template <int BM>
+__device__ __forceinline__ void mma_tile(const char* cA, const char* cB, f32x16 (&acc)[BM / 64][2], int wm, int wn,
+                                         int l31, int lhi) {
+    constexpr int MI = BM / 64;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        h8 af[MI], bf[2];
+        const int ch = kk * 2 + lhi;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int r = wm * (BM / 2) + mi * 32 + l31;
+            af[mi] = *reinterpret_cast<const h8*>(cA + r * 128 + swz(r, ch));
+        }
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int r = wn * 64 + ni * 32 + l31;
+            bf[ni] = *reinterpret_cast<const h8*>(cB + r * 128 + swz(r, ch));
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[ni], af[mi], acc[mi][ni], 0, 0, 0);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- epilogue
+// stage 1: bias / row-group bias, round to f16, park the tile in LDS as [m][n] (BM > 128 goes in 128-row halves);
+// stage 2: coalesced 16-byte rows out of LDS (+ activation, + residual, or GEGLU pairing).
+// D layout (operands swapped): lane holds row m_local = ..+(lane&31); regs r -> n = (r&3)+8*(r>>2)+4*(lane>>5)
+template <int BM>
+__device__ __forceinline__ void epilogue(const GemmParams& p, f32x16 (&acc)[BM / 64][2], char* smem, int m0, int n0,
+                                         long bz, int wm, int wn, int l31, int lhi, int tid) {
+    constexpr int MI = BM / 64;
+    constexpr int HALVES = BM > 128 ? BM / 128 : 1;
+    constexpr int HR = BM / HALVES;  // rows staged per pass
+    char* sC = smem;
+    half_t* Cg = p.C + bz * p.sC;
+    const half_t* Rg = p.residual ? p.residual + bz * p.sR : nullptr;
+#pragma unroll
+    for (int half = 0; half < HALVES; ++half) {
+        if (half) __syncthreads();
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int ml = wm * (BM / 2) + mi * 32 + l31;  // row within the block tile
+            if (ml / HR != half) continue;                   // wave-uniform: (wm, mi) decide the half
+            const int ms = ml - half * HR;
+            const int m = m0 + ml;
+            const int grp = p.rowbias ? ((m < p.M ? m : p.M - 1) / p.rows_per_group) : 0;
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int nl = wn * 64 + ni * 32 + 8 * g + 4 * lhi;
+                    const int n = n0 + nl;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][4 * g + e];
+                    if (n < p.N) {
+                        if (p.bias) {
+                            const h4 bv = *reinterpret_cast<const h4*>(p.bias + n);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] += (float)bv[e];
+                        }
+                        if (p.rowbias) {
+                            const h4 bv = *reinterpret_cast<const h4*>(p.rowbias + (long)grp * p.rowbias_ld + n);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] += (float)bv[e];
+                        }
+                    }
+                    h4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (half_t)v[e];
+                    *reinterpret_cast<h4*>(sC + ms * CS_STRIDE + nl * 2) = o;
+                }
+            }
+        }
+        __syncthreads();
+        const int mh = m0 + half * HR;
+        if (p.epi == EPI_GEGLU) {
+            // packed weight rows: each 128-row tile = 64 "hidden" columns followed by their 64 "gate" columns
+            constexpr int IT = HR * 8 / 256;
+#pragma unroll
+            for (int j = 0; j < IT; ++j) {
+                const int id = tid + 256 * j;
+                const int row = id >> 3, c = id & 7;
+                const int m = mh + row, n = (n0 >> 1) + c * 8;
+                if (m < p.M && n < (p.N >> 1)) {
+                    const h8 hv = *reinterpret_cast<const h8*>(sC + row * CS_STRIDE + c * 16);
+                    const h8 gv = *reinterpret_cast<const h8*>(sC + row * CS_STRIDE + 128 + c * 16);
+                    h8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const half_t ge = (half_t)ds_gelu_erf((float)gv[e]);
+                        o[e] = (half_t)((float)hv[e] * (float)ge);
+                    }
+                    *reinterpret_cast<h8*>(Cg + (long)m * p.ldc + n) = o;
+                }
+            }
+        } else {
+            constexpr int IT = HR * 16 / 256;
+#pragma unroll
+            for (int j = 0; j < IT; ++j) {
+                const int id = tid + 256 * j;
+                const int row = id >> 4, c = id & 15;
+                const int m = mh + row, n = n0 + c * 8;
+                if (m < p.M && n < p.N) {
+                    h8 v = *reinterpret_cast<const h8*>(sC + row * CS_STRIDE + c * 16);
+                    if (p.epi == EPI_GELU) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = (half_t)ds_gelu_erf((float)v[e]);
+                    } else if (p.epi == EPI_QUICK_GELU) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float f = (float)v[e];
+                            v[e] = (half_t)(f / (1.0f + __expf(-1.702f * f)));
+                        }
+                    }
+                    if (Rg) {
+                        const h8 rv = *reinterpret_cast<const h8*>(Rg + (long)m * p.ldr + n);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rv[e]);
+                    }
+                    *reinterpret_cast<h8*>(Cg + (long)m * p.ldc + n) = v;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- glds pipeline
+template <int BM, bool CONV>
+__global__ __launch_bounds__(256, (BM > 128 ? 1 : 2)) void gemm_glds_kernel(const GemmParams p) {
+    constexpr int MI = BM / 64;
+    constexpr int ASEG = BM / 32;  // 1-KiB (8-row) A segments per wave per k-tile
+    constexpr int BSEG = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sA = smem;
+    char* sB = smem + 2 * BM * 128;
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef const __attribute__((address_space(1))) void glb_void;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const long bz = blockIdx.z;
+    const int lrow = lane >> 3, slot = lane & 7;
+
+    // per-lane source descriptors: lane writes LDS slot `slot` of row `row`, so it must fetch the chunk that the
+    // swizzle maps there: chunk = slot ^ ((row>>1)&7)
+    const half_t* a1[ASEG];
+    const half_t* a2[ASEG];
+    int a_pb[ASEG], a_oy[ASEG], a_ox[ASEG], a_ch[ASEG];
+#pragma unroll
+    for (int j = 0; j < ASEG; ++j) {
+        const int row = (wave * ASEG + j) * 8 + lrow;
+        const int chunk = slot ^ ((row >> 1) & 7);
+        const int m = min(m0 + row, p.M - 1);
+        a_ch[j] = chunk * 8;
+        if constexpr (CONV) {
+            const int hw = p.Hout * p.Wout;
+            const int b = m / hw, rem = m - b * hw;
+            a_oy[j] = rem / p.Wout;
+            a_ox[j] = rem - a_oy[j] * p.Wout;
+            a_pb[j] = b * p.Hin * p.Win;
+            a1[j] = a2[j] = p.A;
+        } else {
+            a1[j] = p.A + bz * p.sA + (long)m * p.lda + chunk * 8;
+            a2[j] = p.A2 ? p.A2 + bz * p.sA2 + (long)m * p.lda2 + chunk * 8 : a1[j];
+            a_pb[j] = a_oy[j] = a_ox[j] = 0;
+        }
+    }
+    const half_t* wrow[BSEG];
+#pragma unroll
+    for (int j = 0; j < BSEG; ++j) {
+        const int row = (wave * BSEG + j) * 8 + lrow;
+        const int chunk = slot ^ ((row >> 1) & 7);
+        const int n = min(n0 + row, p.N - 1);
+        wrow[j] = p.W + bz * p.sW + (long)n * p.ldw + chunk * 8;
+    }
+
+    auto issue = [&](int kt, int buf) {
+        const int k0 = kt * BK;
+        char* dA = sA + buf * BM * 128 + wave * ASEG * 1024;
+        char* dB = sB + buf * BN * 128 + wave * BSEG * 1024;
+        if constexpr (CONV) {
+            const int tap = k0 / p.Cin;
+            const int ci0 = k0 - tap * p.Cin;
+            const int ky = tap / 3, kx = tap - 3 * ky;
+#pragma unroll
+            for (int j = 0; j < ASEG; ++j) {
+                int iy, ix;
+                bool ok;
+                if (p.upsample) {
+                    const int uy = a_oy[j] + ky - 1, ux = a_ox[j] + kx - 1;
+                    ok = (uy >= 0) & (uy < p.Hout) & (ux >= 0) & (ux < p.Wout);
+                    iy = uy >> 1;
+                    ix = ux >> 1;
+                } else {
+                    iy = a_oy[j] * p.cstride + ky - 1;
+                    ix = a_ox[j] * p.cstride + kx - 1;
+                    ok = (iy >= 0) & (iy < p.Hin) & (ix >= 0) & (ix < p.Win);
+                }
+                const long off = ((long)a_pb[j] + (long)iy * p.Win + ix) * p.Cin + ci0 + a_ch[j];
+                const void* src = ok ? (const void*)(p.A + off) : (const void*)g_zero_page;
+                __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(dA + j * 1024), 16, 0, 0);
+            }
+        } else {
+            const bool first = k0 < p.K1;
+#pragma unroll
+            for (int j = 0; j < ASEG; ++j) {
+                const half_t* src = first ? a1[j] + k0 : a2[j] + (k0 - p.K1);
+                __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(dA + j * 1024), 16, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < BSEG; ++j)
+            __builtin_amdgcn_global_load_lds((glb_void*)(wrow[j] + k0), (lds_void*)(dB + j * 1024), 16, 0, 0);
+    };
+
+    f32x16 acc[MI][2];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = p.K / BK;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    issue(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA for tile kt has landed
+        __syncthreads();                                   // ... everyone's has; everyone finished tile kt-1
+        if (kt + 1 < nk) issue(kt + 1, buf ^ 1);           // tile kt+1 flies under the MFMAs of tile kt
+        mma_tile<BM>(sA + buf * BM * 128, sB + buf * BN * 128, acc, wm, wn, l31, lhi);
+    }
+    __syncthreads();
+    epilogue<BM>(p, acc, smem, m0, n0, bz, wm, wn, l31, lhi, tid);
+}
+
+// ---------------------------------------------------------------------------------------------- register staging
 template <int BM, bool CONV>
 __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const GemmParams p) {
     constexpr int MI = BM / 64;   // 32-row fragments per wave along M
@@ -40,10 +297,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const GemmParams p) {
     const int m0 = tm * BM, n0 = tn * BN;
     const long bz = blockIdx.z;
 
-    const int c8 = tid & 7;       // 16-byte chunk within the 128-byte k-row
-    const int r0 = tid >> 3;      // first row handled by this thread (then +32 per chunk)
+    const int c8 = tid & 7;   // 16-byte chunk within the 128-byte k-row
+    const int r0 = tid >> 3;  // first row handled by this thread (then +32 per chunk)
 
-    // ---- per-thread A row descriptors
     const half_t* a1[ACH];
     const half_t* a2[ACH];
     bool a_ok[ACH];
@@ -147,147 +403,59 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const GemmParams p) {
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) load_tile(kt + 1);
-        const char* cA = sA + buf * BM * 128;
-        const char* cB = sB + buf * BN * 128;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            h8 af[MI], bf[2];
-            const int ch = kk * 2 + lhi;
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-                const int r = wm * (BM / 2) + mi * 32 + l31;
-                af[mi] = *reinterpret_cast<const h8*>(cA + r * 128 + swz(r, ch));
-            }
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-                const int r = wn * 64 + ni * 32 + l31;
-                bf[ni] = *reinterpret_cast<const h8*>(cB + r * 128 + swz(r, ch));
-            }
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[ni], af[mi], acc[mi][ni], 0, 0, 0);
-        }
+        mma_tile<BM>(sA + buf * BM * 128, sB + buf * BN * 128, acc, wm, wn, l31, lhi);
         if (kt + 1 < nk) store_tile(buf ^ 1);
         __syncthreads();
     }
-
-    // ---- epilogue, stage 1: bias / row-group bias, round to f16, park the tile in LDS as [m][n]
-    // D layout (operands swapped): lane holds row m_local = ..+(lane&31); regs r -> n = (r&3)+8*(r>>2)+4*(lane>>5)
-    char* sC = smem;
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-        const int ml = wm * (BM / 2) + mi * 32 + l31;
-        const int m = m0 + ml;
-        const int grp = p.rowbias ? ((m < p.M ? m : p.M - 1) / p.rows_per_group) : 0;
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int nl = wn * 64 + ni * 32 + 8 * g + 4 * lhi;
-                const int n = n0 + nl;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][4 * g + e];
-                if (n < p.N) {
-                    if (p.bias) {
-                        const h4 bv = *reinterpret_cast<const h4*>(p.bias + n);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += (float)bv[e];
-                    }
-                    if (p.rowbias) {
-                        const h4 bv = *reinterpret_cast<const h4*>(p.rowbias + (long)grp * p.rowbias_ld + n);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += (float)bv[e];
-                    }
-                }
-                h4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (half_t)v[e];
-                *reinterpret_cast<h4*>(sC + ml * CS_STRIDE + nl * 2) = o;
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- epilogue, stage 2: coalesced 16-byte rows out of LDS (+ residual, or GEGLU pairing)
-    half_t* Cg = p.C + bz * p.sC;
-    if (p.epi == EPI_GEGLU) {
-        // packed weight rows: each 128-row tile = 64 "hidden" columns followed by their 64 "gate" columns
-        constexpr int IT = BM * 8 / 256;
-#pragma unroll
-        for (int j = 0; j < IT; ++j) {
-            const int id = tid + 256 * j;
-            const int row = id >> 3, c = id & 7;
-            const int m = m0 + row, n = (n0 >> 1) + c * 8;
-            if (m < p.M && n < (p.N >> 1)) {
-                const h8 hv = *reinterpret_cast<const h8*>(sC + row * CS_STRIDE + c * 16);
-                const h8 gv = *reinterpret_cast<const h8*>(sC + row * CS_STRIDE + 128 + c * 16);
-                h8 o;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const half_t ge = (half_t)ds_gelu_erf((float)gv[e]);
-                    o[e] = (half_t)((float)hv[e] * (float)ge);
-                }
-                *reinterpret_cast<h8*>(Cg + (long)m * p.ldc + n) = o;
-            }
-        }
-    } else {
-        constexpr int IT = BM * 16 / 256;
-        const half_t* Rg = p.residual ? p.residual + bz * p.sR : nullptr;
-#pragma unroll
-        for (int j = 0; j < IT; ++j) {
-            const int id = tid + 256 * j;
-            const int row = id >> 4, c = id & 15;
-            const int m = m0 + row, n = n0 + c * 8;
-            if (m < p.M && n < p.N) {
-                h8 v = *reinterpret_cast<const h8*>(sC + row * CS_STRIDE + c * 16);
-                if (p.epi == EPI_GELU) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = (half_t)ds_gelu_erf((float)v[e]);
-                } else if (p.epi == EPI_QUICK_GELU) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float f = (float)v[e];
-                        v[e] = (half_t)(f / (1.0f + __expf(-1.702f * f)));
-                    }
-                }
-                if (Rg) {
-                    const h8 rv = *reinterpret_cast<const h8*>(Rg + (long)m * p.ldr + n);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rv[e]);
-                }
-                *reinterpret_cast<h8*>(Cg + (long)m * p.ldc + n) = v;
-            }
-        }
-    }
+    epilogue<BM>(p, acc, smem, m0, n0, bz, wm, wn, l31, lhi, tid);
 }
 
-template <int BM, bool CONV>
+template <int BM, bool CONV, bool GLDS>
 int launch(const GemmParams& p0, int batch, hipStream_t stream) {
     GemmParams p = p0;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
     const size_t lds = 2 * BM * 128 + 2 * BN * 128;
+    auto kern = GLDS ? gemm_glds_kernel<BM, CONV> : gemm_f16_kernel<(BM > 128 ? 128 : BM), CONV>;
     static bool attr_set = false;
     if (!attr_set) {
-        DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_kernel<BM, CONV>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds));
         attr_set = true;
     }
     dim3 grid(p.tiles_m * p.tiles_n, 1, batch);
-    hipLaunchKernelGGL((gemm_f16_kernel<BM, CONV>), grid, dim3(256), lds, stream, p);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p);
     DS_LAUNCH_CHECK();
     return 0;
 }
 
+struct Choice {
+    int bm;
+    bool glds;
+};
+
+Choice choose(const GemmParams& p, int batch) {
+    const long tiles128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * batch;
+    const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 127) / 128) * batch;
+    Choice c;
+    c.glds = (p.K % 64 == 0) && g_gemm_variant != 1;
+    c.bm = (tiles128 < 384 || p.M <= 64) ? 64 : 128;
+    if (c.glds && g_gemm_variant == 3 && tiles256 >= 512) c.bm = 256;
+    return c;
+}
+
 }  // namespace
 
-// pick BM: small problems get 64-row tiles so the grid covers the 256 CUs
-bool ds_gemm_uses_small_tile(const GemmParams& p, int batch) {
-    const long tiles128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * batch;
-    return tiles128 < 384 || p.M <= 64;
+const char* ds_gemm_kernel_name(const GemmParams& p, int batch) {
+    const Choice c = choose(p, batch);
+    const bool conv = p.conv != 0;
+    if (c.glds) {
+        if (c.bm == 256) return conv ? "gemm_glds_kernel<256,true>" : "gemm_glds_kernel<256,false>";
+        if (c.bm == 128) return conv ? "gemm_glds_kernel<128,true>" : "gemm_glds_kernel<128,false>";
+        return conv ? "gemm_glds_kernel<64,true>" : "gemm_glds_kernel<64,false>";
+    }
+    if (c.bm == 128) return conv ? "gemm_f16_kernel<128,true>" : "gemm_f16_kernel<128,false>";
+    return conv ? "gemm_f16_kernel<64,true>" : "gemm_f16_kernel<64,false>";
 }
 
 int ds_launch_gemm(const GemmParams& p, int batch, hipStream_t stream) {
@@ -304,7 +472,17 @@ int ds_launch_gemm(const GemmParams& p, int batch, hipStream_t stream) {
         DS_REQUIRE(p.A2 == nullptr || (p.K1 % 64 == 0 && p.lda2 % 8 == 0), "gemm: split-A needs K1 %% 64 == 0");
     }
     if (p.epi == EPI_GEGLU) DS_REQUIRE(p.N % 128 == 0, "geglu: packed N (%d) must be a multiple of 128", p.N);
-    const bool small = ds_gemm_uses_small_tile(p, batch);
-    if (conv) return small ? launch<64, true>(p, batch, stream) : launch<128, true>(p, batch, stream);
-    return small ? launch<64, false>(p, batch, stream) : launch<128, false>(p, batch, stream);
+    const Choice c = choose(p, batch);
+    if (c.glds) {
+        if (conv) {
+            if (c.bm == 256) return launch<256, true, true>(p, batch, stream);
+            if (c.bm == 128) return launch<128, true, true>(p, batch, stream);
+            return launch<64, true, true>(p, batch, stream);
+        }
+        if (c.bm == 256) return launch<256, false, true>(p, batch, stream);
+        if (c.bm == 128) return launch<128, false, true>(p, batch, stream);
+        return launch<64, false, true>(p, batch, stream);
+    }
+    if (conv) return c.bm == 64 ? launch<64, true, false>(p, batch, stream) : launch<128, true, false>(p, batch, stream);
+    return c.bm == 64 ? launch<64, false, false>(p, batch, stream) : launch<128, false, false>(p, batch, stream);
 }

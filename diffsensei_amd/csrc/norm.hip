@@ -55,7 +55,22 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GroupNormParams p) {
         const bool first = g.c < p.C1;
         const half_t* src = first ? p.x1 + (long)b * p.HW * p.C1 + g.c : p.x2 + (long)b * p.HW * p.C2 + (g.c - p.C1);
         const int ld = first ? p.C1 : p.C2;
-        for (int row = g.row_start; row < g.row_end; row += g.R) {
+        int row = g.row_start;
+        const long step = (long)g.R * ld;
+        for (; row + 3 * g.R < g.row_end; row += 4 * g.R) {  // 4 independent 16-byte loads in flight per lane
+            const half_t* q = src + (long)row * ld;
+            const h8 v0 = *reinterpret_cast<const h8*>(q);
+            const h8 v1 = *reinterpret_cast<const h8*>(q + step);
+            const h8 v2 = *reinterpret_cast<const h8*>(q + 2 * step);
+            const h8 v3 = *reinterpret_cast<const h8*>(q + 3 * step);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float f0 = (float)v0[e], f1 = (float)v1[e], f2 = (float)v2[e], f3 = (float)v3[e];
+                s[e] += (f0 + f1) + (f2 + f3);
+                ss[e] += fmaf(f0, f0, f1 * f1) + fmaf(f2, f2, f3 * f3);
+            }
+        }
+        for (; row < g.row_end; row += g.R) {
             const h8 v = *reinterpret_cast<const h8*>(src + (long)row * ld);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -98,7 +113,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(GroupNormParams p, int
     float* tabA = p.ws + (long)gridDim.x * nchunks * C * 2 + (long)b * C * 2;
     float* tabS = tabA + C;
     const float inv_n = 1.0f / ((float)cpg * (float)p.HW);
-    for (int g = wave; g < p.groups; g += 4) {
+    for (int g = blockIdx.y * 4 + wave; g < p.groups; g += 4 * gridDim.y) {
         float s = 0.f, ss = 0.f;
         const int items = nchunks * cpg;
         for (int i = lane; i < items; i += 64) {
@@ -138,8 +153,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GroupNormParams p, int nc
     const half_t* src = first ? p.x1 + (long)b * p.HW * p.C1 + g.c : p.x2 + (long)b * p.HW * p.C2 + (g.c - p.C1);
     const int ld = first ? p.C1 : p.C2;
     half_t* dst = p.y + (long)b * p.HW * C + g.c;
-    for (int row = g.row_start; row < g.row_end; row += g.R) {
-        const h8 v = *reinterpret_cast<const h8*>(src + (long)row * ld);
+    auto norm8 = [&](const h8& v) {
         h8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -147,7 +161,25 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GroupNormParams p, int nc
             if (p.silu) f = ds_silu(f);
             o[e] = (half_t)f;
         }
-        *reinterpret_cast<h8*>(dst + (long)row * C) = o;
+        return o;
+    };
+    int row = g.row_start;
+    const long step = (long)g.R * ld, dstep = (long)g.R * C;
+    for (; row + 3 * g.R < g.row_end; row += 4 * g.R) {  // 4 independent 16-byte loads in flight per lane
+        const half_t* q = src + (long)row * ld;
+        const h8 v0 = *reinterpret_cast<const h8*>(q);
+        const h8 v1 = *reinterpret_cast<const h8*>(q + step);
+        const h8 v2 = *reinterpret_cast<const h8*>(q + 2 * step);
+        const h8 v3 = *reinterpret_cast<const h8*>(q + 3 * step);
+        half_t* d = dst + (long)row * C;
+        *reinterpret_cast<h8*>(d) = norm8(v0);
+        *reinterpret_cast<h8*>(d + dstep) = norm8(v1);
+        *reinterpret_cast<h8*>(d + 2 * dstep) = norm8(v2);
+        *reinterpret_cast<h8*>(d + 3 * dstep) = norm8(v3);
+    }
+    for (; row < g.row_end; row += g.R) {
+        const h8 v = *reinterpret_cast<const h8*>(src + (long)row * ld);
+        *reinterpret_cast<h8*>(dst + (long)row * C) = norm8(v);
     }
 }
 
@@ -217,7 +249,7 @@ int ds_launch_groupnorm(const GroupNormParams& p, hipStream_t stream) {
     const int nslab = ((C >> 3) + 255) / 256;
     dim3 grid(nslab, nch, p.B);
     hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), 0, stream, p);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(p.B), dim3(256), 0, stream, p, nch);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(p.B, (p.groups + 3) / 4), dim3(256), 0, stream, p, nch);
     hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(256), 0, stream, p, nch);
     DS_LAUNCH_CHECK();
     return 0;
