@@ -85,6 +85,10 @@ def load() -> C.CDLL:
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    v = os.environ.get("DS_GEMM_VARIANT")
+    if v is not None:  # tuning/A-B knob only; 0 = the library's own choice
+        if lib.ds_set_option(b"gemm_variant", int(v)) != 0:
+            raise DiffSenseiHipError(lib.ds_last_error().decode())
     return lib
 
 

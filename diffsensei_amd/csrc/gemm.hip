@@ -21,7 +21,7 @@
 #include "ds_common.h"
 #include "ds_kernels.h"
 
-static int g_gemm_variant = 0;  // 0 auto, 1 force register staging, 2 glds BM<=128, 3 glds prefer BM=256
+static int g_gemm_variant = 0;  // 0 auto, 1 register staging, 2 glds BM<=128, 3 glds BM=256 (4 waves), 4 8-wave ring
 void ds_gemm_set_variant(int v) { g_gemm_variant = v; }
 
 namespace {
@@ -35,17 +35,17 @@ __device__ __attribute__((aligned(256))) char g_zero_page[256];  // zero-initial
 __device__ __forceinline__ int swz(int row, int chunk) { return ((chunk ^ ((row >> 1) & 7)) << 4); }
 
 // ---------------------------------------------------------------------------------------------- MFMA over one k-tile
-template <int BM>
-__device__ __forceinline__ void mma_tile(const char* cA, const char* cB, f32x16 (&acc)[BM / 64][2], int wm, int wn,
+template <int WR>  // WR = rows of the block tile owned by one wave (32 * MI)
+__device__ __forceinline__ void mma_tile(const char* cA, const char* cB, f32x16 (&acc)[WR / 32][2], int wm, int wn,
                                          int l31, int lhi) {
-    constexpr int MI = BM / 64;
+    constexpr int MI = WR / 32;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
         h8 af[MI], bf[2];
         const int ch = kk * 2 + lhi;
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
-            const int r = wm * (BM / 2) + mi * 32 + l31;
+            const int r = wm * WR + mi * 32 + l31;
             af[mi] = *reinterpret_cast<const h8*>(cA + r * 128 + swz(r, ch));
         }
 #pragma unroll
@@ -65,10 +65,10 @@ __device__ __forceinline__ void mma_tile(const char* cA, const char* cB, f32x16 
 // stage 1: bias / row-group bias, round to f16, park the tile in LDS as [m][n] (BM > 128 goes in 128-row halves);
 // stage 2: coalesced 16-byte rows out of LDS (+ activation, + residual, or GEGLU pairing).
 // D layout (operands swapped): lane holds row m_local = ..+(lane&31); regs r -> n = (r&3)+8*(r>>2)+4*(lane>>5)
-template <int BM>
-__device__ __forceinline__ void epilogue(const GemmParams& p, f32x16 (&acc)[BM / 64][2], char* smem, int m0, int n0,
+template <int BM, int WR, int NT>  // block rows, rows per wave, threads per block
+__device__ __forceinline__ void epilogue(const GemmParams& p, f32x16 (&acc)[WR / 32][2], char* smem, int m0, int n0,
                                          long bz, int wm, int wn, int l31, int lhi, int tid) {
-    constexpr int MI = BM / 64;
+    constexpr int MI = WR / 32;
     constexpr int HALVES = BM > 128 ? BM / 128 : 1;
     constexpr int HR = BM / HALVES;  // rows staged per pass
     char* sC = smem;
@@ -79,7 +79,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x16 (&acc)[BM /
         if (half) __syncthreads();
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
-            const int ml = wm * (BM / 2) + mi * 32 + l31;  // row within the block tile
+            const int ml = wm * WR + mi * 32 + l31;  // row within the block tile
             if (ml / HR != half) continue;                   // wave-uniform: (wm, mi) decide the half
             const int ms = ml - half * HR;
             const int m = m0 + ml;
@@ -116,10 +116,10 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x16 (&acc)[BM /
         const int mh = m0 + half * HR;
         if (p.epi == EPI_GEGLU) {
             // packed weight rows: each 128-row tile = 64 "hidden" columns followed by their 64 "gate" columns
-            constexpr int IT = HR * 8 / 256;
+            constexpr int IT = HR * 8 / NT;
 #pragma unroll
             for (int j = 0; j < IT; ++j) {
-                const int id = tid + 256 * j;
+                const int id = tid + NT * j;
                 const int row = id >> 3, c = id & 7;
                 const int m = mh + row, n = (n0 >> 1) + c * 8;
                 if (m < p.M && n < (p.N >> 1)) {
@@ -135,10 +135,10 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x16 (&acc)[BM /
                 }
             }
         } else {
-            constexpr int IT = HR * 16 / 256;
+            constexpr int IT = HR * 16 / NT;
 #pragma unroll
             for (int j = 0; j < IT; ++j) {
-                const int id = tid + 256 * j;
+                const int id = tid + NT * j;
                 const int row = id >> 4, c = id & 15;
                 const int m = mh + row, n = n0 + c * 8;
                 if (m < p.M && n < p.N) {
@@ -181,7 +181,8 @@ __global__ __launch_bounds__(256, (BM > 128 ? 1 : 2)) void gemm_glds_kernel(cons
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
+    int tm, tn;
+    tile_coords(tile, p.tiles_m, p.tiles_n, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
     const long bz = blockIdx.z;
     const int lrow = lane >> 3, slot = lane & 7;
@@ -274,10 +275,130 @@ __global__ __launch_bounds__(256, (BM > 128 ? 1 : 2)) void gemm_glds_kernel(cons
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA for tile kt has landed
         __syncthreads();                                   // ... everyone's has; everyone finished tile kt-1
         if (kt + 1 < nk) issue(kt + 1, buf ^ 1);           // tile kt+1 flies under the MFMAs of tile kt
-        mma_tile<BM>(sA + buf * BM * 128, sB + buf * BN * 128, acc, wm, wn, l31, lhi);
+        mma_tile<BM / 2>(sA + buf * BM * 128, sB + buf * BN * 128, acc, wm, wn, l31, lhi);
     }
     __syncthreads();
-    epilogue<BM>(p, acc, smem, m0, n0, bz, wm, wn, l31, lhi, tid);
+    epilogue<BM, BM / 2, 256>(p, acc, smem, m0, n0, bz, wm, wn, l31, lhi, tid);
+}
+
+// ---------------------------------------------------------------------------------------------- 8-wave, 3-stage ring
+// Tile 256 x 128 x 64, 512 threads = 8 waves (4 along M x 2 along N, 64x64 per wave, two waves per SIMD), one block
+// per CU.  Three LDS stages (3 x 48 KiB): the DMA of tile t+2 is issued while tile t is multiplied, and the wait is
+// COUNTED — s_waitcnt vmcnt(6) retires exactly the oldest tile (6 LDS-DMA pieces per wave per tile) and leaves the
+// next one in flight across the barrier.  A raw s_barrier is used: __syncthreads() would drain vmcnt to 0.
+template <bool CONV>
+__global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const GemmParams p) {
+    constexpr int BM = 256, ASEG = 4, BSEG = 2, STAGE = (BM + BN) * 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef const __attribute__((address_space(1))) void glb_void;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    int tm, tn;
+    tile_coords(tile, p.tiles_m, p.tiles_n, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const long bz = blockIdx.z;
+    const int lrow = lane >> 3, slot = lane & 7;
+
+    const half_t* a1[ASEG];
+    const half_t* a2[ASEG];
+    int a_pb[ASEG], a_oy[ASEG], a_ox[ASEG], a_ch[ASEG];
+#pragma unroll
+    for (int j = 0; j < ASEG; ++j) {
+        const int row = (wave * ASEG + j) * 8 + lrow;
+        const int chunk = slot ^ ((row >> 1) & 7);
+        const int m = min(m0 + row, p.M - 1);
+        a_ch[j] = chunk * 8;
+        if constexpr (CONV) {
+            const int hw = p.Hout * p.Wout;
+            const int b = m / hw, rem = m - b * hw;
+            a_oy[j] = rem / p.Wout;
+            a_ox[j] = rem - a_oy[j] * p.Wout;
+            a_pb[j] = b * p.Hin * p.Win;
+            a1[j] = a2[j] = p.A;
+        } else {
+            a1[j] = p.A + bz * p.sA + (long)m * p.lda + chunk * 8;
+            a2[j] = p.A2 ? p.A2 + bz * p.sA2 + (long)m * p.lda2 + chunk * 8 : a1[j];
+            a_pb[j] = a_oy[j] = a_ox[j] = 0;
+        }
+    }
+    const half_t* wrow[BSEG];
+#pragma unroll
+    for (int j = 0; j < BSEG; ++j) {
+        const int row = (wave * BSEG + j) * 8 + lrow;
+        const int chunk = slot ^ ((row >> 1) & 7);
+        const int n = min(n0 + row, p.N - 1);
+        wrow[j] = p.W + bz * p.sW + (long)n * p.ldw + chunk * 8;
+    }
+
+    auto issue = [&](int kt, int stage) {
+        const int k0 = kt * BK;
+        char* dA = smem + stage * STAGE + wave * ASEG * 1024;
+        char* dB = smem + stage * STAGE + BM * 128 + wave * BSEG * 1024;
+        if constexpr (CONV) {
+            const int tap = k0 / p.Cin;
+            const int ci0 = k0 - tap * p.Cin;
+            const int ky = tap / 3, kx = tap - 3 * ky;
+#pragma unroll
+            for (int j = 0; j < ASEG; ++j) {
+                int iy, ix;
+                bool ok;
+                if (p.upsample) {
+                    const int uy = a_oy[j] + ky - 1, ux = a_ox[j] + kx - 1;
+                    ok = (uy >= 0) & (uy < p.Hout) & (ux >= 0) & (ux < p.Wout);
+                    iy = uy >> 1;
+                    ix = ux >> 1;
+                } else {
+                    iy = a_oy[j] * p.cstride + ky - 1;
+                    ix = a_ox[j] * p.cstride + kx - 1;
+                    ok = (iy >= 0) & (iy < p.Hin) & (ix >= 0) & (ix < p.Win);
+                }
+                const long off = ((long)a_pb[j] + (long)iy * p.Win + ix) * p.Cin + ci0 + a_ch[j];
+                const void* src = ok ? (const void*)(p.A + off) : (const void*)g_zero_page;
+                __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(dA + j * 1024), 16, 0, 0);
+            }
+        } else {
+            const bool first = k0 < p.K1;
+#pragma unroll
+            for (int j = 0; j < ASEG; ++j) {
+                const half_t* src = first ? a1[j] + k0 : a2[j] + (k0 - p.K1);
+                __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(dA + j * 1024), 16, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < BSEG; ++j)
+            __builtin_amdgcn_global_load_lds((glb_void*)(wrow[j] + k0), (lds_void*)(dB + j * 1024), 16, 0, 0);
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = p.K / BK;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    int stage = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        // retire tile kt (oldest); tile kt+1, if any, stays in flight across the barrier
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // every wave's pieces of tile kt landed; every wave is done with tile kt-1
+        if (kt + 2 < nk) issue(kt + 2, stage == 0 ? 2 : stage - 1);  // (kt+2)%3 == (kt-1)%3: the stage just released
+        const char* base = smem + stage * STAGE;
+        mma_tile<64>(base, base + BM * 128, acc, wm, wn, l31, lhi);
+        stage = stage == 2 ? 0 : stage + 1;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    epilogue<BM, 64, 512>(p, acc, smem, m0, n0, bz, wm, wn, l31, lhi, tid);
 }
 
 // ---------------------------------------------------------------------------------------------- register staging
@@ -293,7 +414,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const GemmParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
+    int tm, tn;
+    tile_coords(tile, p.tiles_m, p.tiles_n, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
     const long bz = blockIdx.z;
 
@@ -403,11 +525,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const GemmParams p) {
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) load_tile(kt + 1);
-        mma_tile<BM>(sA + buf * BM * 128, sB + buf * BN * 128, acc, wm, wn, l31, lhi);
+        mma_tile<BM / 2>(sA + buf * BM * 128, sB + buf * BN * 128, acc, wm, wn, l31, lhi);
         if (kt + 1 < nk) store_tile(buf ^ 1);
         __syncthreads();
     }
-    epilogue<BM>(p, acc, smem, m0, n0, bz, wm, wn, l31, lhi, tid);
+    epilogue<BM, BM / 2, 256>(p, acc, smem, m0, n0, bz, wm, wn, l31, lhi, tid);
 }
 
 template <int BM, bool CONV, bool GLDS>
@@ -429,9 +551,28 @@ int launch(const GemmParams& p0, int batch, hipStream_t stream) {
     return 0;
 }
 
+template <bool CONV>
+int launch_ring(const GemmParams& p0, int batch, hipStream_t stream) {
+    GemmParams p = p0;
+    p.tiles_m = (p.M + 255) / 256;
+    p.tiles_n = (p.N + BN - 1) / BN;
+    const size_t lds = 3 * (256 + BN) * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring_kernel<CONV>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    dim3 grid(p.tiles_m * p.tiles_n, 1, batch);
+    hipLaunchKernelGGL(gemm_ring_kernel<CONV>, grid, dim3(512), lds, stream, p);
+    DS_LAUNCH_CHECK();
+    return 0;
+}
+
 struct Choice {
     int bm;
     bool glds;
+    bool ring;
 };
 
 Choice choose(const GemmParams& p, int batch) {
@@ -441,6 +582,7 @@ Choice choose(const GemmParams& p, int batch) {
     c.glds = (p.K % 64 == 0) && g_gemm_variant != 1;
     c.bm = (tiles128 < 384 || p.M <= 64) ? 64 : 128;
     if (c.glds && g_gemm_variant == 3 && tiles256 >= 512) c.bm = 256;
+    c.ring = c.glds && g_gemm_variant == 4 && tiles256 >= 192 && p.K >= 128;
     return c;
 }
 
@@ -449,6 +591,7 @@ Choice choose(const GemmParams& p, int batch) {
 const char* ds_gemm_kernel_name(const GemmParams& p, int batch) {
     const Choice c = choose(p, batch);
     const bool conv = p.conv != 0;
+    if (c.ring) return conv ? "gemm_ring_kernel<true>" : "gemm_ring_kernel<false>";
     if (c.glds) {
         if (c.bm == 256) return conv ? "gemm_glds_kernel<256,true>" : "gemm_glds_kernel<256,false>";
         if (c.bm == 128) return conv ? "gemm_glds_kernel<128,true>" : "gemm_glds_kernel<128,false>";
@@ -473,6 +616,7 @@ int ds_launch_gemm(const GemmParams& p, int batch, hipStream_t stream) {
     }
     if (p.epi == EPI_GEGLU) DS_REQUIRE(p.N % 128 == 0, "geglu: packed N (%d) must be a multiple of 128", p.N);
     const Choice c = choose(p, batch);
+    if (c.ring) return conv ? launch_ring<true>(p, batch, stream) : launch_ring<false>(p, batch, stream);
     if (c.glds) {
         if (conv) {
             if (c.bm == 256) return launch<256, true, true>(p, batch, stream);
