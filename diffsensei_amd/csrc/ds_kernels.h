@@ -20,9 +20,11 @@ struct GemmParams {
     int conv = 0;
     int Hin = 0, Win = 0, Cin = 0, Hout = 0, Wout = 0, cstride = 1, upsample = 0;
     int tiles_m = 0, tiles_n = 0;
+    int debug = 0;  // ablation only (ds_set_option "gemm_debug"): 1 skip MFMA, 2 skip tile loads — results are garbage
 };
 int ds_launch_gemm(const GemmParams& p, int batch, hipStream_t stream);
 const char* ds_gemm_kernel_name(const GemmParams& p, int batch);  // the instantiation ds_launch_gemm dispatches to
+void ds_gemm_set_debug(int v);
 void ds_gemm_set_variant(int v);  // 0 auto, 1 register staging only, 2 glds (BM <= 128), 3 glds, BM = 256 when large
 
 // ---- normalisation ---------------------------------------------------------------------------------
