@@ -18,6 +18,9 @@
 #include "ds_common.h"
 #include "ds_kernels.h"
 
+static int g_attn_variant = 0;  // 0 auto, 1 force 32 query rows per wave
+void ds_attn_set_variant(int v) { g_attn_variant = v; }
+
 namespace {
 
 constexpr float LOG2E = 1.4426950408889634f;
@@ -33,22 +36,28 @@ __device__ __forceinline__ h8 pack8(const f32x16& s, int base) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Flash self-attention.  grid = (ceil(Nq/128), B*heads), 256 threads, KV tile 64 keys, LDS 32 KiB.
+// Flash self-attention.  grid = (ceil(Nq/(128*QB)), B*heads), 256 threads, KV tile 64 keys, LDS 32 KiB.
+// A wave owns QB blocks of 32 query rows; every K / V^T fragment read from LDS feeds QB MFMAs, so QB = 2 halves the
+// LDS read traffic per flop (the limiter of the QB = 1 kernel: 1 KiB of ds_read per MFMA).
 // ------------------------------------------------------------------------------------------------
+template <int QB>
 __global__ __launch_bounds__(256, 2) void self_attn_kernel(const SelfAttnParams p) {
     __shared__ __attribute__((aligned(16))) char sK[2][64 * 128];
     __shared__ __attribute__((aligned(16))) char sV[2][64 * 128];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lhi = lane >> 5;
     const int b = blockIdx.y / p.heads, h = blockIdx.y % p.heads;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = blockIdx.x * (128 * QB) + wave * (32 * QB);
 
     // Q fragments (B operand of S^T): lane holds Q[q][kk*16 + lhi*8 .. +7]
-    const int qrow = min(q0 + l31, p.Nq - 1);
-    const half_t* qp = p.q + (long)b * p.sq + (long)qrow * p.ldq + h * 64 + lhi * 8;
-    h8 qf[4];
+    h8 qf[QB][4];
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) qf[kk] = *reinterpret_cast<const h8*>(qp + kk * 16);
+    for (int qb = 0; qb < QB; ++qb) {
+        const int qrow = min(q0 + qb * 32 + l31, p.Nq - 1);
+        const half_t* qp = p.q + (long)b * p.sq + (long)qrow * p.ldq + h * 64 + lhi * 8;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) qf[qb][kk] = *reinterpret_cast<const h8*>(qp + kk * 16);
+    }
 
     const half_t* kbase = p.k + (long)b * p.sk + h * 64;
     const half_t* vbase = p.vt + ((long)(b * p.heads + h) * 64) * p.ldv;
@@ -75,12 +84,17 @@ __global__ __launch_bounds__(256, 2) void self_attn_kernel(const SelfAttnParams 
         }
     };
 
-    f32x16 ot[2];
+    f32x16 ot[QB][2];
+    float m_run[QB], l_part[QB];
 #pragma unroll
-    for (int d = 0; d < 2; ++d)
+    for (int qb = 0; qb < QB; ++qb) {
+        m_run[qb] = NEG_BIG;
+        l_part[qb] = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ot[d][r] = 0.f;
-    float m_run = NEG_BIG, l_part = 0.f;
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ot[qb][d][r] = 0.f;
+    }
     const float c = p.scale * LOG2E;
 
     const int nt = (p.Nk + 63) / 64;
@@ -90,59 +104,71 @@ __global__ __launch_bounds__(256, 2) void self_attn_kernel(const SelfAttnParams 
     for (int t = 0; t < nt; ++t) {
         const int buf = t & 1;
         if (t + 1 < nt) load_tile(t + 1);
-        // ---- S^T = K Q^T  (two 32-key blocks)
-        f32x16 st[2];
+        // ---- S^T = K Q^T  (two 32-key blocks per q-block; each K fragment feeds QB MFMAs)
+        f32x16 st[QB][2];
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[qb][kb][r] = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
             const int row = kb * 32 + l31;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 const h8 kf = *reinterpret_cast<const h8*>(&sK[buf][row * 128 + swz(row, kk * 2 + lhi)]);
-                st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[kk], st[kb], 0, 0, 0);
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb)
+                    st[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[qb][kk], st[qb][kb], 0, 0, 0);
             }
         }
-        if (t * 64 + 64 > p.Nk) {  // ragged last tile: keys past Nk never contribute
+        const bool ragged = t * 64 + 64 > p.Nk;  // last tile: keys past Nk never contribute
+        // ---- online softmax, query row = lane&31 (the other 16 keys of each block live on lane^32)
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            if (ragged) {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = t * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                        if (key >= p.Nk) st[qb][kb][r] = NEG_BIG;
+                    }
+            }
+            float mloc = NEG_BIG;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, st[qb][kb][r]);
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+            const float m_new = fmaxf(m_run[qb], mloc);
+            const float alpha = exp2f((m_run[qb] - m_new) * c);
+            m_run[qb] = m_new;
+            const float mc = m_new * c;
+            float psum = 0.f;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int key = t * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                    if (key >= p.Nk) st[kb][r] = NEG_BIG;
+                    const float e = exp2f(fmaf(st[qb][kb][r], c, -mc));
+                    st[qb][kb][r] = e;
+                    psum += e;
                 }
+            l_part[qb] = fmaf(l_part[qb], alpha, psum);
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ot[qb][d][r] *= alpha;
         }
-        // ---- online softmax, query row = lane&31 (the other 16 keys of each block live on lane^32)
-        float mloc = NEG_BIG;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, st[kb][r]);
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-        const float m_new = fmaxf(m_run, mloc);
-        const float alpha = exp2f((m_run - m_new) * c);
-        m_run = m_new;
-        const float mc = m_new * c;
-        float psum = 0.f;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float e = exp2f(fmaf(st[kb][r], c, -mc));
-                st[kb][r] = e;
-                psum += e;
-            }
-        l_part = fmaf(l_part, alpha, psum);
-#pragma unroll
-        for (int d = 0; d < 2; ++d)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) ot[d][r] *= alpha;
-        // ---- O^T += V^T P^T
+        // ---- O^T += V^T P^T  (each V^T fragment feeds QB MFMAs)
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int hb = 0; hb < 2; ++hb) {
-                const h8 pf = pack8(st[kb], hb * 8);
+                h8 pf[QB];
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) pf[qb] = pack8(st[qb][kb], hb * 8);
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
                     const int row = db * 32 + l31;
@@ -152,25 +178,31 @@ __global__ __launch_bounds__(256, 2) void self_attn_kernel(const SelfAttnParams 
                     h8 vf;
                     vf[0] = v0[0]; vf[1] = v0[1]; vf[2] = v0[2]; vf[3] = v0[3];
                     vf[4] = v1[0]; vf[5] = v1[1]; vf[6] = v1[2]; vf[7] = v1[3];
-                    ot[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, ot[db], 0, 0, 0);
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb)
+                        ot[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[qb], ot[qb][db], 0, 0, 0);
                 }
             }
         if (t + 1 < nt) store_tile(buf ^ 1);
         __syncthreads();
     }
-    const float l = l_part + __shfl_xor(l_part, 32, 64);
-    const float inv = 1.0f / l;
-    if (q0 + l31 < p.Nq) {
-        half_t* op = p.o + (long)b * p.so + (long)(q0 + l31) * p.ldo + h * 64;
 #pragma unroll
-        for (int db = 0; db < 2; ++db)
+    for (int qb = 0; qb < QB; ++qb) {
+        const float l = l_part[qb] + __shfl_xor(l_part[qb], 32, 64);
+        const float inv = 1.0f / l;
+        const int qrow = q0 + qb * 32 + l31;
+        if (qrow < p.Nq) {
+            half_t* op = p.o + (long)b * p.so + (long)qrow * p.ldo + h * 64;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                h4 o;
+            for (int db = 0; db < 2; ++db)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (half_t)(ot[db][4 * g + e] * inv);
-                *reinterpret_cast<h4*>(op + db * 32 + 8 * g + 4 * lhi) = o;
-            }
+                for (int g = 0; g < 4; ++g) {
+                    h4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (half_t)(ot[qb][db][4 * g + e] * inv);
+                    *reinterpret_cast<h4*>(op + db * 32 + 8 * g + 4 * lhi) = o;
+                }
+        }
     }
 }
 
@@ -410,8 +442,14 @@ int ds_launch_self_attn(const SelfAttnParams& p, hipStream_t stream) {
     DS_REQUIRE(p.B > 0 && p.heads > 0 && p.Nq > 0 && p.Nk > 0, "self_attn: empty problem");
     DS_REQUIRE(p.Nk % 8 == 0 && p.ldv % 8 == 0 && p.ldq % 8 == 0 && p.ldk % 8 == 0 && p.ldo % 4 == 0,
                "self_attn: Nk/ld* alignment (Nk=%d)", p.Nk);
-    dim3 grid((p.Nq + 127) / 128, p.B * p.heads);
-    hipLaunchKernelGGL(self_attn_kernel, grid, dim3(256), 0, stream, p);
+    // 64 query rows per wave when that still leaves >= 2 blocks per CU; 32 rows per wave otherwise
+    const long blocks2 = (long)((p.Nq + 255) / 256) * p.B * p.heads;
+    // (measured on MI355X: 64-row waves win from N = 4096 up, lose at N = 1024 — profiles/r01_attn_variants.txt)
+    if (blocks2 >= 512 && p.Nk >= 2048 && g_attn_variant != 1) {
+        hipLaunchKernelGGL(self_attn_kernel<2>, dim3((p.Nq + 255) / 256, p.B * p.heads), dim3(256), 0, stream, p);
+    } else {
+        hipLaunchKernelGGL(self_attn_kernel<1>, dim3((p.Nq + 127) / 128, p.B * p.heads), dim3(256), 0, stream, p);
+    }
     DS_LAUNCH_CHECK();
     return 0;
 }

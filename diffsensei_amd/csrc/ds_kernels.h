@@ -56,6 +56,7 @@ struct SelfAttnParams {
     float scale = 0.125f;
 };
 int ds_launch_self_attn(const SelfAttnParams& p, hipStream_t stream);
+void ds_attn_set_variant(int v);  // 0 auto, 1 force 32 query rows per wave
 
 struct IPAttnParams {
     const half_t* q = nullptr;     // [B,N,C] rows (ldq)

@@ -989,6 +989,7 @@ Choice choose(const GemmParams& p, int batch) {
     Choice c;
     c.glds = (p.K % 64 == 0) && g_gemm_variant != 1;
     c.bm = (tiles128 < 384 || p.M <= 64) ? 64 : 128;
+    if (g_gemm_variant == 7) c.bm = 64;  // experiment: 64-row tiles everywhere
     if (c.glds && g_gemm_variant == 3 && tiles256 >= 512) c.bm = 256;
     c.ring = c.glds && g_gemm_variant == 4 && tiles256 >= 192 && p.K >= 128;
     c.ws = 0;
