@@ -1,0 +1,151 @@
+"""GPU: behaviours of `DiffSenseiPipeline.__call__` the reference exposes, on the tiny config:
+text-only requests (`ip_images=[]` still runs the whole IP branch on zeroed embeddings, reference :119-135),
+the MLLM hand-off (`ip_image_embeds` overwrites rows 16.. of the positive embeddings only, :143-145), DDIM, re-use of
+one captured plan across requests, `set_ip_scale` reaching a captured graph, determinism under a seeded generator.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+hq = lambda t: t.half().float()
+
+
+def _rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-6)).item()
+
+
+@pytest.fixture(scope="module")
+def pipe(hip_lib):
+    from transformers import CLIPVisionConfig, CLIPVisionModel, ViTMAEConfig, ViTMAEModel
+    from diffsensei_amd.pipeline import DiffSenseiPipeline
+    from diffsensei_amd.resampler import Resampler
+    from diffsensei_amd.schedulers import EulerDiscreteScheduler
+    from diffsensei_amd.unet import UNetMangaModel
+    from diffsensei_amd.unet_config import random_state_dict, tiny_config
+    torch.manual_seed(0)
+    clip = CLIPVisionModel(CLIPVisionConfig(hidden_size=160, intermediate_size=320, num_hidden_layers=3,
+                                            num_attention_heads=2, image_size=224, patch_size=14, hidden_act="quick_gelu")).eval()
+    mae = ViTMAEModel(ViTMAEConfig(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                                   image_size=224, patch_size=16, mask_ratio=0.0)).eval()
+    cfg = tiny_config()
+    sd = {k: v.half() for k, v in random_state_dict(cfg, 4).items()}
+    unet = UNetMangaModel(cfg, device=DEV)
+    unet.load_state_dict(sd)
+    unet.set_manga_modules()          # installs the processors; IP K/V re-initialised from the text K/V like the reference
+    sd = {k: v.float().cpu() for k, v in unet.state_dict().items()}
+    rs = Resampler(dim=128, depth=2, dim_head=64, heads=2, num_queries=16, num_dummy_tokens=16, embedding_dim=160,
+                   magi_embedding_dim=128, output_dim=cfg.cross_attention_dim, ff_mult=4, device=DEV).init_random(5)
+    p = DiffSenseiPipeline(None, None, None, None, None, EulerDiscreteScheduler(), unet, clip)
+    p.register_manga_modules(magi_image_encoder=mae, image_proj_model=rs)
+    g = torch.Generator().manual_seed(9)
+    common = dict(prompt="a manga panel", height=128, width=128, num_inference_steps=3, guidance_scale=7.5,
+                  prompt_embeds=torch.randn(1, 77, cfg.cross_attention_dim, generator=g).half(),
+                  pooled_prompt_embeds=torch.randn(1, 128, generator=g).half(), output_type="latent")
+    return p, cfg, sd, rs, clip, mae, common
+
+
+def _oracle(cfg, sd, rs, clip, mae, common, imgs, ip_bbox, dialog, ns, lat0, ip_embeds=None, ip_scale=0.6, ddim=False):
+    from PIL import Image
+    from transformers import CLIPImageProcessor, ViTImageProcessor
+    from oracle.pipeline_ref import sample_loop
+    from oracle.resampler_ref import resampler_forward
+    from oracle.scheduler_ref import DDIMOracle, EulerDiscreteOracle
+    from oracle.unet_ref import UNetOracle
+    n_real = len(imgs)
+    padded = list(imgs) + [Image.new("RGB", (224, 224))] * (4 - n_real)
+    with torch.no_grad():
+        ce = clip(CLIPImageProcessor()(images=padded, return_tensors="pt").pixel_values,
+                  output_hidden_states=True).hidden_states[-2].unsqueeze(0)
+        me = mae(ViTImageProcessor()(images=padded, return_tensors="pt").pixel_values).last_hidden_state[:, 0].unsqueeze(0)
+        ce[0, n_real:], me[0, n_real:] = 0, 0
+        rsd = {k: v.float().cpu() for k, v in rs.state_dict().items()}
+        img = hq(resampler_forward(rsd, ce, me, 2, 64))
+        neg = hq(resampler_forward(rsd, torch.zeros_like(ce), torch.zeros_like(me), 2, 64))
+        if ip_embeds is not None:
+            k = ip_embeds.shape[0]
+            img[0, 16:(1 + k) * 16] = ip_embeds.float().reshape(-1, img.shape[-1])
+        pe, pooled = common["prompt_embeds"].float(), common["pooled_prompt_embeds"].float()
+        enc = torch.cat([torch.cat([torch.zeros_like(pe).repeat(ns, 1, 1), pe.repeat(ns, 1, 1)]),
+                         torch.cat([neg.repeat(ns, 1, 1), img.repeat(ns, 1, 1)])], dim=1)
+        te = torch.cat([torch.zeros(ns, pooled.shape[1]), pooled.repeat(ns, 1)])
+        tid = torch.tensor([[128, 128, 0, 0, 128, 128]] * (2 * ns), dtype=torch.float32)
+        bbox = torch.zeros(2 * ns, 4, 4)
+        for j, bx in enumerate(ip_bbox):
+            bbox[ns:, j] = torch.tensor(bx)
+        db = torch.zeros(2 * ns, 8, 4, dtype=torch.float16)
+        for j, bx in enumerate(dialog):
+            db[ns:, j] = torch.tensor(bx).half()
+        sch = (DDIMOracle() if ddim else EulerDiscreteOracle()).set_timesteps(3)
+        return sample_loop(UNetOracle(cfg, sd, q=hq), DDIMOracle() if ddim else EulerDiscreteOracle(),
+                           hq(lat0.float() * sch.init_noise_sigma), hq(enc), hq(te), tid, bbox, db, 7.5, 3, ip_scale, q=hq)
+
+
+def test_text_only_request_runs_the_ip_branch(pipe):
+    p, cfg, sd, rs, clip, mae, common = pipe
+    lat0 = torch.randn(1, 4, 16, 16, generator=torch.Generator().manual_seed(1)).half()
+    out = p(ip_images=[], ip_bbox=[], dialog_bbox=[], ip_scale=0.6, latents=lat0.clone(), **common).images
+    ref = _oracle(cfg, sd, rs, clip, mae, common, [], [], [], 1, lat0)
+    assert _rel(out, ref) <= 5e-2, _rel(out, ref)
+
+
+def test_mllm_handoff_ip_image_embeds(pipe):
+    p, cfg, sd, rs, clip, mae, common = pipe
+    g = torch.Generator().manual_seed(2)
+    emb = torch.randn(2, 16, cfg.cross_attention_dim, generator=g).half()
+    boxes = [[0.0, 0.0, 0.5, 1.0], [0.5, 0.0, 1.0, 1.0]]
+    lat0 = torch.randn(1, 4, 16, 16, generator=g).half()
+    out = p(ip_images=[], ip_image_embeds=emb.to(DEV), ip_bbox=[list(b) for b in boxes], dialog_bbox=[], ip_scale=0.6,
+            latents=lat0.clone(), **common).images
+    ref = _oracle(cfg, sd, rs, clip, mae, common, [], boxes, [], 1, lat0, ip_embeds=emb)
+    assert _rel(out, ref) <= 5e-2, _rel(out, ref)
+    plain = p(ip_images=[], ip_bbox=[], dialog_bbox=[], ip_scale=0.6, latents=lat0.clone(), **common).images
+    assert _rel(out, plain) > 1e-3          # the supplied character tokens matter
+
+
+def test_ddim_and_plan_reuse_and_ip_scale(pipe):
+    from PIL import Image
+    from diffsensei_amd.schedulers import DDIMScheduler, EulerDiscreteScheduler
+    p, cfg, sd, rs, clip, mae, common = pipe
+    rng = np.random.RandomState(3)
+    imgs = [Image.fromarray(rng.randint(0, 256, (224, 224, 3), dtype=np.uint8))]
+    boxes, dialog = [[0.1, 0.1, 0.9, 0.9]], [[0.0, 0.0, 0.4, 0.2]]
+    lat0 = torch.randn(2, 4, 16, 16, generator=torch.Generator().manual_seed(4)).half()
+    kw = dict(ip_images=list(imgs), ip_bbox=[list(b) for b in boxes], dialog_bbox=[list(b) for b in dialog], num_samples=2)
+    p.scheduler = DDIMScheduler()
+    out_d = p(ip_scale=0.6, latents=lat0.clone(), **kw, **common).images
+    ref_d = _oracle(cfg, sd, rs, clip, mae, common, imgs, boxes, dialog, 2, lat0, ddim=True)
+    assert _rel(out_d, ref_d) <= 5e-2, _rel(out_d, ref_d)
+    p.scheduler = EulerDiscreteScheduler()
+    a = p(ip_scale=0.6, latents=lat0.clone(), **kw, **common).images
+    b = p(ip_scale=0.0, latents=lat0.clone(), **kw, **common).images      # same captured graph, new device scalar
+    c = p(ip_scale=0.6, latents=lat0.clone(), **kw, **common).images
+    assert torch.equal(a, c) and _rel(a, b) > 1e-3
+    ref_b = _oracle(cfg, sd, rs, clip, mae, common, imgs, boxes, dialog, 2, lat0, ip_scale=0.0)
+    assert _rel(b, ref_b) <= 5e-2, _rel(b, ref_b)
+    # seeded generator -> reproducible latents, like the reference's only determinism knob
+    g1 = p(ip_scale=0.6, generator=torch.Generator().manual_seed(7), **kw, **common).images
+    g2 = p(ip_scale=0.6, generator=torch.Generator().manual_seed(7), **kw, **common).images
+    g3 = p(ip_scale=0.6, generator=torch.Generator().manual_seed(8), **kw, **common).images
+    assert torch.equal(g1, g2) and not torch.equal(g1, g3)
+
+
+def test_forward_flop_inventory_matches_survey(hip_lib):
+    """Algorithmic work of one SDXL forward (B=2, 1024^2) from the launch plan vs SURVEY.md §8d's 13.71 TFLOP:
+    the plan carries 13.71 minus the text/IP K,V projections (0.22 TF) that were hoisted out of the step loop."""
+    import ctypes as C
+    from diffsensei_amd import _lib
+    from diffsensei_amd.engine import make_op  # noqa: F401  (table only)
+    from diffsensei_amd.unet import UNetMangaModel
+    from diffsensei_amd.unet_config import sdxl_config
+    m = UNetMangaModel(sdxl_config(), device=DEV).init_random(0)
+    eng = m.engine(2, 128, 128, 1.0)
+    lib = _lib.load()
+    fl, by, name, tot = C.c_double(), C.c_double(), C.create_string_buffer(64), 0.0
+    for op in eng.forward_ops:
+        lib.ds_op_describe(C.byref(op), name, 64, C.byref(fl), C.byref(by))
+        tot += fl.value
+    assert abs(tot / 1e12 - (13.71 - 0.22)) < 0.05, tot / 1e12
+    assert len(eng.forward_ops) == 963          # + CFG/scheduler step + counter advance = 965 launches per denoise step
