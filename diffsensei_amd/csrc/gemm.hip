@@ -21,7 +21,7 @@
 #include "ds_common.h"
 #include "ds_kernels.h"
 
-static int g_gemm_variant = 0;  // 0 auto, 1 register staging, 2 glds BM<=128, 3 glds BM=256 (4 waves), 4 8-wave ring
+static int g_gemm_variant = 0;  // 0 auto; A/B: 1 register staging, 2 two-buffer glds, 8/9 one-buffer glds (BM 128/64), 7 BM 64, 4 ring, 5/6 producer-consumer
 void ds_gemm_set_variant(int v) { g_gemm_variant = v; }
 static int g_gemm_debug = 0;  // ablation switches, see GemmParams::debug
 void ds_gemm_set_debug(int v) { g_gemm_debug = v; }
@@ -168,14 +168,14 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x16 (&acc)[WR /
 }
 
 // ---------------------------------------------------------------------------------------------- glds pipeline
-template <int BM, bool CONV>
-__global__ __launch_bounds__(256, (BM > 128 ? 1 : 2)) void gemm_glds_kernel(const GemmParams p) {
+template <int BM, bool CONV, int STAGES = 2>  // STAGES = 1: one 32-KiB LDS buffer, three blocks per CU
+__global__ __launch_bounds__(256, (BM > 128 ? 1 : (STAGES == 1 ? (BM == 64 ? 4 : 3) : 2))) void gemm_glds_kernel(const GemmParams p) {
     constexpr int MI = BM / 64;
     constexpr int ASEG = BM / 32;  // 1-KiB (8-row) A segments per wave per k-tile
     constexpr int BSEG = 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sA = smem;
-    char* sB = smem + 2 * BM * 128;
+    char* sB = smem + STAGES * BM * 128;
     typedef __attribute__((address_space(3))) void lds_void;
     typedef const __attribute__((address_space(1))) void glb_void;
 
@@ -277,11 +277,11 @@ __global__ __launch_bounds__(256, (BM > 128 ? 1 : 2)) void gemm_glds_kernel(cons
     // (tile kt+1 is already in flight in the other buffer: two tiles of latency cover with two buffers); (5) the 16
     // MFMAs run out of registers while the DMA lands.  Raw s_barrier: __syncthreads() would drain vmcnt to 0.
     constexpr int PIECES = ASEG + BSEG;  // LDS-DMA instructions per wave per tile
-    const bool deep = !(p.debug & 8);  // debug 8: one barrier per tile, DMA only one tile ahead (A/B switch)
+    const bool deep = STAGES == 2 && !(p.debug & 8);  // debug 8: one barrier per tile, DMA one tile ahead (A/B switch)
     issue(0, 0);
     if (nk > 1 && deep) issue(1, 1);
     for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
+        const int buf = STAGES == 2 ? (kt & 1) : 0;
         if (kt + 1 < nk && deep) {
             if constexpr (PIECES == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             else if constexpr (PIECES == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -309,7 +309,13 @@ __global__ __launch_bounds__(256, (BM > 128 ? 1 : 2)) void gemm_glds_kernel(cons
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (deep) {
+        if (STAGES == 1) {
+            if (kt + 1 < nk) {  // the only buffer is drained once everyone has its fragments: refill it under the MFMAs
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                issue(kt + 1, 0);
+            }
+        } else if (deep) {
             if (kt + 2 < nk) {
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
@@ -940,6 +946,18 @@ int launch(const GemmParams& p0, int batch, hipStream_t stream) {
     return 0;
 }
 
+template <int BM, bool CONV>
+int launch_glds1(const GemmParams& p0, int batch, hipStream_t stream) {
+    GemmParams p = p0;
+    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_n = (p.N + BN - 1) / BN;
+    const size_t lds = 128 * CS_STRIDE;  // >= (BM + BN) * 128: the epilogue staging tile is the larger tenant
+    dim3 grid(p.tiles_m * p.tiles_n, 1, batch);
+    hipLaunchKernelGGL((gemm_glds_kernel<BM, CONV, 1>), grid, dim3(256), lds, stream, p);
+    DS_LAUNCH_CHECK();
+    return 0;
+}
+
 template <bool CONV>
 int launch_ring(const GemmParams& p0, int batch, hipStream_t stream) {
     GemmParams p = p0;
@@ -976,27 +994,59 @@ int launch_ws(const GemmParams& p0, int batch, hipStream_t stream) {
     return 0;
 }
 
+enum Kind { K_REG, K_GLDS2, K_GLDS1, K_RING, K_WS };
 struct Choice {
-    int bm;
-    bool glds;
-    bool ring;
-    int ws;  // 0, or BNT of the producer/consumer kernel
+    Kind kind;
+    int bm;   // rows of the block tile (K_WS: BNT)
 };
 
+// Dispatch (measured on MI355X, profiles/r01_gemm_variants_microbench.txt).  What pays on this chip is the number of
+// INDEPENDENT blocks resident per CU (their load / fragment / MFMA phases de-phase for free), not prefetch depth:
+//   plain GEMM: one 32-KiB LDS buffer, 128x128 tiles, 3 blocks per CU (+5..28 % over two buffers / 2 blocks),
+//               except the long-K (K >= 4096), narrow-N FF down-projection where the 2-deep DMA wins;
+//   3x3 conv:   one buffer, 64x128 tiles, 4 blocks per CU (+15..25 %); small grids: 64-row tiles so they cover the CUs.
+// g_gemm_variant != 0 forces one family for A/B runs.
 Choice choose(const GemmParams& p, int batch) {
     const long tiles128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * batch;
     const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 127) / 128) * batch;
+    const bool conv = p.conv != 0;
+    const bool small = tiles128 < 384 || p.M <= 64;
+    const bool dma_ok = p.K % 64 == 0;
     Choice c;
-    c.glds = (p.K % 64 == 0) && g_gemm_variant != 1;
-    c.bm = (tiles128 < 384 || p.M <= 64) ? 64 : 128;
-    if (g_gemm_variant == 7) c.bm = 64;  // experiment: 64-row tiles everywhere
-    if (c.glds && g_gemm_variant == 3 && tiles256 >= 512) c.bm = 256;
-    c.ring = c.glds && g_gemm_variant == 4 && tiles256 >= 192 && p.K >= 128;
-    c.ws = 0;
-    if (c.glds && p.K >= 128) {
-        const long t256x256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256) * batch;
-        if (g_gemm_variant == 5 && t256x256 >= 128) c.ws = 256;
-        if (g_gemm_variant == 6 && tiles256 >= 192) c.ws = 128;
+    c.bm = small ? 64 : 128;
+    if (!dma_ok || g_gemm_variant == 1) {
+        c.kind = K_REG;
+        return c;
+    }
+    switch (g_gemm_variant) {
+        case 2: c.kind = K_GLDS2; return c;
+        case 7: c.kind = K_GLDS2; c.bm = 64; return c;
+        case 8: c.kind = K_GLDS1; return c;
+        case 9: c.kind = K_GLDS1; c.bm = 64; return c;
+        case 4:
+            if (tiles256 >= 192 && p.K >= 128) { c.kind = K_RING; c.bm = 256; return c; }
+            break;
+        case 5: {
+            const long t = (long)((p.M + 255) / 256) * ((p.N + 255) / 256) * batch;
+            if (t >= 128 && p.K >= 128) { c.kind = K_WS; c.bm = 256; return c; }
+            break;
+        }
+        case 6:
+            if (tiles256 >= 192 && p.K >= 128) { c.kind = K_WS; c.bm = 128; return c; }
+            break;
+        default: break;
+    }
+    if (g_gemm_variant != 0) {  // forced family did not apply to this shape
+        c.kind = K_GLDS2;
+        return c;
+    }
+    if (conv) {
+        c.kind = K_GLDS1;
+        c.bm = 64;
+    } else if (small) {
+        c.kind = K_GLDS1;
+    } else {
+        c.kind = (p.K >= 4096 && p.N <= 2048) ? K_GLDS2 : K_GLDS1;
     }
     return c;
 }
@@ -1006,16 +1056,21 @@ Choice choose(const GemmParams& p, int batch) {
 const char* ds_gemm_kernel_name(const GemmParams& p, int batch) {
     const Choice c = choose(p, batch);
     const bool conv = p.conv != 0;
-    if (c.ws == 256) return conv ? "gemm_ws_kernel<256,true>" : "gemm_ws_kernel<256,false>";
-    if (c.ws == 128) return conv ? "gemm_ws_kernel<128,true>" : "gemm_ws_kernel<128,false>";
-    if (c.ring) return conv ? "gemm_ring_kernel<true>" : "gemm_ring_kernel<false>";
-    if (c.glds) {
-        if (c.bm == 256) return conv ? "gemm_glds_kernel<256,true>" : "gemm_glds_kernel<256,false>";
-        if (c.bm == 128) return conv ? "gemm_glds_kernel<128,true>" : "gemm_glds_kernel<128,false>";
-        return conv ? "gemm_glds_kernel<64,true>" : "gemm_glds_kernel<64,false>";
+    switch (c.kind) {
+        case K_WS:
+            if (c.bm == 256) return conv ? "gemm_ws_kernel<256,true>" : "gemm_ws_kernel<256,false>";
+            return conv ? "gemm_ws_kernel<128,true>" : "gemm_ws_kernel<128,false>";
+        case K_RING: return conv ? "gemm_ring_kernel<true>" : "gemm_ring_kernel<false>";
+        case K_GLDS1:
+            if (c.bm == 128) return conv ? "gemm_glds_kernel<128,true,1>" : "gemm_glds_kernel<128,false,1>";
+            return conv ? "gemm_glds_kernel<64,true,1>" : "gemm_glds_kernel<64,false,1>";
+        case K_GLDS2:
+            if (c.bm == 128) return conv ? "gemm_glds_kernel<128,true,2>" : "gemm_glds_kernel<128,false,2>";
+            return conv ? "gemm_glds_kernel<64,true,2>" : "gemm_glds_kernel<64,false,2>";
+        default:
+            if (c.bm == 128) return conv ? "gemm_f16_kernel<128,true>" : "gemm_f16_kernel<128,false>";
+            return conv ? "gemm_f16_kernel<64,true>" : "gemm_f16_kernel<64,false>";
     }
-    if (c.bm == 128) return conv ? "gemm_f16_kernel<128,true>" : "gemm_f16_kernel<128,false>";
-    return conv ? "gemm_f16_kernel<64,true>" : "gemm_f16_kernel<64,false>";
 }
 
 int ds_launch_gemm(const GemmParams& p_in, int batch, hipStream_t stream) {
@@ -1035,19 +1090,20 @@ int ds_launch_gemm(const GemmParams& p_in, int batch, hipStream_t stream) {
     }
     if (p.epi == EPI_GEGLU) DS_REQUIRE(p.N % 128 == 0, "geglu: packed N (%d) must be a multiple of 128", p.N);
     const Choice c = choose(p, batch);
-    if (c.ws == 256) return conv ? launch_ws<256, true>(p, batch, stream) : launch_ws<256, false>(p, batch, stream);
-    if (c.ws == 128) return conv ? launch_ws<128, true>(p, batch, stream) : launch_ws<128, false>(p, batch, stream);
-    if (c.ring) return conv ? launch_ring<true>(p, batch, stream) : launch_ring<false>(p, batch, stream);
-    if (c.glds) {
-        if (conv) {
-            if (c.bm == 256) return launch<256, true, true>(p, batch, stream);
-            if (c.bm == 128) return launch<128, true, true>(p, batch, stream);
-            return launch<64, true, true>(p, batch, stream);
-        }
-        if (c.bm == 256) return launch<256, false, true>(p, batch, stream);
-        if (c.bm == 128) return launch<128, false, true>(p, batch, stream);
-        return launch<64, false, true>(p, batch, stream);
+    switch (c.kind) {
+        case K_WS:
+            if (c.bm == 256) return conv ? launch_ws<256, true>(p, batch, stream) : launch_ws<256, false>(p, batch, stream);
+            return conv ? launch_ws<128, true>(p, batch, stream) : launch_ws<128, false>(p, batch, stream);
+        case K_RING: return conv ? launch_ring<true>(p, batch, stream) : launch_ring<false>(p, batch, stream);
+        case K_GLDS1:
+            if (c.bm == 128)
+                return conv ? launch_glds1<128, true>(p, batch, stream) : launch_glds1<128, false>(p, batch, stream);
+            return conv ? launch_glds1<64, true>(p, batch, stream) : launch_glds1<64, false>(p, batch, stream);
+        case K_GLDS2:
+            if (c.bm == 128) return conv ? launch<128, true, true>(p, batch, stream) : launch<128, false, true>(p, batch, stream);
+            return conv ? launch<64, true, true>(p, batch, stream) : launch<64, false, true>(p, batch, stream);
+        default:
+            if (c.bm == 128) return conv ? launch<128, true, false>(p, batch, stream) : launch<128, false, false>(p, batch, stream);
+            return conv ? launch<64, true, false>(p, batch, stream) : launch<64, false, false>(p, batch, stream);
     }
-    if (conv) return c.bm == 64 ? launch<64, true, false>(p, batch, stream) : launch<128, true, false>(p, batch, stream);
-    return c.bm == 64 ? launch<64, false, false>(p, batch, stream) : launch<128, false, false>(p, batch, stream);
 }
