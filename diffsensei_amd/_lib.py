@@ -43,6 +43,8 @@ SIGNATURES = {
     "ds_ip_region_flags": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "ds_small_attn_f16": (i32, [vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, i32, i32, i32, i32, i32, f32,
                                 vp]),
+    "ds_small_attn_causal_f16": (i32, [vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, i32, i32, i32, i32, f32, vp]),
+    "ds_embed_tokens_f16": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "ds_conv_in_dialog_f16": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "ds_conv_out_f16": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "ds_skinny_linear_f16": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),

@@ -20,6 +20,8 @@
 
 static int g_attn_variant = 0;  // 0 auto, 1 force 32 query rows per wave
 void ds_attn_set_variant(int v) { g_attn_variant = v; }
+static long g_ip_min_blocks = 1024;  // ip_attn: double the query tiles per block while the grid keeps this many blocks
+void ds_ip_attn_set_min_blocks(int v) { g_ip_min_blocks = v; }
 
 namespace {
 
@@ -295,6 +297,21 @@ __global__ __launch_bounds__(256, 2) void ip_attn_kernel(const IPAttnParams p, i
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) qf[kk] = *reinterpret_cast<const h8*>(qp + kk * 16);
         const unsigned inside = region_flags(bbox_b, p.max_ips, qidx, p.mask_h, p.mask_w);
+        // 96-bit "attendable IP key" set of this query row: dummy keys [0, n_dummy) iff the token lies in NO box,
+        // character k's keys [n_dummy + k*tpi, +tpi) iff it lies in box k  (reference :155-163)
+        unsigned open_ip[3] = {0u, 0u, 0u};
+        {
+            auto set_range = [&](int lo, int hi) {  // bits [lo, hi) of the 96-bit set
+#pragma unroll
+                for (int w = 0; w < 3; ++w) {
+                    const int a = max(lo - 32 * w, 0), b = min(hi - 32 * w, 32);
+                    if (b > a) open_ip[w] |= (b - a == 32 ? 0xffffffffu : ((1u << (b - a)) - 1u)) << a;
+                }
+            };
+            if (inside == 0) set_range(0, p.n_dummy);
+            for (int k = 0; k < p.max_ips; ++k)
+                if ((inside >> k) & 1u) set_range(p.n_dummy + k * p.tok_per_ip, p.n_dummy + (k + 1) * p.tok_per_ip);
+        }
 
         f32x16 ot[2];
 #pragma unroll
@@ -319,20 +336,17 @@ __global__ __launch_bounds__(256, 2) void ip_attn_kernel(const IPAttnParams p, i
                     st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[kk], st[kb], 0, 0, 0);
                 }
             }
-            // scale, additive region mask (-10000, like the reference), padding keys removed
+            // scale, additive region mask (-10000, like the reference), padding keys removed.  `open[kb]` holds one bit
+            // per key of the 32-key block: attendable for THIS query row (IP part), or simply key < L (text part).
             float mloc = NEG_BIG;
 #pragma unroll
             for (int kb = 0; kb < 3; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    const int kbit = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    const int key = kb * 32 + kbit;
                     float s = st[kb][r] * p.qk_scale;
-                    if (part) {
-                        bool masked;
-                        if (key < p.n_dummy) masked = inside != 0;                                  // dummy tokens
-                        else masked = ((inside >> ((key - p.n_dummy) / p.tok_per_ip)) & 1u) == 0;  // character tokens
-                        if (masked) s += -10000.0f;
-                    }
+                    if (part && !((open_ip[kb] >> kbit) & 1u)) s += -10000.0f;
                     if (key >= L) s = NEG_BIG;
                     st[kb][r] = s;
                     mloc = fmaxf(mloc, s);
@@ -396,7 +410,7 @@ __global__ __launch_bounds__(256) void small_attn_kernel(const half_t* __restric
                                                          const half_t* __restrict__ v, half_t* __restrict__ o,
                                                          long ldq, long ldk, long ldv, long ldo, long sq, long sk,
                                                          long sv, long so, int B, int heads, int Nq, int Nk, int D,
-                                                         float scale) {
+                                                         float scale, int causal) {
     extern __shared__ float sp[];  // [4 waves][Nk]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wave;
@@ -415,6 +429,7 @@ __global__ __launch_bounds__(256) void small_attn_kernel(const half_t* __restric
             for (int e = 0; e < 8; ++e) s = fmaf((float)a[e], (float)c[e], s);
         }
         s *= scale;
+        if (causal && j > row) s = NEG_BIG;  // CLIP text encoders: token t attends to tokens <= t
         pw[j] = s;
         mx = fmaxf(mx, s);
     }
@@ -470,7 +485,7 @@ int ds_launch_ip_attn(const IPAttnParams& p0, hipStream_t stream) {
     // walk several query tiles per block once there are plenty of blocks (amortises the K/V panel staging)
     const int tiles = (p.N + 127) / 128;
     int qt = 1;
-    while (qt < 4 && (long)((tiles + 2 * qt - 1) / (2 * qt)) * p.B * p.heads >= 1024) qt *= 2;
+    while (qt < 4 && (long)((tiles + 2 * qt - 1) / (2 * qt)) * p.B * p.heads >= g_ip_min_blocks) qt *= 2;
     dim3 grid((tiles + qt - 1) / qt, p.B * p.heads);
     hipLaunchKernelGGL(ip_attn_kernel, grid, dim3(256), 0, stream, p, qt);
     DS_LAUNCH_CHECK();
@@ -488,12 +503,12 @@ int ds_launch_ip_region_flags(const float* bbox, uint8_t* flags, int B, int N, i
 
 int ds_launch_small_attn(const half_t* q, const half_t* k, const half_t* v, half_t* o, long ldq, long ldk, long ldv,
                          long ldo, long sq, long sk, long sv, long so, int B, int heads, int Nq, int Nk, int D,
-                         float scale, hipStream_t stream) {
+                         float scale, hipStream_t stream, int causal) {
     DS_REQUIRE(D % 8 == 0 && D <= 128, "small_attn: head_dim %d unsupported", D);
     DS_REQUIRE(Nk * 4 * sizeof(float) <= 60000, "small_attn: Nk %d too large", Nk);
     dim3 grid((Nq + 3) / 4, B * heads);
     hipLaunchKernelGGL(small_attn_kernel, grid, dim3(256), (size_t)4 * Nk * sizeof(float), stream, q, k, v, o, ldq,
-                       ldk, ldv, ldo, sq, sk, sv, so, B, heads, Nq, Nk, D, scale);
+                       ldk, ldv, ldo, sq, sk, sv, so, B, heads, Nq, Nk, D, scale, causal);
     DS_LAUNCH_CHECK();
     return 0;
 }

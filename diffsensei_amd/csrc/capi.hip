@@ -48,6 +48,10 @@ int ds_set_option(const char* key, int value) {
         ds_gemm_set_variant(value);
         return 0;
     }
+    if (strcmp(key, "ip_attn_min_blocks") == 0) {
+        ds_ip_attn_set_min_blocks(value);
+        return 0;
+    }
     if (strcmp(key, "attn_variant") == 0) {
         ds_attn_set_variant(value);
         return 0;
@@ -150,6 +154,18 @@ int ds_small_attn_f16(const void* q, int64_t ldq, int64_t sq, const void* k, int
                       int D, float scale, void* stream) {
     return ds_launch_small_attn(H(q), H(k), H(v), HM(o), ldq, ldk, ldv, ldo, sq, sk, sv, so, B, heads, Nq, Nk, D, scale,
                                 S(stream));
+}
+
+int ds_small_attn_causal_f16(const void* q, int64_t ldq, int64_t sq, const void* k, int64_t ldk, int64_t sk, const void* v,
+                             int64_t ldv, int64_t sv, void* o, int64_t ldo, int64_t so, int B, int heads, int N, int D,
+                             float scale, void* stream) {
+    return ds_launch_small_attn(H(q), H(k), H(v), HM(o), ldq, ldk, ldv, ldo, sq, sk, sv, so, B, heads, N, N, D, scale,
+                                S(stream), 1);
+}
+
+int ds_embed_tokens_f16(const int32_t* ids, const void* tok_emb, const void* pos_emb, void* out, int B, int T, int D,
+                        int vocab, void* stream) {
+    return ds_launch_embed_tokens(ids, H(tok_emb), H(pos_emb), HM(out), B, T, D, vocab, S(stream));
 }
 
 int ds_conv_in_dialog_f16(const void* x, const void* w, const void* bias, const int32_t* dialog_boxes,

@@ -57,6 +57,7 @@ struct SelfAttnParams {
 };
 int ds_launch_self_attn(const SelfAttnParams& p, hipStream_t stream);
 void ds_attn_set_variant(int v);  // 0 auto, 1 force 32 query rows per wave
+void ds_ip_attn_set_min_blocks(int v);
 
 struct IPAttnParams {
     const half_t* q = nullptr;     // [B,N,C] rows (ldq)
@@ -79,7 +80,7 @@ struct IPAttnParams {
 int ds_launch_ip_attn(const IPAttnParams& p, hipStream_t stream);
 int ds_launch_small_attn(const half_t* q, const half_t* k, const half_t* v, half_t* o, long ldq, long ldk, long ldv,
                          long ldo, long sq, long sk, long sv, long so, int B, int heads, int Nq, int Nk, int D,
-                         float scale, hipStream_t stream);
+                         float scale, hipStream_t stream, int causal = 0);
 int ds_launch_ip_region_flags(const float* bbox, uint8_t* flags, int B, int N, int max_ips, int mask_h, int mask_w,
                               hipStream_t stream);
 
@@ -113,5 +114,7 @@ int ds_launch_prepare_model_input(const half_t* latents, half_t* model_in, const
 int ds_launch_advance_counter(int* ctr, hipStream_t stream);
 int ds_launch_nhwc_to_nchw(const half_t* x, half_t* y, int B, int HW, int C, hipStream_t stream);
 int ds_launch_nchw_to_nhwc(const half_t* x, half_t* y, int B, int HW, int C, hipStream_t stream);
+int ds_launch_embed_tokens(const int* ids, const half_t* tok_emb, const half_t* pos_emb, half_t* out, int B, int T,
+                           int D, int vocab, hipStream_t stream);
 int ds_launch_pad_rows(const half_t* x, half_t* y, int B, int rows_in, int rows_out, int row_off, int total_rows,
                        int C, hipStream_t stream);

@@ -300,7 +300,36 @@ __global__ void pad_rows_kernel(const half_t* x, half_t* y, int B, int rows_in, 
     *reinterpret_cast<h8*>(y + ((long)b * rows_out + r) * C + cc * 8) = v;
 }
 
+// out[b,t,:] = tok_emb[ids[b,t],:] + pos_emb[t,:]   (CLIP text embeddings; ids clamped to the vocabulary)
+__global__ void embed_tokens_kernel(const int* ids, const half_t* tok_emb, const half_t* pos_emb, half_t* out, int B,
+                                    int T, int D, int vocab) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int d8 = D >> 3;
+    if (i >= (long)B * T * d8) return;
+    const int c = (int)(i % d8);
+    const long bt = i / d8;
+    const int t = (int)(bt % T);
+    int id = ids[bt];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    const h8 a = *reinterpret_cast<const h8*>(tok_emb + (long)id * D + c * 8);
+    const h8 b = *reinterpret_cast<const h8*>(pos_emb + (long)t * D + c * 8);
+    h8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)a[e] + (float)b[e]);
+    *reinterpret_cast<h8*>(out + bt * D + c * 8) = o;
+}
+
 }  // namespace
+
+int ds_launch_embed_tokens(const int* ids, const half_t* tok_emb, const half_t* pos_emb, half_t* out, int B, int T,
+                           int D, int vocab, hipStream_t stream) {
+    DS_REQUIRE(D % 8 == 0 && B > 0 && T > 0 && vocab > 0, "embed_tokens: bad shape");
+    const long total = (long)B * T * (D / 8);
+    hipLaunchKernelGGL(embed_tokens_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, ids, tok_emb,
+                       pos_emb, out, B, T, D, vocab);
+    DS_LAUNCH_CHECK();
+    return 0;
+}
 
 int ds_launch_conv_in(const half_t* x, const half_t* w, const half_t* bias, const int* dialog_boxes,
                       const half_t* dialog_emb, half_t* y, int B, int H, int W, int Cin, int Cout, int ndialog,

@@ -192,3 +192,84 @@ class ViTMAEEngine(ViTEncoderEngine):
         h = self.run_layers(self.embed(pixel_values))
         cls_tok = h[:, 0].contiguous()
         return ops.layernorm(cls_tok, self.post_ln[0], self.post_ln[1], self.eps)
+
+
+class ClipTextEngine:
+    """SDXL prompt encoders on the HIP kernels: `text_encoder(ids, output_hidden_states=True)` of
+    `StableDiffusionXLPipeline.encode_prompt` [3P], called at reference src/pipelines/pipeline_diffsensei.py:237-245.
+
+    Returns what `encode_prompt` consumes: `hidden_states[-2]` (output of the penultimate layer, no final LayerNorm) and
+    `out[0]` (CLIPTextModel: last_hidden_state after the final LayerNorm; CLIPTextModelWithProjection: the EOS token's
+    final-LayerNorm state times `text_projection`).  Pre-LN blocks with CAUSAL attention; token + position embedding
+    gather-add, GEMMs, LayerNorms and attention are HIP launches; locating the EOS token is index plumbing."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.layers: List[_ViTLayer] = []
+        self.dtype = torch.float16
+
+    @classmethod
+    def from_transformers(cls, model, device="cuda") -> "ClipTextEngine":
+        cfg = model.config
+        eng = cls(device)
+        eng.config = cfg
+        eng.hidden, eng.heads, eng.eps = cfg.hidden_size, cfg.num_attention_heads, cfg.layer_norm_eps
+        eng.act = {"gelu": "gelu", "quick_gelu": "quick_gelu"}[cfg.hidden_act]
+        eng.eos_token_id = getattr(cfg, "eos_token_id", None)
+        K = _Keys(dict(model.state_dict()), ("text_model.", ""))
+        eng.tok_emb = _f16(K("embeddings.token_embedding.weight"), device)
+        eng.pos_emb = _f16(K("embeddings.position_embedding.weight"), device)
+        eng.final_ln = (_f16(K("final_layer_norm.weight"), device), _f16(K("final_layer_norm.bias"), device))
+        sd = model.state_dict()
+        eng.text_projection = _f16(sd["text_projection.weight"], device) if "text_projection.weight" in sd else None
+        for i in range(cfg.num_hidden_layers):
+            L, p = _ViTLayer(), f"encoder.layers.{i}."
+            L.ln1_w, L.ln1_b = _f16(K(p + "layer_norm1.weight"), device), _f16(K(p + "layer_norm1.bias"), device)
+            L.qkv_w = _f16(torch.cat([K(p + "self_attn.q_proj.weight"), K(p + "self_attn.k_proj.weight"),
+                                      K(p + "self_attn.v_proj.weight")], 0), device)
+            L.qkv_b = _f16(torch.cat([K(p + "self_attn.q_proj.bias"), K(p + "self_attn.k_proj.bias"),
+                                      K(p + "self_attn.v_proj.bias")], 0), device)
+            L.o_w, L.o_b = _f16(K(p + "self_attn.out_proj.weight"), device), _f16(K(p + "self_attn.out_proj.bias"), device)
+            L.ln2_w, L.ln2_b = _f16(K(p + "layer_norm2.weight"), device), _f16(K(p + "layer_norm2.bias"), device)
+            L.fc1_w, L.fc1_b = _f16(K(p + "mlp.fc1.weight"), device), _f16(K(p + "mlp.fc1.bias"), device)
+            L.fc2_w, L.fc2_b = _f16(K(p + "mlp.fc2.weight"), device), _f16(K(p + "mlp.fc2.bias"), device)
+            eng.layers.append(L)
+        return eng
+
+    def parameters(self):
+        yield self.tok_emb
+
+    def _block(self, h: Tensor, L: _ViTLayer, B: int, N: int) -> Tensor:
+        D = self.hidden
+        scale = (D // self.heads) ** -0.5
+        n1 = ops.layernorm(h, L.ln1_w, L.ln1_b, self.eps)
+        qkv = ops.gemm(n1, L.qkv_w, L.qkv_b).reshape(B, N, 3 * D)
+        o = ops.causal_attention(qkv[:, :, :D].contiguous(), qkv[:, :, D:2 * D], qkv[:, :, 2 * D:], self.heads, scale)
+        h = ops.gemm(o.reshape(B * N, D), L.o_w, L.o_b, residual=h)
+        n2 = ops.layernorm(h, L.ln2_w, L.ln2_b, self.eps)
+        m = ops.gemm(n2, L.fc1_w, L.fc1_b, act=self.act)
+        return ops.gemm(m, L.fc2_w, L.fc2_b, residual=h)
+
+    def encode(self, input_ids: Tensor):
+        """input_ids: [B,T] integer tokens -> (penultimate hidden states [B,T,D], pooled-or-last output)."""
+        ids = input_ids.to(self.device, torch.int32).contiguous()
+        B, T = ids.shape
+        D = self.hidden
+        h = ops.embed_tokens(ids, self.tok_emb, self.pos_emb).reshape(B * T, D)
+        penultimate = None
+        for i, L in enumerate(self.layers):
+            if i == len(self.layers) - 1:
+                penultimate = h.reshape(B, T, D).clone()
+            h = self._block(h, L, B, T)
+        if len(self.layers) == 1:
+            penultimate = penultimate if penultimate is not None else h.reshape(B, T, D)
+        last = ops.layernorm(h, self.final_ln[0], self.final_ln[1], self.eps).reshape(B, T, D)
+        if self.text_projection is None:
+            return penultimate, last
+        # pooled = state at the EOS token (transformers: first eos_token_id position, legacy: argmax of the ids)
+        if self.eos_token_id is not None and self.eos_token_id != 2:
+            pos = (ids == self.eos_token_id).int().argmax(dim=-1)
+        else:
+            pos = ids.argmax(dim=-1)
+        pooled = last[torch.arange(B, device=self.device), pos.long()].contiguous()
+        return penultimate, ops.gemm(pooled, self.text_projection)

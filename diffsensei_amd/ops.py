@@ -145,6 +145,32 @@ def ip_region_flags(bbox: Tensor, N: int, mask_hw: Tuple[int, int]) -> Tensor:
     return flags
 
 
+def embed_tokens(ids: Tensor, tok_emb: Tensor, pos_emb: Tensor) -> Tensor:
+    """ids: int32 [B,T]; tok_emb: [vocab,D]; pos_emb: [>=T,D] -> [B,T,D] = tok_emb[ids] + pos_emb[:T]."""
+    _chk(tok_emb, pos_emb)
+    _chk(ids, dtype=torch.int32)
+    B, T = ids.shape
+    D = tok_emb.shape[1]
+    out = torch.empty((B, T, D), dtype=torch.float16, device=ids.device)
+    check(_lib.load().ds_embed_tokens_f16(_p(ids), _p(tok_emb), _p(pos_emb), _p(out), B, T, D, tok_emb.shape[0],
+                                          _stream()), "ds_embed_tokens_f16")
+    return out
+
+
+def causal_attention(q: Tensor, k: Tensor, v: Tensor, heads: int, scale: float) -> Tensor:
+    """Causal self-attention over [B,N,heads*D] (k/v may be column-slice views): the CLIP text encoders."""
+    _chk(q)
+    for t in (k, v):
+        if not t.is_cuda or t.dtype != torch.float16 or t.stride(2) != 1:
+            raise _lib.DiffSenseiHipError("causal_attention: k/v must be fp16 device tensors with unit inner stride")
+    B, N, Cc = q.shape
+    o = torch.empty_like(q)
+    check(_lib.load().ds_small_attn_causal_f16(_p(q), Cc, N * Cc, _p(k), k.stride(1), k.stride(0), _p(v), v.stride(1),
+                                               v.stride(0), _p(o), Cc, N * Cc, B, heads, N, Cc // heads, scale,
+                                               _stream()), "ds_small_attn_causal_f16")
+    return o
+
+
 def small_attention(q: Tensor, k: Tensor, v: Tensor, heads: int, scale: float) -> Tensor:
     """q: [B,Nq,heads*D], k/v: [B,Nk,heads*D] (any D<=128 multiple of 8); k/v may be column-slice views."""
     _chk(q)

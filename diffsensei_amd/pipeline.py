@@ -20,7 +20,7 @@ from typing import Any, List, Optional, Tuple, Union
 
 import torch
 
-from .encoders import ClipVisionEngine, ViTMAEEngine
+from .encoders import ClipTextEngine, ClipVisionEngine, ViTMAEEngine
 from .unet import UNetMangaModel, dialog_pixel_boxes
 
 Tensor = torch.Tensor
@@ -39,9 +39,11 @@ def _black_image():
 class DiffSenseiPipeline:
     def __init__(self, vae, text_encoder, text_encoder_2, tokenizer, tokenizer_2, scheduler, unet: UNetMangaModel,
                  image_encoder, feature_extractor=None, force_zeros_for_empty_prompt: bool = True):
-        self.vae, self.text_encoder, self.text_encoder_2 = vae, text_encoder, text_encoder_2
+        self.vae = vae
         self.tokenizer, self.tokenizer_2 = tokenizer, tokenizer_2
         self.scheduler, self.unet = scheduler, unet
+        self.text_encoder = self._as_text_engine(text_encoder)
+        self.text_encoder_2 = self._as_text_engine(text_encoder_2)
         self.image_encoder = self._as_clip_engine(image_encoder)
         self.feature_extractor = feature_extractor
         self.force_zeros_for_empty_prompt = force_zeros_for_empty_prompt
@@ -84,6 +86,11 @@ class DiffSenseiPipeline:
         if m is None or isinstance(m, ClipVisionEngine):
             return m
         return ClipVisionEngine.from_transformers(m, self.unet.device)
+
+    def _as_text_engine(self, m):
+        if m is None or isinstance(m, ClipTextEngine):
+            return m
+        return ClipTextEngine.from_transformers(m, self.unet.device)
 
     def _as_magi_engine(self, m):
         if m is None or isinstance(m, ViTMAEEngine):
@@ -181,10 +188,9 @@ class DiffSenseiPipeline:
             embs, pooled = [], None
             for text, tok, te in zip(texts, toks, encs):
                 ids = tok(text, padding="max_length", max_length=tok.model_max_length, truncation=True,
-                          return_tensors="pt").input_ids.to(next(te.parameters()).device)
-                out = te(ids, output_hidden_states=True)
-                pooled = out[0]
-                embs.append(out.hidden_states[-2])
+                          return_tensors="pt").input_ids
+                hidden, pooled = te.encode(ids)     # HIP text-encoder engine: (hidden_states[-2], out[0])
+                embs.append(hidden)
             return torch.cat(embs, dim=-1), pooled
 
         with torch.no_grad():

@@ -94,6 +94,15 @@ int ds_small_attn_f16(const void* q, int64_t ldq, int64_t sq, const void* k, int
                       int64_t ldv, int64_t sv, void* o, int64_t ldo, int64_t so, int B, int heads, int Nq, int Nk,
                       int D, float scale, void* stream);
 
+/* causal variant (token t attends to tokens <= t): the SDXL CLIP text encoders reached through `encode_prompt`
+ * (reference src/pipelines/pipeline_diffsensei.py:237-245 -> transformers CLIPTextModel [3P]) */
+int ds_small_attn_causal_f16(const void* q, int64_t ldq, int64_t sq, const void* k, int64_t ldk, int64_t sk, const void* v,
+                             int64_t ldv, int64_t sv, void* o, int64_t ldo, int64_t so, int B, int heads, int N, int D,
+                             float scale, void* stream);
+/* out[b,t,:] = tok_emb[ids[b,t],:] + pos_emb[t,:]  (CLIPTextEmbeddings [3P]); ids int32 [B,T] */
+int ds_embed_tokens_f16(const int32_t* ids, const void* tok_emb, const void* pos_emb, void* out, int B, int T, int D,
+                        int vocab, void* stream);
+
 /* conv_in (Cin=4) fused with UNetMangaModel.encode_dialog_bbox (reference src/models/unet.py:206-210, :88-114).
  * dialog_boxes: int32 [B,ndialog,4] pixel boxes (x1,y1,x2,y2), already truncated/clamped like the reference. */
 int ds_conv_in_dialog_f16(const void* x, const void* w, const void* bias, const int32_t* dialog_boxes,

@@ -108,3 +108,55 @@ def test_pipeline_call_vs_oracle(encoders):
         ref = sample_loop(UNetOracle(cfg, sd, q=hq), EulerDiscreteOracle(), hq(lat0.float() * sch.init_noise_sigma),
                           hq(enc), hq(te), tid, bbox, db, 7.5, steps, 0.6, q=hq)
     assert _rel(results[0], ref) <= 5e-2, _rel(results[0], ref)
+
+
+class _FakeTokenizer:
+    """Deterministic stand-in for CLIPTokenizer (no vocabulary files offline): hashes words to ids, BOS/EOS/pad like CLIP."""
+    model_max_length = 77
+
+    def __init__(self, vocab=1000, bos=998, eos=999):
+        self.vocab, self.bos, self.eos = vocab, bos, eos
+
+    def __call__(self, text, padding=None, max_length=77, truncation=True, return_tensors="pt"):
+        words = [1 + (sum(ord(c) * (i + 1) for i, c in enumerate(w)) % (self.bos - 2)) for w in text.split()]
+        ids = [self.bos] + words[: max_length - 2] + [self.eos]
+        ids += [self.eos] * (max_length - len(ids))
+        return type("Enc", (), {"input_ids": torch.tensor([ids])})()
+
+
+def test_text_encoder_engines_and_encode_prompt(hip_lib):
+    """SDXL prompt path (reference :237-245): both CLIP text encoders on the HIP engine vs transformers fp32."""
+    from transformers import CLIPTextConfig, CLIPTextModel, CLIPTextModelWithProjection
+    from diffsensei_amd.encoders import ClipTextEngine
+    from diffsensei_amd.pipeline import DiffSenseiPipeline
+    from diffsensei_amd.schedulers import EulerDiscreteScheduler
+    from diffsensei_amd.unet import UNetMangaModel
+    from diffsensei_amd.unet_config import tiny_config
+    torch.manual_seed(0)
+    c1 = CLIPTextConfig(vocab_size=1000, hidden_size=128, intermediate_size=256, num_hidden_layers=3, num_attention_heads=2,
+                        max_position_embeddings=77, hidden_act="quick_gelu", eos_token_id=999, bos_token_id=998, pad_token_id=0)
+    c2 = CLIPTextConfig(vocab_size=1000, hidden_size=192, intermediate_size=384, num_hidden_layers=4, num_attention_heads=3,
+                        max_position_embeddings=77, hidden_act="gelu", projection_dim=128, eos_token_id=999,
+                        bos_token_id=998, pad_token_id=0)
+    te1, te2 = CLIPTextModel(c1).eval(), CLIPTextModelWithProjection(c2).eval()
+    tok = _FakeTokenizer()
+    ids = torch.cat([tok("a young man holding a baby on his back").input_ids, tok("two men talking").input_ids])
+    with torch.no_grad():
+        r1, r2 = te1(ids, output_hidden_states=True), te2(ids, output_hidden_states=True)
+    e1, e2 = ClipTextEngine.from_transformers(te1, DEV), ClipTextEngine.from_transformers(te2, DEV)
+    h1, last1 = e1.encode(ids)
+    h2, pooled2 = e2.encode(ids)
+    assert _rel(h1, r1.hidden_states[-2]) <= 2e-2 and _rel(last1, r1[0]) <= 2e-2
+    assert _rel(h2, r2.hidden_states[-2]) <= 2e-2 and _rel(pooled2, r2[0]) <= 2e-2
+    assert pooled2.shape == (2, 128)
+    # through the pipeline's encode_prompt, CFG with the empty negative prompt forced to zeros
+    unet = UNetMangaModel(tiny_config(), device=DEV)
+    pipe = DiffSenseiPipeline(None, te1, te2, tok, tok, EulerDiscreteScheduler(), unet, None)
+    pe, ne, pp, npool = pipe.encode_prompt("a young man holding a baby on his back", None, DEV, 2, True, None, None)
+    ref = torch.cat([r1.hidden_states[-2][:1], r2.hidden_states[-2][:1]], dim=-1)
+    assert pe.shape == (2, 77, 128 + 192) and pp.shape == (2, 128)
+    assert _rel(pe[0], ref[0]) <= 2e-2 and torch.equal(pe[0], pe[1]) and _rel(pp[0], r2[0][0]) <= 2e-2
+    assert ne.abs().sum() == 0 and npool.abs().sum() == 0
+    pe2, ne2, _, _ = pipe.encode_prompt("a young man holding a baby on his back", None, DEV, 1, True, "two men talking", None)
+    ref_n = torch.cat([r1.hidden_states[-2][1:2], r2.hidden_states[-2][1:2]], dim=-1)
+    assert _rel(ne2[0], ref_n[0]) <= 2e-2
