@@ -10,8 +10,9 @@ A "step" is ONE `DiffSenseiPipeline.__call__` over a batch of `--num-samples` pa
 plan.  Inputs are synthetic and already resident in HBM where tensors are involved (prompt embeddings, character
 images are 224x224 uint8 that go through the reference's CPU image processors).  Weights: seeded random at the true
 SDXL / CLIP-H / ViT-MAE / Resampler shapes (no checkpoint is reachable offline; throughput is value independent).
-NOT in the timed region (SURVEY.md §8f "next", stated in `config.timed_region`): the two CLIP text encoders
-(prompt embeddings are inputs) and the VAE decode (latents are the output).
+The timed region also runs both SDXL text encoders (CLIP-L + OpenCLIP bigG shapes, HIP engine) on the prompt and the
+negative prompt (token ids from a synthetic tokenizer: no vocabulary files offline).  NOT in the timed region
+(SURVEY.md §8f "next", stated in `config.timed_region`): the VAE decode (latents are the output).
 
 N > 1: one process per GPU, weights broadcast from rank 0 over RCCL once (time reported, outside the timed region),
 each rank serves its own requests with no data-path collective -> "scaling": "weak".  Timing: barrier +
@@ -69,10 +70,24 @@ def build_pipeline(device, num_gpus, rank, seed=0):
     resampler = Resampler(dim=1280, depth=4, dim_head=64, heads=20, num_queries=16, num_dummy_tokens=16,
                           embedding_dim=1280, magi_embedding_dim=768, output_dim=cfg.cross_attention_dim, ff_mult=4,
                           device=device).init_random(seed + 1)
+    # SDXL prompt encoders (CLIP ViT-L/14 text, OpenCLIP bigG/14 text) at their true shapes, random init
+    from transformers import CLIPTextConfig, CLIPTextModel, CLIPTextModelWithProjection
+    from diffsensei_amd.encoders import ClipTextEngine
+    t1 = CLIPTextConfig(vocab_size=49408, hidden_size=768, intermediate_size=3072, num_hidden_layers=12,
+                        num_attention_heads=12, max_position_embeddings=77, hidden_act="quick_gelu")
+    t2 = CLIPTextConfig(vocab_size=49408, hidden_size=1280, intermediate_size=5120, num_hidden_layers=32,
+                        num_attention_heads=20, max_position_embeddings=77, hidden_act="gelu", projection_dim=1280)
+    with torch.device("cpu"):
+        te1 = ClipTextEngine.from_transformers(CLIPTextModel(t1).eval(), device)
+        te2 = ClipTextEngine.from_transformers(CLIPTextModelWithProjection(t2).eval(), device)
     t_init = time.perf_counter() - t0
     bstats = {"bytes": 0, "seconds": 0.0, "buckets": 0}
     if num_gpus > 1:
         tensors = list(unet._sd.values()) + list(resampler._sd.values())
+        for eng in (te1, te2):
+            for L in eng.layers:
+                tensors += [getattr(L, s) for s in L.__slots__]
+            tensors += [eng.tok_emb, eng.pos_emb, *eng.final_ln] + ([eng.text_projection] if eng.text_projection is not None else [])
         for eng in (clip, magi):
             for L in eng.layers:
                 tensors += [getattr(L, s) for s in L.__slots__]
@@ -82,11 +97,23 @@ def build_pipeline(device, num_gpus, rank, seed=0):
                     tensors += list(pair)
         dist.barrier()
         bstats = broadcast_tensors(tensors, src=0)
-    pipe = DiffSenseiPipeline(vae=None, text_encoder=None, text_encoder_2=None, tokenizer=None, tokenizer_2=None,
+    tok = SyntheticTokenizer()
+    pipe = DiffSenseiPipeline(vae=None, text_encoder=te1, text_encoder_2=te2, tokenizer=tok, tokenizer_2=tok,
                               scheduler=EulerDiscreteScheduler(), unet=unet, image_encoder=clip)
     pipe.register_manga_modules(magi_image_encoder=magi, image_proj_model=resampler)
     return pipe, {"init_s": round(t_init, 2), "broadcast_bytes": bstats["bytes"],
                   "broadcast_ms": round(bstats["seconds"] * 1e3, 2), "broadcast_buckets": bstats["buckets"]}
+
+
+class SyntheticTokenizer:
+    """CLIP tokenizer stand-in (no vocabulary files offline): hashes words to ids, BOS 49406 / EOS+pad 49407, 77 slots."""
+    model_max_length = 77
+
+    def __call__(self, text, padding=None, max_length=77, truncation=True, return_tensors="pt"):
+        words = [1 + (sum(ord(c) * (i + 1) for i, c in enumerate(w)) % 49000) for w in text.split()]
+        ids = [49406] + words[: max_length - 2] + [49407]
+        ids += [49407] * (max_length - len(ids))
+        return type("Enc", (), {"input_ids": torch.tensor([ids])})()
 
 
 def synthetic_request(device, size, seed):
@@ -100,8 +127,7 @@ def synthetic_request(device, size, seed):
         num_inference_steps=50, guidance_scale=7.5, ip_images=imgs,
         ip_bbox=[[0.05, 0.10, 0.50, 0.95], [0.50, 0.10, 0.95, 0.95]], ip_scale=0.6,
         dialog_bbox=[[0.05, 0.02, 0.30, 0.15], [0.65, 0.02, 0.95, 0.15]],
-        prompt_embeds=torch.randn(1, 77, 2048, generator=g).half().to(device),
-        pooled_prompt_embeds=torch.randn(1, 1280, generator=g).half().to(device),
+        negative_prompt="think lines, pure black background, colored, lowres, bad anatomy, worst quality, low quality",
         generator=torch.Generator().manual_seed(seed), output_type="latent")
 
 
@@ -227,12 +253,12 @@ def main():
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"{args.size}x{args.size}, 50-step Euler, CFG 7.5, 2 character refs (padded to 4) + "
                                    f"2 dialog boxes, num_samples={ns} per call (UNet batch {2 * ns}), one call per step",
-                       "timed_region": "CLIP-H + ViT-MAE + Resampler character encoding, 50 x (UNet + CFG + scheduler "
-                                       "step); text encoders and VAE decode excluded (inputs: prompt embeddings, "
-                                       "output: latents)",
+                       "timed_region": "2 SDXL text encoders (prompt + negative prompt), CLIP-H + ViT-MAE + Resampler "
+                                       "character encoding, 50 x (UNet + CFG + scheduler step); VAE decode excluded "
+                                       "(output: latents)",
                        "num_samples": ns, "unet_batch": 2 * ns, "hipgraph": pipe.last_run_info.get("graph"),
                        "kernel_launches_per_denoise_step": pipe.last_run_info.get("ops_per_step"),
-                       "weights": "seeded random at SDXL/CLIP-H/ViT-MAE/Resampler shapes", **setup},
+                       "weights": "seeded random at SDXL UNet / CLIP-L + bigG text / CLIP-H / ViT-MAE / Resampler shapes", **setup},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         if extra:

@@ -8,9 +8,11 @@ What runs where
   * denoising loop (UNet + CFG + scheduler step): C++ launch plan over the HIP kernels, one `step_plan` run (or
     hipGraph replay) per step, zero host arithmetic and zero host<->device syncs inside the loop;
   * character encoders (CLIP-H, Magi ViT-MAE) + Resampler: HIP engines (`encoders.py`, `resampler.py`);
-  * text encoders and the VAE decoder are NOT part of this path (SURVEY.md §8f "next"): any object with the
-    transformers / diffusers call protocol can be passed in, or the caller supplies `prompt_embeds` and asks for
-    `output_type="latent"`.
+  * the two SDXL CLIP text encoders (`encode_prompt`): HIP engine (`encoders.ClipTextEngine`),
+    transformers models passed to the constructor are re-laid-out for it; tokenisation stays on the host;
+  * the VAE decoder is NOT part of this path yet (the reference runs it in fp32 because fp16
+    overflows; these kernels are fp16): any object with the diffusers `decode` protocol can be passed in, or the caller
+    asks for `output_type="latent"`.
 """
 from __future__ import annotations
 
