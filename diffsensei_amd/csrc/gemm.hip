@@ -994,7 +994,7 @@ int launch_ws(const GemmParams& p0, int batch, hipStream_t stream) {
     return 0;
 }
 
-enum Kind { K_REG, K_GLDS2, K_GLDS1, K_RING, K_WS };
+enum Kind { K_REG, K_GLDS2, K_GLDS1, K_RING, K_WS, K_PP };
 struct Choice {
     Kind kind;
     int bm;   // rows of the block tile (K_WS: BNT)
@@ -1019,6 +1019,9 @@ Choice choose(const GemmParams& p, int batch) {
         return c;
     }
     switch (g_gemm_variant) {
+        case 3:
+            if (ds_gemm_pp_applicable(p)) { c.kind = K_PP; c.bm = 256; return c; }
+            break;
         case 2: c.kind = K_GLDS2; return c;
         case 7: c.kind = K_GLDS2; c.bm = 64; return c;
         case 8: c.kind = K_GLDS1; return c;
@@ -1047,6 +1050,19 @@ Choice choose(const GemmParams& p, int batch) {
         c.kind = K_GLDS1;
     } else {
         c.kind = (p.K >= 4096 && p.N <= 2048) ? K_GLDS2 : K_GLDS1;
+        // 256 x 256 persistent ping-pong kernel (gemm_pp.hip): one block per CU, so it only pays when the tile count
+        // fills whole rounds of the 256 CUs (>= 2 rounds, last round >= 80 % full) and the problem is not the
+        // short-K, narrow-N projection (profiles/r01_gemm_pp_microbench.txt: +6..20 % on the FF up-projections, the
+        // fused q|k projection and the level-1 FF down-projection; a loss at N = 1280 x M = 16384 = 1.25 rounds).
+        if (batch == 1 && ds_gemm_pp_applicable(p)) {
+            const long t = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
+            const long rounds = (t + 255) / 256;
+            const bool fills = t >= 512 && t * 10 >= rounds * 256 * 8;
+            if (fills && !(p.N <= 640 && p.K <= 640)) {
+                c.kind = K_PP;
+                c.bm = 256;
+            }
+        }
     }
     return c;
 }
@@ -1057,6 +1073,7 @@ const char* ds_gemm_kernel_name(const GemmParams& p, int batch) {
     const Choice c = choose(p, batch);
     const bool conv = p.conv != 0;
     switch (c.kind) {
+        case K_PP: return "gemm_pp_kernel<0>";
         case K_WS:
             if (c.bm == 256) return conv ? "gemm_ws_kernel<256,true>" : "gemm_ws_kernel<256,false>";
             return conv ? "gemm_ws_kernel<128,true>" : "gemm_ws_kernel<128,false>";
@@ -1091,6 +1108,7 @@ int ds_launch_gemm(const GemmParams& p_in, int batch, hipStream_t stream) {
     if (p.epi == EPI_GEGLU) DS_REQUIRE(p.N % 128 == 0, "geglu: packed N (%d) must be a multiple of 128", p.N);
     const Choice c = choose(p, batch);
     switch (c.kind) {
+        case K_PP: return ds_launch_gemm_pp(p, batch, stream);
         case K_WS:
             if (c.bm == 256) return conv ? launch_ws<256, true>(p, batch, stream) : launch_ws<256, false>(p, batch, stream);
             return conv ? launch_ws<128, true>(p, batch, stream) : launch_ws<128, false>(p, batch, stream);

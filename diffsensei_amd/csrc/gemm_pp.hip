@@ -1,0 +1,473 @@
+// fp16 MFMA GEMM, 256 x 256 x 64 block tile, 8 waves in two staggered groups ("ping-pong"), persistent blocks:
+// the large-problem path of ds_launch_gemm (same GemmParams and epilogue semantics as gemm.hip; the reference call
+// sites are listed there).
+//
+// Why a second main loop.  The 128 x 128 kernels of gemm.hip move 32 KiB of operand tiles through L2 -> LDS per
+// 2 MFLOP of work; a CU sustains ~25-40 B/clk on that path (profiles/r01_gemm_ablation.txt), which caps them near
+// 0.8 PFLOP/s whatever the schedule.  A 256 x 256 tile halves the bytes per flop, but one workgroup then owns the CU,
+// so the overlap that three independent 128 x 128 blocks got for free has to be built inside the block:
+//
+//   * 8 waves = 2 (M) x 4 (N); waves w and w+4 share a SIMD.  Waves 4..7 run one barrier behind waves 0..3, so on
+//     every SIMD one wave is inside its MFMA cluster (s_setprio 1) while the other issues ds_reads and LDS-DMA.
+//   * a k-tile is four phases; each phase = {ds_read one operand sub-tile, stage one 16-KiB half-tile of a later
+//     k-tile with global_load_lds, s_barrier, 8 x v_mfma_f32_32x32x16_f16 on one 64 x 32 quadrant, s_barrier}.
+//   * the tile is cut into half-tiles A0/A1 (tile rows 0..127 / 128..255) and B0/B1 so that each is read in exactly
+//     one phase (A0: P1, B0: P1, B1: P2, A1: P3; B0's fragments stay in registers for P4).  A wave owns rows
+//     {64 wr.., 128 + 64 wr..} and two 32-column strips, one out of each B half.
+//   * LDS: 2 buffers x 4 half-tiles x 16 KiB = 128 KiB (+ 8 x 4 KiB wave-private epilogue staging = all 160 KiB).
+//     Staging order P1: A1(t+1), P2: B0(t+2), P3: A0(t+2), P4: B1(t+2): every slot is refilled as soon as it is
+//     free, and waited for (counted s_waitcnt vmcnt(10): all but the five newest half-tiles) one phase before its
+//     own read, so ~80 KiB per CU are in flight in the steady state.  The k-loop has no branch: past the end of K the
+//     stages re-fetch the last k-tile into slots nobody reads, so the counts never change.
+//   Hazards (group 1 runs one barrier late, so a phase spans three barrier intervals):
+//     RAW  data waited for in phase p is read from phase p+1 on.
+//     WAR  a half-tile is restaged >= 2 phases after its last ds_read; B0 is restaged ONE phase after its read,
+//          which is legal only because P1 issues the B0 reads first and retires them (lgkmcnt(8)) before P1's
+//          first barrier.
+//   * persistent: a block walks tiles id = round * grid + chunk-of-its-XCD; the operand loads of the NEXT output
+//     tile's first k-tiles are issued before the epilogue of the current one, so the pipeline fill hides under the
+//     C stores.
+//
+// Column ownership is chosen for the epilogue (the B half-tiles are just a permutation of the 256 tile columns):
+//   plain  half h, LDS row r -> tile column (r>>5)*64 + h*32 + (r&31): a wave ends up with 64 adjacent columns, i.e.
+//          whole 128-byte lines of C per row;
+//   GEGLU  (packed weights: every 128 columns = 64 hidden | their 64 gates)  (r>>6)*128 + h*64 + (r&63): a lane holds
+//          a hidden value (B0 strip) and its gate (B1 strip), so h * gelu(g) happens in registers.
+// The epilogue transposes 32-row pieces through the wave's private 4 KiB of LDS (swizzled, conflict-free, no
+// barrier) so every global store / residual load is 16 bytes per lane over whole rows.
+#include "ds_common.h"
+#include "ds_kernels.h"
+
+namespace {
+
+constexpr int HT = 16384;  // bytes of one half-tile: 128 rows x 64 k of f16
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+template <int V>
+struct IC {
+    static constexpr int value = V;
+};
+
+#define PP_FENCE()                               \
+    do {                                         \
+        asm volatile("" ::: "memory");           \
+        __builtin_amdgcn_sched_barrier(0);       \
+    } while (0)
+#define PP_BARRIER()                             \
+    do {                                         \
+        PP_FENCE();                              \
+        __builtin_amdgcn_s_barrier();            \
+        PP_FENCE();                              \
+    } while (0)
+
+#define PP_PRIO(v)                                              \
+    do {                                                        \
+        if constexpr ((DBG & 8) == 0) __builtin_amdgcn_s_setprio(v); \
+    } while (0)
+
+template <int DBG>  // ablation builds only: 1 = no MFMA, 2 = no tile loads, 4 = no fragment reads (garbage results), 8 = no s_setprio, 16 = clock probe written over C[0..15]; 0 in production
+__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const long bz = blockIdx.z;
+    const int nk = p.K / 64;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const bool geglu = p.epi == EPI_GEGLU;
+    const int ntiles = p.tiles_m * p.tiles_n;
+
+    // ---- persistent tile walk: round-major, then one contiguous chunk of the logical order per XCD (block b runs on
+    // XCD b % 8), so the tiles an XCD has in flight share A / W panels in its L2
+    const int G = gridDim.x;
+    const int tile_local = (G % 8 == 0) ? (int)(blockIdx.x % 8) * (G / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+
+    // ---- staging: every wave moves LDS rows 16w .. 16w+15 of each half-tile (two 1-KiB LDS-DMA pieces).  The DMA
+    // destination is lane-linear, so the XOR swizzle is applied to the lane's SOURCE chunk.
+    const int lrow = lane >> 3, slot = lane & 7;
+    unsigned oA[2], oB[2];  // BYTE offsets, unsigned: (uniform base) + zext(lane offset) selects the SGPR-base address mode
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = j * 8 + lrow;                     // row within the wave's 16
+        const int chunk = slot ^ ((r >> 1) & 7);        // (16w + r) >> 1 & 7 == (r >> 1) & 7
+        oA[j] = (unsigned)(r * (int)p.lda + chunk * 8) * 2u;
+        oB[j] = (unsigned)(r * (int)p.ldw + chunk * 8) * 2u;
+    }
+    // tile columns of this wave's staging rows, per B half (see the header): first column of its 16
+    const int cb0 = geglu ? (wave >> 2) * 128 + (wave & 3) * 16 : (wave >> 1) * 64 + (wave & 1) * 16;
+    const int cbh = geglu ? 64 : 32;
+    const half_t* gA[2];
+    const half_t* gB[2];
+    auto set_tile = [&](int id, int& m0, int& n0) {
+        int tm, tn;
+        tile_coords(id, p.tiles_m, p.tiles_n, tm, tn);
+        if constexpr ((DBG & 32) != 0) tm = tn = 0;  // ablation: every block works on tile (0,0): all operand loads hit L2
+        m0 = tm * 256;
+        n0 = tn * 256;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            // ragged edges: a wave's 16 rows are all inside or all outside (M, N multiples of 16); outside rows
+            // re-read the tile's first row - their products are never stored
+            const int ra = m0 + h * 128 + wave * 16;
+            const int rb = n0 + cb0 + h * cbh;
+            gA[h] = p.A + bz * p.sA + (long)(ra < p.M ? ra : m0) * p.lda;
+            gB[h] = p.W + bz * p.sW + (long)(rb < p.N ? rb : n0) * p.ldw;
+        }
+    };
+    char* const sdst = smem + wave * 2048;
+    auto stage = [&](int op, int half, int buf, int kt) {
+        char* d = sdst + ((op * 2 + half) * 2 + buf) * HT;
+        const char* s = reinterpret_cast<const char*>((op == 0 ? gA[half] : gB[half]) + kt * 64);
+        const unsigned o0 = op == 0 ? oA[0] : oB[0], o1 = op == 0 ? oA[1] : oB[1];
+        if constexpr ((DBG & 2) != 0) return;
+        __builtin_amdgcn_global_load_lds((glb_void*)(s + (size_t)o0), (lds_void*)d, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_void*)(s + (size_t)o1), (lds_void*)(d + 1024), 16, 0, 0);
+    };
+    auto stage_prologue = [&]() {  // all of k-tile 0, and B0/A0/B1 of k-tile 1 (its A1 is staged by tile 0's P1)
+        stage(0, 0, 0, 0);
+        stage(1, 0, 0, 0);
+        stage(1, 1, 0, 0);
+        stage(0, 1, 0, 0);
+        if (nk > 1) {
+            stage(1, 0, 1, 1);
+            stage(0, 0, 1, 1);
+            stage(1, 1, 1, 1);
+        }
+    };
+
+    // ---- fragment addresses: row r of a half-tile at r*128, 16-byte chunk c at ((c ^ ((r>>1)&7)) << 4)
+    const int sw = (l31 >> 1) & 7;
+    unsigned fA[4], fB[4];  // LDS byte offsets, one per k-step: half / buffer / row-block are immediate ds_read offsets
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        fA[kk] = (wr * 64 + l31) * 128 + (((kk * 2 + lhi) ^ sw) << 4);
+        fB[kk] = 4 * HT + (wc * 32 + l31) * 128 + (((kk * 2 + lhi) ^ sw) << 4);
+        asm volatile("" : "+v"(fA[kk]), "+v"(fB[kk]));  // keep the eight addresses resident: no VALU in the load phases
+    }
+    h8 dummy = {};
+    if constexpr ((DBG & 4) != 0) asm volatile("" : "+v"(dummy));
+    auto readA = [&](int half, int buf, int mi, int kk) -> h8 {
+        if constexpr ((DBG & 4) != 0) return dummy;  // ablation: no fragment reads
+        return *reinterpret_cast<const h8*>(smem + fA[kk] + ((half * 2 + buf) * HT + mi * 4096));
+    };
+    auto readB = [&](int half, int buf, int kk) -> h8 {
+        if constexpr ((DBG & 4) != 0) return dummy;
+        return *reinterpret_cast<const h8*>(smem + fB[kk] + (half * 2 + buf) * HT);
+    };
+
+    // Counted wait: returns once every LDS-DMA older than the `n` newest half-tiles (2 instructions each) has landed.
+    // Each half-tile is staged as soon as its slot is free (2 phases after the slot's read) and waited for one phase
+    // before its own read, so 5 half-tiles (80 KiB) are in flight per CU in the steady state: ~10 barrier intervals
+    // (~1.5 us) of latency cover.  (One wait per k-tile - vmcnt(6) in P4 - measured the same within noise.)
+    auto wait_newer = [&](int n) {
+        switch (n) {
+            case 5: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        }
+    };
+
+    f32x16 acc[4][2];
+    constexpr bool mma_on = (DBG & 1) == 0;
+    // No branch anywhere in a k-tile (a taken scalar branch costs more than the slack a phase has): past the end of K
+    // the stages simply re-fetch the last k-tile into a buffer nobody reads, so the counted waits never change.
+    auto ktile = [&](auto bufc, int kt) {
+        constexpr int B = decltype(bufc)::value;
+        constexpr bool n1 = true, n2 = true;
+        const int kt1 = min(kt + 1, nk - 1), kt2 = min(kt + 2, nk - 1);
+        h8 bl[4], br[4], a0[4][2], a1[4][2];
+        // ---------------- P1: B0 strip (first: retired before the barrier, see WAR above) + A0 rows
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) bl[kk] = readB(0, B, kk);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            a0[kk][0] = readA(0, B, 0, kk);
+            a0[kk][1] = readA(0, B, 1, kk);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        stage(0, 1, B ^ 1, kt1);
+        wait_newer(n1 ? 5 : 1);  // B1(kt), read in P2: newer = A1(kt) [+ B0 A0 B1 A1 of kt+1]
+        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+        PP_BARRIER();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        PP_PRIO(1);
+        if constexpr (mma_on) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[kk], a0[kk][0], acc[0][0], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[kk], a0[kk][1], acc[1][0], 0, 0, 0);
+            }
+        }
+        PP_PRIO(0);
+        PP_BARRIER();
+        // ---------------- P2: B1 strip
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) br[kk] = readB(1, B, kk);
+        __builtin_amdgcn_sched_barrier(0);
+        stage(1, 0, B, kt2);
+        wait_newer((n1 ? 4 : 0) + (n2 ? 1 : 0));  // A1(kt), read in P3: newer = all of kt+1 [+ B0(kt+2)]
+        PP_BARRIER();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        PP_PRIO(1);
+        if constexpr (mma_on) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(br[kk], a0[kk][0], acc[0][1], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(br[kk], a0[kk][1], acc[1][1], 0, 0, 0);
+            }
+        }
+        PP_PRIO(0);
+        PP_BARRIER();
+        // ---------------- P3: A1 rows
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            a1[kk][0] = readA(1, B, 0, kk);
+            a1[kk][1] = readA(1, B, 1, kk);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        stage(0, 0, B, kt2);
+        PP_BARRIER();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        PP_PRIO(1);
+        if constexpr (mma_on) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(br[kk], a1[kk][0], acc[2][1], 0, 0, 0);
+                acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(br[kk], a1[kk][1], acc[3][1], 0, 0, 0);
+            }
+        }
+        PP_PRIO(0);
+        PP_BARRIER();
+        // ---------------- P4: no reads (B0 strip still in registers); the k-tile's one counted wait
+        stage(1, 1, B, kt2);
+        if (n1) wait_newer(n2 ? 5 : 2);  // B0 A0 (kt+1), read in the next P1: newer = B1 A1 (kt+1) [+ B0 A0 B1 (kt+2)]
+        PP_BARRIER();
+        PP_PRIO(1);
+        if constexpr (mma_on) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[kk], a1[kk][0], acc[2][0], 0, 0, 0);
+                acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[kk], a1[kk][1], acc[3][0], 0, 0, 0);
+            }
+        }
+        PP_PRIO(0);
+        PP_BARRIER();
+    };
+
+    half_t* const Cg = p.C + bz * p.sC;
+    const half_t* const Rg = p.residual ? p.residual + bz * p.sR : nullptr;
+    char* const ep = smem + 8 * HT + wave * 4096;  // wave-private transposition tile
+
+    int id = tile_local;
+    if (id >= ntiles) return;
+    unsigned long long probe_c0 = 0, probe_r0 = 0;
+    if constexpr ((DBG & 16) != 0) {  // clock probe: shader cycles vs the constant 100 MHz reference
+        probe_c0 = __builtin_readcyclecounter();
+        probe_r0 = __builtin_amdgcn_s_memrealtime();
+    }
+    int m0, n0;
+    set_tile(id, m0, n0);
+    stage_prologue();
+    bool first = true;
+    while (true) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        // k-tile 0 must have landed; after the first tile the previous epilogue's stores are in the count too
+        if (first) wait_newer(nk > 1 ? 5 : 2);  // A0 B0 of k-tile 0: newer = B1 A1 [+ B0 A0 B1 of k-tile 1]
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        first = false;
+        PP_BARRIER();
+        if (wr == 1) PP_BARRIER();  // group 1 runs one barrier behind group 0 from here on
+        for (int kt = 0; kt < nk; kt += 2) {  // nk is even
+            ktile(IC<0>{}, kt);
+            ktile(IC<1>{}, kt + 1);
+        }
+        // (the over-fetched stages may still be in flight: a wave only ever writes its own 16 rows of a slot, and its
+        // loads return in order, so the next tile's prologue into the same slots lands after them)
+        if (wr == 0) PP_BARRIER();  // balance group 1's extra barrier: every ds_read of this tile has retired
+
+        // ---- next tile's pipeline fill goes out before this tile's epilogue
+        const int cm0 = m0, cn0 = n0;
+        id += G;
+        const bool more = id < ntiles;
+        if (more) {
+            set_tile(id, m0, n0);
+            stage_prologue();
+        }
+
+        // ---- epilogue.  D layout (operands swapped): lane holds tile row ..+(lane&31); register r of a fragment is
+        // column (r&3) + 8*(r>>2) + 4*(lane>>5) of its 32-column strip.
+        // (the lane-derived epilogue constants are rebuilt from an opaque copy so they are not kept live - spilled -
+        // across the main loop)
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        const int l31 = lane_e & 31, lhi = lane_e >> 5;
+        if (geglu) {
+            const int nw = cn0 + (wc >> 1) * 128 + (wc & 1) * 32;  // hidden strip; gates 64 columns further
+            const int no = (cn0 >> 1) + wc * 32;                   // first output column of the wave
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const int mb = cm0 + (mi >> 1) * 128 + wr * 64 + (mi & 1) * 32;
+                const int ml = mb + l31;
+                const int grp = p.rowbias ? ((ml < p.M ? ml : p.M - 1) / p.rows_per_group) : 0;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c = 8 * g + 4 * lhi;  // column within the 32-column strip
+                    float hv[4], gv[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        hv[e] = acc[mi][0][4 * g + e];
+                        gv[e] = acc[mi][1][4 * g + e];
+                    }
+                    if (nw + c < p.N) {
+                        if (p.bias) {
+                            const h4 b0 = *reinterpret_cast<const h4*>(p.bias + nw + c);
+                            const h4 b1 = *reinterpret_cast<const h4*>(p.bias + nw + 64 + c);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) hv[e] += (float)b0[e], gv[e] += (float)b1[e];
+                        }
+                        if (p.rowbias) {
+                            const half_t* rb = p.rowbias + (long)grp * p.rowbias_ld + nw + c;
+                            const h4 b0 = *reinterpret_cast<const h4*>(rb);
+                            const h4 b1 = *reinterpret_cast<const h4*>(rb + 64);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) hv[e] += (float)b0[e], gv[e] += (float)b1[e];
+                        }
+                    }
+                    h4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float hq = (float)(half_t)hv[e], gq = (float)(half_t)gv[e];
+                        o[e] = (half_t)(hq * (float)(half_t)ds_gelu_erf(gq));
+                    }
+                    // 64-byte rows: chunk (c>>3) of row l31 sits at slot chunk ^ ((row>>2)&3)
+                    *reinterpret_cast<h4*>(ep + l31 * 64 + ((((c >> 3) ^ (l31 >> 2)) & 3) << 4) + ((c >> 2) & 1) * 8) = o;
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int row = i * 16 + (lane_e >> 2), ch = lane_e & 3;
+                    const h8 v = *reinterpret_cast<const h8*>(ep + row * 64 + (((ch ^ (row >> 2)) & 3) << 4));
+                    const int m = mb + row, n = no + ch * 8;
+                    if (m < p.M && n < (p.N >> 1)) *reinterpret_cast<h8*>(Cg + (long)m * p.ldc + n) = v;
+                }
+            }
+        } else {
+            const int nw = cn0 + wc * 64;  // 64 adjacent columns: strip ni at +32*ni
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const int mb = cm0 + (mi >> 1) * 128 + wr * 64 + (mi & 1) * 32;
+                const int ml = mb + l31;
+                const int grp = p.rowbias ? ((ml < p.M ? ml : p.M - 1) / p.rows_per_group) : 0;
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int c = ni * 32 + 8 * g + 4 * lhi;  // column within the wave's 64
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][4 * g + e];
+                        if (nw + c < p.N) {
+                            if (p.bias) {
+                                const h4 bv = *reinterpret_cast<const h4*>(p.bias + nw + c);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] += (float)bv[e];
+                            }
+                            if (p.rowbias) {
+                                const h4 bv = *reinterpret_cast<const h4*>(p.rowbias + (long)grp * p.rowbias_ld + nw + c);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] += (float)bv[e];
+                            }
+                        }
+                        h4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = (half_t)v[e];
+                        // 128-byte rows: chunk (c>>3) of row l31 sits at slot chunk ^ ((row>>1)&7)
+                        *reinterpret_cast<h4*>(ep + l31 * 128 + ((((c >> 3) ^ (l31 >> 1)) & 7) << 4) + ((c >> 2) & 1) * 8) = o;
+                    }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = i * 8 + (lane_e >> 3), ch = lane_e & 7;
+                    h8 v = *reinterpret_cast<const h8*>(ep + row * 128 + (((ch ^ (row >> 1)) & 7) << 4));
+                    const int m = mb + row, n = nw + ch * 8;
+                    if (m < p.M && n < p.N) {
+                        if (p.epi == EPI_GELU) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] = (half_t)ds_gelu_erf((float)v[e]);
+                        } else if (p.epi == EPI_QUICK_GELU) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                const float f = (float)v[e];
+                                v[e] = (half_t)(f / (1.0f + __expf(-1.702f * f)));
+                            }
+                        }
+                        if (Rg) {
+                            const h8 rv = *reinterpret_cast<const h8*>(Rg + (long)m * p.ldr + n);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rv[e]);
+                        }
+                        *reinterpret_cast<h8*>(Cg + (long)m * p.ldc + n) = v;
+                    }
+                }
+            }
+        }
+        if (!more) break;
+    }
+    if constexpr ((DBG & 16) != 0) {
+        if (blockIdx.x == 0 && blockIdx.z == 0 && tid == 0) {
+            unsigned long long* o = reinterpret_cast<unsigned long long*>(p.C);
+            __builtin_amdgcn_s_waitcnt(0);
+            o[0] = __builtin_readcyclecounter() - probe_c0;
+            o[1] = __builtin_amdgcn_s_memrealtime() - probe_r0;
+        }
+    }
+}
+
+int g_pp_blocks = 0;  // persistent grid size: one block per CU
+
+}  // namespace
+
+// Shapes the kernel takes: K a multiple of 128 (an even number of k-tiles), a single A source, M and N multiples of 16 (a wave's 16
+// staged rows are then wholly inside or outside the problem).  ds_launch_gemm decides when it is also the faster choice.
+bool ds_gemm_pp_applicable(const GemmParams& p) {
+    return p.conv == 0 && p.A2 == nullptr && p.M % 16 == 0 && p.N % 16 == 0 && p.K % 128 == 0 &&
+           (p.epi != EPI_GEGLU || p.N % 128 == 0) && p.lda * 15 + 64 < (1L << 30) && p.ldw * 15 + 64 < (1L << 30);
+}
+
+int ds_launch_gemm_pp(const GemmParams& p0, int batch, hipStream_t stream) {
+    GemmParams p = p0;
+    DS_REQUIRE(ds_gemm_pp_applicable(p), "gemm_pp: shape M=%d N=%d K=%d not supported", p.M, p.N, p.K);
+    p.tiles_m = (p.M + 255) / 256;
+    p.tiles_n = (p.N + 255) / 256;
+    const size_t lds = 8 * HT + 8 * 4096;
+    typedef void (*kern_t)(const GemmParams);
+    static const struct { int dbg; kern_t k; } table[] = {
+        {0, gemm_pp_kernel<0>},   {1, gemm_pp_kernel<1>},   {2, gemm_pp_kernel<2>},   {3, gemm_pp_kernel<3>},
+        {4, gemm_pp_kernel<4>},   {6, gemm_pp_kernel<6>},   {8, gemm_pp_kernel<8>},   {16, gemm_pp_kernel<16>},
+        {17, gemm_pp_kernel<17>}, {18, gemm_pp_kernel<18>}, {20, gemm_pp_kernel<20>}, {22, gemm_pp_kernel<22>},
+        {24, gemm_pp_kernel<24>}, {48, gemm_pp_kernel<48>}, {49, gemm_pp_kernel<49>}};
+    if (g_pp_blocks == 0) {
+        for (const auto& e : table)
+            DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(e.k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int dev = 0, cus = 0;
+        DS_HIP(hipGetDevice(&dev));
+        DS_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        g_pp_blocks = cus > 0 ? cus : 256;
+    }
+    const int tiles = p.tiles_m * p.tiles_n;
+    dim3 grid(tiles < g_pp_blocks ? tiles : g_pp_blocks, 1, batch);
+    kern_t kern = nullptr;
+    for (const auto& e : table)
+        if (e.dbg == (p.debug & 63)) kern = e.k;
+    DS_REQUIRE(kern != nullptr, "gemm_pp: no ablation build for gemm_debug=%d", p.debug);
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, p);
+    DS_LAUNCH_CHECK();
+    return 0;
+}

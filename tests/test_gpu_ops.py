@@ -91,6 +91,62 @@ def test_gemm_activation(hip_lib, act):
     _close(ops.gemm(x.to(DEV), w.to(DEV), b.to(DEV), act=act), ref, what=act)
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (512, 768, 384), (272, 640, 256), (1040, 384, 640),
+                                   (4144, 1408, 640), (16, 128, 128), (8192, 2560, 1280)])
+def test_gemm_pingpong_kernel(hip_lib, M, N, K):
+    """256x256 persistent ping-pong kernel (gemm_pp.hip), forced with gemm_variant 3: fp32 reference, and bit-exact
+    agreement with the register-staged kernel (same MFMA order per output).  Ragged M/N (multiples of 16) included."""
+    from diffsensei_amd import _lib
+    ops = _ops(hip_lib)
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M * 3 + N + K)
+    x, w, b, r = _r((M, K), g), _r((N, K), g, 1 / math.sqrt(K)), _r((N,), g), _r((M, N), g)
+    ref = (x.float() @ w.float().t() + b.float()).half().float() + r.float()
+    try:
+        assert lib.ds_set_option(b"gemm_variant", 3) == 0
+        got = ops.gemm(x.to(DEV), w.to(DEV), b.to(DEV), r.to(DEV))
+        got_act = ops.gemm(x.to(DEV), w.to(DEV), b.to(DEV), act="gelu")
+        assert lib.ds_set_option(b"gemm_variant", 1) == 0
+        base = ops.gemm(x.to(DEV), w.to(DEV), b.to(DEV), r.to(DEV))
+    finally:
+        lib.ds_set_option(b"gemm_variant", 0)
+    _close(got, ref, what="pingpong bias+residual")
+    assert torch.equal(got, base)
+    _close(got_act, F.gelu(x.float() @ w.float().t() + b.float()), what="pingpong gelu")
+
+
+def test_gemm_pingpong_geglu_and_dispatch(hip_lib):
+    """GEGLU epilogue of the ping-pong kernel (hidden/gate pairing in registers) on a ragged packed width, and the
+    automatic dispatch picking it for a shape that fills whole rounds of CUs."""
+    from diffsensei_amd import _lib
+    from diffsensei_amd.engine import pack_geglu
+    ops = _ops(hip_lib)
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(11)
+    M, C = 1040, 176  # packed N = 8*C = 1408 = 5.5 tiles of 256
+    x, w, b = _r((M, 384), g), _r((8 * C, 384), g, 1 / math.sqrt(384)), _r((8 * C,), g)
+    p = (x.float() @ w.float().t() + b.float()).half().float()
+    hid, gate = p.chunk(2, dim=-1)
+    ref = hid * F.gelu(gate).half().float()
+    wp, bp = pack_geglu(w, b)
+    try:
+        assert lib.ds_set_option(b"gemm_variant", 3) == 0
+        got = ops.gemm(x.to(DEV), wp.to(DEV), bp.to(DEV), geglu=True)
+    finally:
+        lib.ds_set_option(b"gemm_variant", 0)
+    _close(got, ref, what="pingpong geglu")
+    # auto dispatch: 32 x 40 tiles = 5 full rounds -> ping-pong; results must not depend on the choice
+    x2, w2 = _r((8192, 1280), g), _r((10240, 1280), g, 1 / math.sqrt(1280))
+    auto = ops.gemm(x2.to(DEV), w2.to(DEV))
+    try:
+        lib.ds_set_option(b"gemm_variant", 8)
+        forced = ops.gemm(x2.to(DEV), w2.to(DEV))
+    finally:
+        lib.ds_set_option(b"gemm_variant", 0)
+    assert torch.equal(auto, forced)
+    _close(auto, x2.float() @ w2.float().t(), what="auto dispatch")
+
+
 @pytest.mark.parametrize("M,C", [(256, 128), (2048, 640), (777, 256)])
 def test_gemm_geglu(hip_lib, M, C):
     from diffsensei_amd.engine import pack_geglu
