@@ -44,7 +44,7 @@ int ds_device_info(int* cu_count, int* lds_bytes, char* arch_name, int arch_name
 int ds_set_option(const char* key, int value) {
     DS_REQUIRE(key != nullptr, "ds_set_option: null key");
     if (strcmp(key, "gemm_variant") == 0) {
-        DS_REQUIRE(value >= 0 && value <= 9, "gemm_variant must be 0..9");
+        DS_REQUIRE(value >= 0 && value <= 10, "gemm_variant must be 0..10");
         ds_gemm_set_variant(value);
         return 0;
     }
@@ -327,6 +327,7 @@ int ds_op_describe(const ds_op* op, char* name, int name_len, double* flops, dou
             const int Wo = i[6] ? 2 * i[2] : (i[5] == 2 ? (i[2] + 1) / 2 : i[2]);
             g.M = i[0] * Ho * Wo; g.N = i[4]; g.K = 9 * i[3];
             g.conv = 1;
+            g.Hin = i[1]; g.Win = i[2]; g.Cin = i[3]; g.Hout = Ho; g.Wout = Wo; g.cstride = i[5]; g.upsample = i[6];
             nm = ds_gemm_kernel_name(g, 1);
             fl = 2.0 * g.M * (double)g.N * g.K;
             by = 2.0 * ((double)i[0] * i[1] * i[2] * i[3] + (double)g.N * g.K + (double)g.M * g.N);

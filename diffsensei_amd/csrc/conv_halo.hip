@@ -1,0 +1,230 @@
+// 3x3 convolution (stride 1, optional fused nearest x2 upsample) over NHWC f16 activations as an implicit GEMM whose
+// A operand is staged ONCE per 64-channel slice: the large-resolution path of ds_launch_gemm's conv mode
+// (ResnetBlock2D conv1/conv2 and Upsample2D.conv on the DiffSensei UNet path, reference src/models/unet.py:244-338 ->
+// diffusers blocks; same GemmParams / epilogue semantics as gemm.hip's conv instantiation).
+//
+// Why.  gemm.hip's conv kernel re-gathers the 64 x 64-channel A tile from L2 for each of the 9 taps; its 64 x 128 tile
+// then moves 24 KiB per 1 MFLOP through L2 -> LDS and sits on that path's limit (~38 B/clk/CU, ~650 TFLOP/s).  Here
+// a block owns an 8 x 16 patch of output pixels (M tile = 128) x 128 output channels, and per channel slice it
+// loads the 10 x 18 halo patch (180 pixels x 128 B = 22.5 KiB) once; the nine taps then read their A fragments from
+// that patch at a uniform row shift (ky*18 + kx).  Per slice: 22.5 KiB of A + 9 x 16 KiB of W for 18.9 MFLOP =
+// 113 flop/B instead of 43.  LDS: patch 24 KiB + one W tile 16 KiB = 40 KiB -> the three independent blocks per CU that
+// the 128 x 128 GEMM relies on (gemm.hip, STAGES = 1 schedule: wait, barrier, all fragments to registers, barrier,
+// refill the single W buffer under the 16 MFMAs).
+//
+// The patch is written by LDS-DMA (lane-linear destination), so it is dense [row][64 ch] with the same XOR swizzle as
+// every other tile (16-byte chunk c of row q at slot c ^ ((q>>1)&7)); because the tap shift changes q per lane, the
+// reader rebuilds its swizzle per tap: base = q*128 + ((lhi ^ (q>>1)&7) << 4), k-step kk at base ^ (kk << 5).
+// Halo pixels outside the image come from a zero page.  With upsample the patch is gathered from input pixel
+// (uy>>1, ux>>1): the upsampled tensor never exists.
+//
+// K order: channel slices outer, taps inner (k = tap*Cin + ci in the weight rows) - the sum is the same set of
+// products as the tap-major kernel's, in a different order, so results agree to fp32-accumulation rounding.
+#include "ds_common.h"
+#include "ds_kernels.h"
+
+namespace {
+
+constexpr int PH = 8, PW = 16;            // output pixels per block: 8 rows x 16 columns = 128 GEMM rows
+constexpr int HWD = PW + 2;               // halo patch width
+constexpr int HROWS = (PH + 2) * HWD;     // 180 patch pixels
+constexpr int PROWS = 192;                // staged rows (24 LDS-DMA pieces of 8 rows)
+constexpr int BN = 128;
+constexpr int CS_STRIDE = 272;            // bytes per row of the epilogue staging tile (128 f16 + 8 pad)
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+__device__ __attribute__((aligned(256))) char g_halo_zero_page[256];
+
+__device__ __forceinline__ int swz(int row, int chunk) { return ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+__global__ __launch_bounds__(256, 3) void conv_halo_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const sP = smem;
+    char* const sW = smem + PROWS * 128;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int lrow = lane >> 3, slot = lane & 7;
+
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    int tm, tn;
+    tile_coords(tile, p.tiles_m, p.tiles_n, tm, tn);
+    const int tiles_x = p.Wout / PW, tiles_y = p.Hout / PH;
+    const int tx = tm % tiles_x, ty = (tm / tiles_x) % tiles_y, b = tm / (tiles_x * tiles_y);
+    const int oy0 = ty * PH, ox0 = tx * PW, n0 = tn * BN;
+
+    // ---- patch descriptors: this wave stages patch rows (6w + j) * 8 + lrow, j < 6
+    int poff[6];  // element offset of the lane's 16-byte chunk at channel 0, or -1: zero page (halo / pad rows)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int q = (wave * 6 + j) * 8 + lrow;
+        const int qy = q / HWD, qx = q - qy * HWD;
+        const int uy = oy0 - 1 + qy, ux = ox0 - 1 + qx;  // output-resolution pixel
+        const bool ok = (q < HROWS) & (uy >= 0) & (uy < p.Hout) & (ux >= 0) & (ux < p.Wout);
+        const int iy = p.upsample ? uy >> 1 : uy, ix = p.upsample ? ux >> 1 : ux;
+        const int chunk = slot ^ ((q >> 1) & 7);
+        poff[j] = ok ? ((b * p.Hin + iy) * p.Win + ix) * p.Cin + chunk * 8 : -1;
+    }
+    int woff[4];  // element offset of the lane's chunk in the weight matrix at k = 0 (Cout * 9 * Cin < 2^31)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = (wave * 4 + j) * 8 + lrow;
+        const int chunk = slot ^ ((row >> 1) & 7);
+        const int n = min(n0 + row, p.N - 1);
+        woff[j] = n * (int)p.ldw + chunk * 8;
+    }
+    auto issue_patch = [&](int ci0) {
+        char* d = sP + wave * 6 * 1024;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const void* src = poff[j] >= 0 ? (const void*)(p.A + poff[j] + ci0) : (const void*)g_halo_zero_page;
+            __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(d + j * 1024), 16, 0, 0);
+        }
+    };
+    auto issue_w = [&](int k0) {
+        char* d = sW + wave * 4 * 1024;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_global_load_lds((glb_void*)(p.W + k0 + woff[j]), (lds_void*)(d + j * 1024), 16, 0, 0);
+    };
+
+    // ---- A fragment rows: GEMM row r = 64 wm + 32 mi + l31  <->  patch pixel (r >> 4, r & 15), tap (0,0) at q0
+    int q0[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) q0[mi] = (wm * 4 + mi * 2 + (l31 >> 4)) * HWD + (l31 & 15);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int slices = p.Cin / 64;
+    issue_patch(0);
+    issue_w(0);
+    for (int s = 0; s < slices; ++s) {
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            const int shift = ky * HWD + kx;
+            h8 af[4][2], bf[4][2];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const int q = q0[mi] + shift;
+                const int base = q * 128 + ((lhi ^ ((q >> 1) & 7)) << 4);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) af[kk][mi] = *reinterpret_cast<const h8*>(sP + (base ^ (kk << 5)));
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const int r = wn * 64 + ni * 32 + l31;
+                    bf[kk][ni] = *reinterpret_cast<const h8*>(sW + r * 128 + swz(r, kk * 2 + lhi));
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const bool last = (s + 1 == slices) & (tap == 8);
+            if (!last) {  // the W buffer (and after tap 8 the patch) is drained once everyone holds its fragments
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (tap == 8) {
+                    issue_patch((s + 1) * 64);
+                    issue_w((s + 1) * 64);
+                } else {
+                    issue_w((tap + 1) * p.Cin + s * 64);
+                }
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[kk][ni], af[kk][mi], acc[mi][ni], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+
+    // ---- epilogue: bias (+ per-image bias), round to f16, park the 128 x 128 tile in LDS, then whole 16-byte pieces
+    // of output rows (+ residual).  D layout (operands swapped): lane holds row ..+(lane&31); register r is column
+    // (r&3) + 8*(r>>2) + 4*(lane>>5) of its 32-column fragment.
+    char* const sC = smem;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int ms = wm * 64 + mi * 32 + l31;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int nl = wn * 64 + ni * 32 + 8 * g + 4 * lhi;
+                const int n = n0 + nl;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][4 * g + e];
+                if (n < p.N) {
+                    if (p.bias) {
+                        const h4 bv = *reinterpret_cast<const h4*>(p.bias + n);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += (float)bv[e];
+                    }
+                    if (p.rowbias) {
+                        const h4 bv = *reinterpret_cast<const h4*>(p.rowbias + (long)b * p.rowbias_ld + n);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += (float)bv[e];
+                    }
+                }
+                h4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (half_t)v[e];
+                *reinterpret_cast<h4*>(sC + ms * CS_STRIDE + nl * 2) = o;
+            }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int id = tid + 256 * j;
+        const int row = id >> 4, c = id & 15;
+        const long m = ((long)b * p.Hout + oy0 + (row >> 4)) * p.Wout + ox0 + (row & 15);
+        const int n = n0 + c * 8;
+        if (n < p.N) {
+            h8 v = *reinterpret_cast<const h8*>(sC + row * CS_STRIDE + c * 16);
+            if (p.residual) {
+                const h8 rv = *reinterpret_cast<const h8*>(p.residual + m * p.ldr + n);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rv[e]);
+            }
+            *reinterpret_cast<h8*>(p.C + m * p.ldc + n) = v;
+        }
+    }
+}
+
+}  // namespace
+
+// Shapes the kernel takes: stride 1 (optionally the fused x2 upsample), output height % 8 == 0 and width % 16 == 0,
+// Cin % 64 == 0, plain epilogue, and an input small enough for 32-bit element offsets.
+bool ds_conv_halo_applicable(const GemmParams& p) {
+    if (!p.conv || p.cstride != 1 || p.epi != EPI_NONE || p.Hout <= 0 || p.Wout <= 0) return false;
+    if (p.Hout % PH != 0 || p.Wout % PW != 0 || p.Cin % 64 != 0 || p.N % 8 != 0) return false;
+    const long batch = p.M / ((long)p.Hout * p.Wout);
+    return batch * p.Hin * p.Win * p.Cin < (1L << 31);
+}
+
+int ds_launch_conv_halo(const GemmParams& p0, hipStream_t stream) {
+    GemmParams p = p0;
+    DS_REQUIRE(ds_conv_halo_applicable(p), "conv_halo: shape not supported");
+    const int batch = p.M / (p.Hout * p.Wout);
+    p.tiles_m = batch * (p.Hout / PH) * (p.Wout / PW);
+    p.tiles_n = (p.N + BN - 1) / BN;
+    const size_t lds = PROWS * 128 + BN * 128;  // 40 KiB; the 128 x 272 B epilogue tile fits inside
+    dim3 grid(p.tiles_m * p.tiles_n);
+    hipLaunchKernelGGL(conv_halo_kernel, grid, dim3(256), lds, stream, p);
+    DS_LAUNCH_CHECK();
+    return 0;
+}

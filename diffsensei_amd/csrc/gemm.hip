@@ -994,7 +994,7 @@ int launch_ws(const GemmParams& p0, int batch, hipStream_t stream) {
     return 0;
 }
 
-enum Kind { K_REG, K_GLDS2, K_GLDS1, K_RING, K_WS, K_PP };
+enum Kind { K_REG, K_GLDS2, K_GLDS1, K_RING, K_WS, K_PP, K_HALO };
 struct Choice {
     Kind kind;
     int bm;   // rows of the block tile (K_WS: BNT)
@@ -1016,6 +1016,12 @@ Choice choose(const GemmParams& p, int batch) {
     c.bm = small ? 64 : 128;
     if (!dma_ok || g_gemm_variant == 1) {
         c.kind = K_REG;
+        return c;
+    }
+    // stride-1 3x3 convolution on 8 x 16 pixel patches: A staged once per channel slice (conv_halo.hip)
+    if (conv && (g_gemm_variant == 0 || g_gemm_variant == 10) && ds_conv_halo_applicable(p)) {
+        c.kind = K_HALO;
+        c.bm = 128;
         return c;
     }
     switch (g_gemm_variant) {
@@ -1074,6 +1080,7 @@ const char* ds_gemm_kernel_name(const GemmParams& p, int batch) {
     const bool conv = p.conv != 0;
     switch (c.kind) {
         case K_PP: return "gemm_pp_kernel<0>";
+        case K_HALO: return "conv_halo_kernel";
         case K_WS:
             if (c.bm == 256) return conv ? "gemm_ws_kernel<256,true>" : "gemm_ws_kernel<256,false>";
             return conv ? "gemm_ws_kernel<128,true>" : "gemm_ws_kernel<128,false>";
@@ -1109,6 +1116,7 @@ int ds_launch_gemm(const GemmParams& p_in, int batch, hipStream_t stream) {
     const Choice c = choose(p, batch);
     switch (c.kind) {
         case K_PP: return ds_launch_gemm_pp(p, batch, stream);
+        case K_HALO: return ds_launch_conv_halo(p, stream);
         case K_WS:
             if (c.bm == 256) return conv ? launch_ws<256, true>(p, batch, stream) : launch_ws<256, false>(p, batch, stream);
             return conv ? launch_ws<128, true>(p, batch, stream) : launch_ws<128, false>(p, batch, stream);
