@@ -346,7 +346,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float hq = (float)(half_t)hv[e], gq = (float)(half_t)gv[e];
-                        o[e] = (half_t)(hq * (float)(half_t)ds_gelu_erf(gq));
+                        if constexpr ((DBG & 64) != 0) o[e] = (half_t)(hq * gq);  // ablation: no erf
+                        else o[e] = (half_t)(hq * (float)(half_t)ds_gelu_erf(gq));
                     }
                     // 64-byte rows: chunk (c>>3) of row l31 sits at slot chunk ^ ((row>>2)&3)
                     *reinterpret_cast<h4*>(ep + l31 * 64 + ((((c >> 3) ^ (l31 >> 2)) & 3) << 4) + ((c >> 2) & 1) * 8) = o;
@@ -452,7 +453,7 @@ int ds_launch_gemm_pp(const GemmParams& p0, int batch, hipStream_t stream) {
         {0, gemm_pp_kernel<0>},   {1, gemm_pp_kernel<1>},   {2, gemm_pp_kernel<2>},   {3, gemm_pp_kernel<3>},
         {4, gemm_pp_kernel<4>},   {6, gemm_pp_kernel<6>},   {8, gemm_pp_kernel<8>},   {16, gemm_pp_kernel<16>},
         {17, gemm_pp_kernel<17>}, {18, gemm_pp_kernel<18>}, {20, gemm_pp_kernel<20>}, {22, gemm_pp_kernel<22>},
-        {24, gemm_pp_kernel<24>}, {48, gemm_pp_kernel<48>}, {49, gemm_pp_kernel<49>}};
+        {24, gemm_pp_kernel<24>}, {48, gemm_pp_kernel<48>}, {49, gemm_pp_kernel<49>}, {64, gemm_pp_kernel<64>}};
     if (g_pp_blocks == 0) {
         for (const auto& e : table)
             DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(e.k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -465,7 +466,7 @@ int ds_launch_gemm_pp(const GemmParams& p0, int batch, hipStream_t stream) {
     dim3 grid(tiles < g_pp_blocks ? tiles : g_pp_blocks, 1, batch);
     kern_t kern = nullptr;
     for (const auto& e : table)
-        if (e.dbg == (p.debug & 63)) kern = e.k;
+        if (e.dbg == (p.debug & 127)) kern = e.k;
     DS_REQUIRE(kern != nullptr, "gemm_pp: no ablation build for gemm_debug=%d", p.debug);
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, p);
     DS_LAUNCH_CHECK();
