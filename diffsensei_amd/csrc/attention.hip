@@ -30,6 +30,11 @@ constexpr float NEG_BIG = -1.0e30f;
 
 __device__ __forceinline__ int swz(int row, int chunk) { return ((chunk ^ ((row >> 1) & 7)) << 4); }
 
+// 2^x as ONE v_exp_f32.  exp2f() adds a denormal-range rescue (compare, select, ldexp: five more VALU slots per score);
+// softmax arguments are <= 0 and anything below 2^-126 may flush to zero.  The softmax of the flash kernels is VALU
+// bound (32 scores per lane per 16 MFMAs), so every slot per score shows up in the kernel time.
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 __device__ __forceinline__ h8 pack8(const f32x16& s, int base) {
     h8 o;
 #pragma unroll
@@ -130,12 +135,16 @@ __global__ __launch_bounds__(256, 2) void self_attn_kernel(const SelfAttnParams 
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
             if (ragged) {
+                // keep this a (rarely taken) branch: if-converted or hoisted it costs up to 4 VALU slots per score
+                int nk_here = p.Nk;
+                asm volatile("" : "+s"(nk_here)::"memory");
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int key = t * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                        if (key >= p.Nk) st[qb][kb][r] = NEG_BIG;
+                        if (key >= nk_here) st[qb][kb][r] = NEG_BIG;
+                        asm volatile("" : "+v"(st[qb][kb][r]));  // pins the select inside the branch
                     }
             }
             float mloc = NEG_BIG;
@@ -145,23 +154,34 @@ __global__ __launch_bounds__(256, 2) void self_attn_kernel(const SelfAttnParams 
                 for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, st[qb][kb][r]);
             mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
             const float m_new = fmaxf(m_run[qb], mloc);
-            const float alpha = exp2f((m_run[qb] - m_new) * c);
+            const float alpha = fast_exp2((m_run[qb] - m_new) * c);
+            const bool moved = __builtin_amdgcn_ballot_w64(m_new != m_run[qb]) != 0;  // wave-uniform
             m_run[qb] = m_new;
             const float mc = m_new * c;
-            float psum = 0.f;
+            // two scores per VALU slot where the ISA allows it: v_pk_fma_f32 for the scale-and-shift, v_pk_add_f32
+            // for the row sum (the exponential itself has no packed form)
+            f32x2 psum2 = {0.f, 0.f};
+            const f32x2 c2 = {c, c}, mc2 = {-mc, -mc};
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float e = exp2f(fmaf(st[qb][kb][r], c, -mc));
-                    st[qb][kb][r] = e;
-                    psum += e;
+                for (int r = 0; r < 16; r += 2) {
+                    f32x2 v = {st[qb][kb][r], st[qb][kb][r + 1]};
+                    v = __builtin_elementwise_fma(v, c2, mc2);
+                    f32x2 e = {fast_exp2(v[0]), fast_exp2(v[1])};
+                    st[qb][kb][r] = e[0];
+                    st[qb][kb][r + 1] = e[1];
+                    psum2 += e;
                 }
+            const float psum = psum2[0] + psum2[1];
             l_part[qb] = fmaf(l_part[qb], alpha, psum);
+            if (moved) {  // once the running maxima have settled (a few tiles in) alpha == 1 on every lane
+                asm volatile("" ::: "memory");
 #pragma unroll
-            for (int d = 0; d < 2; ++d)
+                for (int d = 0; d < 2; ++d)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) ot[qb][d][r] *= alpha;
+                    for (int r = 0; r < 16; ++r) ot[qb][d][r] *= alpha;
+            }
         }
         // ---- O^T += V^T P^T  (each V^T fragment feeds QB MFMAs)
 #pragma unroll
@@ -357,7 +377,7 @@ __global__ __launch_bounds__(256, 2) void ip_attn_kernel(const IPAttnParams p, i
             for (int kb = 0; kb < 3; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float e = exp2f((st[kb][r] - mloc) * LOG2E);
+                    const float e = fast_exp2((st[kb][r] - mloc) * LOG2E);
                     st[kb][r] = e;
                     psum += e;
                 }

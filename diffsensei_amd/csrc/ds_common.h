@@ -10,6 +10,7 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define DS_WAVE 64
 
