@@ -171,7 +171,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--num-samples", type=int, default=int(os.environ.get("DS_BENCH_NUM_SAMPLES", "8")))
+    ap.add_argument("--num-samples", type=int, default=int(os.environ.get("DS_BENCH_NUM_SAMPLES", "16")))
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")

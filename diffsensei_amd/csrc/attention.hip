@@ -356,37 +356,80 @@ __global__ __launch_bounds__(256, 2) void ip_attn_kernel(const IPAttnParams p, i
                     st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[kk], st[kb], 0, 0, 0);
                 }
             }
-            // scale, additive region mask (-10000, like the reference), padding keys removed.  `open[kb]` holds one bit
-            // per key of the 32-key block: attendable for THIS query row (IP part), or simply key < L (text part).
+            // scale + additive region mask (-10000, like the reference) + padding keys removed, then softmax.  The whole
+            // core is VALU bound (192 scores per query row against 48 MFMAs), so the per-score work is kept to packed
+            // fp32 ops: s = fma(raw, scale, bias) with a per-REGISTER bias.  Register r of key block kb is key
+            // 32 kb + (r&3) + 8 (r>>2) + 4 lhi, i.e. 16-key group 2 kb + (r>>3) on every lane; when the dummy / per-
+            // character token counts are multiples of 16 (the model's: 16 / 16) a group is open or closed as a whole
+            // and six per-lane biases replace 96 bit tests.  Unmasked scores are bit-identical to raw*scale.
+            const bool grouped = (p.n_dummy % 16 == 0) && (p.tok_per_ip % 16 == 0) && L > 64;
             float mloc = NEG_BIG;
+            if (grouped) {
+                float gb[6];
 #pragma unroll
-            for (int kb = 0; kb < 3; ++kb)
+                for (int g = 0; g < 6; ++g)
+                    gb[g] = (part && !((open_ip[g >> 1] >> ((g & 1) * 16)) & 1u)) ? -10000.0f : 0.0f;
+                const f32x2 sc2 = {p.qk_scale, p.qk_scale};
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int kbit = (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                    const int key = kb * 32 + kbit;
-                    float s = st[kb][r] * p.qk_scale;
-                    if (part && !((open_ip[kb] >> kbit) & 1u)) s += -10000.0f;
-                    if (key >= L) s = NEG_BIG;
-                    st[kb][r] = s;
-                    mloc = fmaxf(mloc, s);
-                }
+                for (int kb = 0; kb < 3; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const float g = gb[kb * 2 + (r >> 3)];
+                        f32x2 v = {st[kb][r], st[kb][r + 1]};
+                        v = __builtin_elementwise_fma(v, sc2, (f32x2){g, g});
+                        if (kb == 2) {  // only the last block holds padding keys (L > 64)
+                            const int key = 64 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                            if (key >= L) v[0] = NEG_BIG;
+                            if (key + 1 >= L) v[1] = NEG_BIG;
+                        }
+                        st[kb][r] = v[0];
+                        st[kb][r + 1] = v[1];
+                        mloc = fmaxf(mloc, fmaxf(v[0], v[1]));
+                    }
+            } else {
+#pragma unroll
+                for (int kb = 0; kb < 3; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int kbit = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                        const int key = kb * 32 + kbit;
+                        float sv = fmaf(st[kb][r], p.qk_scale, (part && !((open_ip[kb] >> kbit) & 1u)) ? -10000.0f : 0.0f);
+                        if (key >= L) sv = NEG_BIG;
+                        st[kb][r] = sv;
+                        mloc = fmaxf(mloc, sv);
+                    }
+            }
             mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-            float psum = 0.f;
+            f32x2 psum2 = {0.f, 0.f};
+            {
+                const f32x2 l2 = {LOG2E, LOG2E}, m2 = {-mloc * LOG2E, -mloc * LOG2E};
 #pragma unroll
-            for (int kb = 0; kb < 3; ++kb)
+                for (int kb = 0; kb < 3; ++kb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float e = fast_exp2((st[kb][r] - mloc) * LOG2E);
-                    st[kb][r] = e;
-                    psum += e;
-                }
+                    for (int r = 0; r < 16; r += 2) {
+                        f32x2 v = {st[kb][r], st[kb][r + 1]};
+                        v = __builtin_elementwise_fma(v, l2, m2);
+                        const f32x2 e = {fast_exp2(v[0]), fast_exp2(v[1])};
+                        st[kb][r] = e[0];
+                        st[kb][r + 1] = e[1];
+                        psum2 += e;
+                    }
+            }
+            float psum = psum2[0] + psum2[1];
             psum += __shfl_xor(psum, 32, 64);
             const float w = (part ? ip_scale : 1.0f) / psum;
+            {
+                const f32x2 w2 = {w, w};
 #pragma unroll
-            for (int kb = 0; kb < 3; ++kb)
+                for (int kb = 0; kb < 3; ++kb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) st[kb][r] *= w;
+                    for (int r = 0; r < 16; r += 2) {
+                        f32x2 v = {st[kb][r], st[kb][r + 1]};
+                        v *= w2;
+                        st[kb][r] = v[0];
+                        st[kb][r + 1] = v[1];
+                    }
+            }
             // O^T += V^T P^T
 #pragma unroll
             for (int kb = 0; kb < 3; ++kb)

@@ -1063,7 +1063,7 @@ Choice choose(const GemmParams& p, int batch) {
         if (batch == 1 && ds_gemm_pp_applicable(p)) {
             const long t = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
             const long rounds = (t + 255) / 256;
-            const bool fills = t >= 512 && t * 10 >= rounds * 256 * 8;
+            const bool fills = t >= 410 && t * 10 >= rounds * 256 * 8;
             if (fills && !(p.N <= 640 && p.K <= 640)) {
                 c.kind = K_PP;
                 c.bm = 256;
