@@ -227,6 +227,16 @@ def main():
                     "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None, "kernel": name,
                     "launches_per_forward": d["launches"], "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 2),
                     "algorithmic_tflop_per_forward": round(d["flops"] / 1e12, 3)}
+        # HBM-side traffic comes from separate rocprofv3 --pmc passes (tools/gpu_pmc_pp.sh), committed under profiles/:
+        # it cannot be collected inside this process.  Attached only when it was measured for this very kernel.
+        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_gemm_pp.json")
+        if os.path.exists(pmc_path):
+            pmc = json.load(open(pmc_path))
+            if pmc.get("kernel") == name:
+                roofline["traffic"] = pmc["traffic_bytes_per_launch"]
+                roofline["traffic_detail"] = {"unit": "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, L2 fabric side)",
+                                              "launch": pmc["shape"], "algorithmic_bytes": pmc["algorithmic_bytes_per_launch"],
+                                              "l2_hit_rate": pmc["l2_hit_rate"], "source": "profiles/r01_pmc_gemm_pp.json"}
         tot_fl = sum(v["flops"] for v in table.values())
         extra = {"unet_forward_ms_event_sum": round(fwd_ms, 3),
                  "unet_forward_algorithmic_tflop": round(tot_fl / 1e12, 2),

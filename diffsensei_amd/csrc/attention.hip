@@ -276,6 +276,16 @@ __global__ __launch_bounds__(256, 2) void ip_attn_kernel(const IPAttnParams p, i
     const int l31 = lane & 31, lhi = lane >> 5;
     const int b = blockIdx.y / p.heads, h = blockIdx.y % p.heads;
 
+    // Q fragments (B operand of S^T) are fetched one query tile ahead: the kernel runs two waves per SIMD, too few to
+    // hide a global-load round trip inside the tile loop, and the first tile's rows are requested before the panels.
+    h8 qn[4];
+    auto load_q = [&](int it) {
+        const int qrow = min((int)(blockIdx.x * qt + it) * 128 + wave * 32 + l31, p.N - 1);
+        const half_t* qp = p.q + ((long)b * p.N + qrow) * p.ldq + h * 64 + lhi * 8;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) qn[kk] = *reinterpret_cast<const h8*>(qp + kk * 16);
+    };
+    load_q(0);
     // ---- stage the four panels once
     {
         const half_t* ktp = p.kt + (long)b * p.sk + h * 64;
@@ -312,10 +322,10 @@ __global__ __launch_bounds__(256, 2) void ip_attn_kernel(const IPAttnParams p, i
         const int q0 = (blockIdx.x * qt + it) * 128 + wave * 32;
         if (q0 >= p.N) break;  // wave-uniform
         const int qidx = min(q0 + l31, p.N - 1);
-        const half_t* qp = p.q + ((long)b * p.N + qidx) * p.ldq + h * 64 + lhi * 8;
         h8 qf[4];
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) qf[kk] = *reinterpret_cast<const h8*>(qp + kk * 16);
+        for (int kk = 0; kk < 4; ++kk) qf[kk] = qn[kk];
+        if (it + 1 < qt) load_q(it + 1);  // next tile's Q rows land under this tile's MFMAs / softmax
         const unsigned inside = region_flags(bbox_b, p.max_ips, qidx, p.mask_h, p.mask_w);
         // 96-bit "attendable IP key" set of this query row: dummy keys [0, n_dummy) iff the token lies in NO box,
         // character k's keys [n_dummy + k*tpi, +tpi) iff it lies in box k  (reference :155-163)
