@@ -27,6 +27,11 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hooks (a 1-GPU box can still drive the N > 1 control flow): DS_DIST_BACKEND overrides the backend (gloo moves
+    # CUDA tensors through the host), DS_FORCE_DEVICE pins every rank to one device index
+    backend = os.environ.get("DS_DIST_BACKEND", backend)
+    if "DS_FORCE_DEVICE" in os.environ:
+        local = int(os.environ["DS_FORCE_DEVICE"])
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
