@@ -84,7 +84,7 @@ int ds_gemm_f16_batched(const void* x, int64_t ldx, int64_t sx, const void* w, i
 
 static int conv3x3_impl(const void* x, const void* w, const void* bias, const void* rowbias, int64_t rowbias_ld,
                         const void* residual, void* y, int B, int H_, int W_, int Cin, int Cout, int stride,
-                        int upsample, hipStream_t stream) {
+                        int upsample, hipStream_t stream, int dtype = DS_DTYPE_F16) {
     DS_REQUIRE(stride == 1 || stride == 2, "conv3x3: stride must be 1 or 2");
     DS_REQUIRE(!(upsample && stride != 1), "conv3x3: upsample with stride 2 is not a thing");
     GemmParams p;
@@ -96,6 +96,7 @@ static int conv3x3_impl(const void* x, const void* w, const void* bias, const vo
     p.Wout = upsample ? 2 * W_ : (stride == 2 ? (W_ + 1) / 2 : W_);
     p.M = B * p.Hout * p.Wout; p.N = Cout; p.K = 9 * Cin; p.K1 = p.K;
     p.rows_per_group = p.Hout * p.Wout;
+    p.dtype = dtype;
     return ds_launch_gemm(p, 1, stream);
 }
 
@@ -103,6 +104,51 @@ int ds_conv3x3_f16(const void* x, const void* w, const void* bias, const void* r
                    const void* residual, void* y, int B, int H_, int W_, int Cin, int Cout, int stride, int upsample,
                    void* stream) {
     return conv3x3_impl(x, w, bias, rowbias, rowbias_ld, residual, y, B, H_, W_, Cin, Cout, stride, upsample, S(stream));
+}
+
+// ---- bf16 entry points: the VAE decoder (fp16 overflows there; the reference runs it in fp32) ----------------------
+int ds_conv3x3_bf16(const void* x, const void* w, const void* bias, const void* residual, void* y, int B, int H_,
+                    int W_, int Cin, int Cout, int upsample, void* stream) {
+    return conv3x3_impl(x, w, bias, nullptr, 0, residual, y, B, H_, W_, Cin, Cout, 1, upsample, S(stream), DS_DTYPE_BF16);
+}
+
+int ds_gemm_bf16(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias, const void* residual,
+                 int64_t ldr, void* y, int64_t ldy, int M, int N, int K, void* stream) {
+    GemmParams p;
+    p.A = H(x); p.lda = ldx; p.K1 = K; p.W = H(w); p.ldw = ldw; p.bias = H(bias); p.residual = H(residual); p.ldr = ldr;
+    p.C = HM(y); p.ldc = ldy; p.M = M; p.N = N; p.K = K; p.dtype = DS_DTYPE_BF16;
+    return ds_launch_gemm(p, 1, S(stream));
+}
+
+int ds_gemm_bf16_batched(const void* x, int64_t ldx, int64_t sx, const void* w, int64_t ldw, int64_t sw, void* y,
+                         int64_t ldy, int64_t sy, int M, int N, int K, int batch, void* stream) {
+    GemmParams p;
+    p.A = H(x); p.lda = ldx; p.sA = sx; p.K1 = K; p.W = H(w); p.ldw = ldw; p.sW = sw;
+    p.C = HM(y); p.ldc = ldy; p.sC = sy; p.M = M; p.N = N; p.K = K; p.dtype = DS_DTYPE_BF16;
+    return ds_launch_gemm(p, batch, S(stream));
+}
+
+int ds_groupnorm_bf16(const void* x, void* y, const void* gamma, const void* beta, void* ws, int B, int HW, int C,
+                      int groups, float eps, int silu, void* stream) {
+    GroupNormParams p;
+    p.x1 = H(x); p.y = HM(y); p.gamma = H(gamma); p.beta = H(beta); p.ws = reinterpret_cast<float*>(ws);
+    p.B = B; p.HW = HW; p.C1 = C; p.C2 = 0; p.groups = groups; p.eps = eps; p.silu = silu; p.dtype = DS_DTYPE_BF16;
+    return ds_launch_groupnorm(p, S(stream));
+}
+
+int ds_wide_attn_bf16(const void* q, const void* k, const void* vt, void* o, int B, int N, float scale, void* stream) {
+    return ds_launch_wide_attn(q, k, vt, o, B, N, DS_DTYPE_BF16, scale, S(stream));
+}
+
+int ds_vae_conv_in_bf16(const float* latents, const float* post_quant_w, const float* post_quant_b, const void* w,
+                        const void* bias, void* y, int B, int H_, int W_, int C, float scaling_factor, void* stream) {
+    return ds_launch_vae_conv_in(latents, post_quant_w, post_quant_b, w, bias, y, B, H_, W_, C, scaling_factor,
+                                 DS_DTYPE_BF16, S(stream));
+}
+
+int ds_vae_conv_out_bf16(const void* x, const void* w, const void* bias, float* image, int B, int H_, int W_, int C,
+                         int denormalize, void* stream) {
+    return ds_launch_vae_conv_out(x, w, bias, image, B, H_, W_, C, denormalize, DS_DTYPE_BF16, S(stream));
 }
 
 size_t ds_groupnorm_workspace_bytes(int B, int C) { return ds_groupnorm_ws_floats(B, C) * sizeof(float); }

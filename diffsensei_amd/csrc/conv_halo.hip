@@ -38,7 +38,10 @@ __device__ __attribute__((aligned(256))) char g_halo_zero_page[256];
 
 __device__ __forceinline__ int swz(int row, int chunk) { return ((chunk ^ ((row >> 1) & 7)) << 4); }
 
+template <typename T>  // half_t (UNet) or bf16_t (VAE decoder)
 __global__ __launch_bounds__(256, 3) void conv_halo_kernel(const GemmParams p) {
+    typedef typename Elt<T>::v8 V8;
+    typedef typename Elt<T>::v4 V4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const sP = smem;
     char* const sW = smem + PROWS * 128;
@@ -114,20 +117,20 @@ __global__ __launch_bounds__(256, 3) void conv_halo_kernel(const GemmParams p) {
             asm volatile("" ::: "memory");
             const int ky = tap / 3, kx = tap - 3 * ky;
             const int shift = ky * HWD + kx;
-            h8 af[4][2], bf[4][2];
+            V8 af[4][2], bf[4][2];
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) {
                 const int q = q0[mi] + shift;
                 const int base = q * 128 + ((lhi ^ ((q >> 1) & 7)) << 4);
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) af[kk][mi] = *reinterpret_cast<const h8*>(sP + (base ^ (kk << 5)));
+                for (int kk = 0; kk < 4; ++kk) af[kk][mi] = *reinterpret_cast<const V8*>(sP + (base ^ (kk << 5)));
             }
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) {
                     const int r = wn * 64 + ni * 32 + l31;
-                    bf[kk][ni] = *reinterpret_cast<const h8*>(sW + r * 128 + swz(r, kk * 2 + lhi));
+                    bf[kk][ni] = *reinterpret_cast<const V8*>(sW + r * 128 + swz(r, kk * 2 + lhi));
                 }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             const bool last = (s + 1 == slices) & (tap == 8);
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(256, 3) void conv_halo_kernel(const GemmParams p) {
                 for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < 2; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[kk][ni], af[kk][mi], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = Elt<T>::mfma(bf[kk][ni], af[kk][mi], acc[mi][ni]);
         }
     }
     __syncthreads();
@@ -170,20 +173,20 @@ __global__ __launch_bounds__(256, 3) void conv_halo_kernel(const GemmParams p) {
                 for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][4 * g + e];
                 if (n < p.N) {
                     if (p.bias) {
-                        const h4 bv = *reinterpret_cast<const h4*>(p.bias + n);
+                        const V4 bv = *reinterpret_cast<const V4*>(p.bias + n);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] += (float)bv[e];
                     }
                     if (p.rowbias) {
-                        const h4 bv = *reinterpret_cast<const h4*>(p.rowbias + (long)b * p.rowbias_ld + n);
+                        const V4 bv = *reinterpret_cast<const V4*>(p.rowbias + (long)b * p.rowbias_ld + n);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] += (float)bv[e];
                     }
                 }
-                h4 o;
+                V4 o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (half_t)v[e];
-                *reinterpret_cast<h4*>(sC + ms * CS_STRIDE + nl * 2) = o;
+                for (int e = 0; e < 4; ++e) o[e] = (T)v[e];
+                *reinterpret_cast<V4*>(sC + ms * CS_STRIDE + nl * 2) = o;
             }
     }
     __syncthreads();
@@ -194,13 +197,13 @@ __global__ __launch_bounds__(256, 3) void conv_halo_kernel(const GemmParams p) {
         const long m = ((long)b * p.Hout + oy0 + (row >> 4)) * p.Wout + ox0 + (row & 15);
         const int n = n0 + c * 8;
         if (n < p.N) {
-            h8 v = *reinterpret_cast<const h8*>(sC + row * CS_STRIDE + c * 16);
+            V8 v = *reinterpret_cast<const V8*>(sC + row * CS_STRIDE + c * 16);
             if (p.residual) {
-                const h8 rv = *reinterpret_cast<const h8*>(p.residual + m * p.ldr + n);
+                const V8 rv = *reinterpret_cast<const V8*>(p.residual + m * p.ldr + n);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rv[e]);
+                for (int e = 0; e < 8; ++e) v[e] = (T)((float)v[e] + (float)rv[e]);
             }
-            *reinterpret_cast<h8*>(p.C + m * p.ldc + n) = v;
+            *reinterpret_cast<V8*>(p.C + m * p.ldc + n) = v;
         }
     }
 }
@@ -224,7 +227,8 @@ int ds_launch_conv_halo(const GemmParams& p0, hipStream_t stream) {
     p.tiles_n = (p.N + BN - 1) / BN;
     const size_t lds = PROWS * 128 + BN * 128;  // 40 KiB; the 128 x 272 B epilogue tile fits inside
     dim3 grid(p.tiles_m * p.tiles_n);
-    hipLaunchKernelGGL(conv_halo_kernel, grid, dim3(256), lds, stream, p);
+    if (p.dtype == DS_DTYPE_BF16) hipLaunchKernelGGL(conv_halo_kernel<bf16_t>, grid, dim3(256), lds, stream, p);
+    else hipLaunchKernelGGL(conv_halo_kernel<half_t>, grid, dim3(256), lds, stream, p);
     DS_LAUNCH_CHECK();
     return 0;
 }

@@ -20,6 +20,7 @@ struct GemmParams {
     int conv = 0;
     int Hin = 0, Win = 0, Cin = 0, Hout = 0, Wout = 0, cstride = 1, upsample = 0;
     int tiles_m = 0, tiles_n = 0;
+    int dtype = DS_DTYPE_F16;  // element type of A / W / C / bias / residual (the pointers are 2-byte opaque): bf16 = VAE path
     int debug = 0;  // ablation only (ds_set_option "gemm_debug"): 1 skip MFMA, 2 skip tile loads — results are garbage
 };
 int ds_launch_gemm(const GemmParams& p, int batch, hipStream_t stream);
@@ -30,6 +31,14 @@ int ds_launch_conv_halo(const GemmParams& p, hipStream_t stream);
 const char* ds_gemm_kernel_name(const GemmParams& p, int batch);  // the instantiation ds_launch_gemm dispatches to
 void ds_gemm_set_debug(int v);
 void ds_gemm_set_variant(int v);  // 0 auto, 1 register staging only, 2 glds (BM <= 128), 3 glds, BM = 256 when large
+
+// ---- VAE decoder only (vae.hip) ---------------------------------------------------------------------
+int ds_launch_wide_attn(const void* q, const void* k, const void* vt, void* o, int B, int N, int dtype, float scale,
+                        hipStream_t stream);  // one head of dim 512: q,k,o [B,N,512]; vt [B,512,N]
+int ds_launch_vae_conv_in(const float* lat, const float* wpq, const float* bpq, const void* w, const void* bias, void* y,
+                          int B, int H, int W, int C, float scaling_factor, int dtype, hipStream_t stream);
+int ds_launch_vae_conv_out(const void* x, const void* w, const void* bias, float* img, int B, int H, int W, int C,
+                           int denorm, int dtype, hipStream_t stream);
 
 // ---- normalisation ---------------------------------------------------------------------------------
 struct GroupNormParams {
@@ -42,6 +51,7 @@ struct GroupNormParams {
     int B = 0, HW = 0, C1 = 0, C2 = 0, groups = 32;
     float eps = 1e-5f;
     int silu = 0;
+    int dtype = DS_DTYPE_F16;  // bf16: VAE decoder path (x, y, gamma, beta are 2-byte opaque pointers)
 };
 size_t ds_groupnorm_ws_floats(int B, int C);
 int ds_launch_groupnorm(const GroupNormParams& p, hipStream_t stream);

@@ -1113,7 +1113,16 @@ int ds_launch_gemm(const GemmParams& p_in, int batch, hipStream_t stream) {
         DS_REQUIRE(p.A2 == nullptr || (p.K1 % 64 == 0 && p.lda2 % 8 == 0), "gemm: split-A needs K1 %% 64 == 0");
     }
     if (p.epi == EPI_GEGLU) DS_REQUIRE(p.N % 128 == 0, "geglu: packed N (%d) must be a multiple of 128", p.N);
-    const Choice c = choose(p, batch);
+    Choice c = choose(p, batch);
+    if (p.dtype != DS_DTYPE_F16) {  // bf16 (VAE decoder): only the two kernels that are templated on the element type
+        if (conv) {
+            DS_REQUIRE(ds_conv_halo_applicable(p), "conv3x3 bf16: needs stride 1, H %% 8 == 0, W %% 16 == 0, Cin %% 64 == 0");
+            c.kind = K_HALO;
+        } else {
+            DS_REQUIRE(ds_gemm_pp_applicable(p), "gemm bf16: needs M, N %% 16 == 0 and K %% 128 == 0 (M=%d N=%d K=%d)", p.M, p.N, p.K);
+            c.kind = K_PP;
+        }
+    }
     switch (c.kind) {
         case K_PP: return ds_launch_gemm_pp(p, batch, stream);
         case K_HALO: return ds_launch_conv_halo(p, stream);

@@ -66,8 +66,10 @@ struct IC {
         if constexpr ((DBG & 8) == 0) __builtin_amdgcn_s_setprio(v); \
     } while (0)
 
-template <int DBG>  // ablation builds only: 1 = no MFMA, 2 = no tile loads, 4 = no fragment reads (garbage results), 8 = no s_setprio, 16 = clock probe written over C[0..15]; 0 in production
+template <typename T, int DBG>  // T: half_t (UNet) or bf16_t (VAE decoder).  DBG: ablation builds only: 1 = no MFMA, 2 = no tile loads, 4 = no fragment reads (garbage results), 8 = no s_setprio, 16 = clock probe written over C[0..15]; 0 in production
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
+    typedef typename Elt<T>::v8 V8;
+    typedef typename Elt<T>::v4 V4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -145,15 +147,15 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
         fB[kk] = 4 * HT + (wc * 32 + l31) * 128 + (((kk * 2 + lhi) ^ sw) << 4);
         asm volatile("" : "+v"(fA[kk]), "+v"(fB[kk]));  // keep the eight addresses resident: no VALU in the load phases
     }
-    h8 dummy = {};
+    V8 dummy = {};
     if constexpr ((DBG & 4) != 0) asm volatile("" : "+v"(dummy));
-    auto readA = [&](int half, int buf, int mi, int kk) -> h8 {
+    auto readA = [&](int half, int buf, int mi, int kk) -> V8 {
         if constexpr ((DBG & 4) != 0) return dummy;  // ablation: no fragment reads
-        return *reinterpret_cast<const h8*>(smem + fA[kk] + ((half * 2 + buf) * HT + mi * 4096));
+        return *reinterpret_cast<const V8*>(smem + fA[kk] + ((half * 2 + buf) * HT + mi * 4096));
     };
-    auto readB = [&](int half, int buf, int kk) -> h8 {
+    auto readB = [&](int half, int buf, int kk) -> V8 {
         if constexpr ((DBG & 4) != 0) return dummy;
-        return *reinterpret_cast<const h8*>(smem + fB[kk] + (half * 2 + buf) * HT);
+        return *reinterpret_cast<const V8*>(smem + fB[kk] + (half * 2 + buf) * HT);
     };
 
     // Counted wait: returns once every LDS-DMA older than the `n` newest half-tiles (2 instructions each) has landed.
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
         constexpr int B = decltype(bufc)::value;
         constexpr bool n1 = true, n2 = true;
         const int kt1 = min(kt + 1, nk - 1), kt2 = min(kt + 2, nk - 1);
-        h8 bl[4], br[4], a0[4][2], a1[4][2];
+        V8 bl[4], br[4], a0[4][2], a1[4][2];
         // ---------------- P1: B0 strip (first: retired before the barrier, see WAR above) + A0 rows
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) bl[kk] = readB(0, B, kk);
@@ -198,8 +200,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
         if constexpr (mma_on) {
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[kk], a0[kk][0], acc[0][0], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[kk], a0[kk][1], acc[1][0], 0, 0, 0);
+                acc[0][0] = Elt<T>::mfma(bl[kk], a0[kk][0], acc[0][0]);
+                acc[1][0] = Elt<T>::mfma(bl[kk], a0[kk][1], acc[1][0]);
             }
         }
         PP_PRIO(0);
@@ -216,8 +218,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
         if constexpr (mma_on) {
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(br[kk], a0[kk][0], acc[0][1], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(br[kk], a0[kk][1], acc[1][1], 0, 0, 0);
+                acc[0][1] = Elt<T>::mfma(br[kk], a0[kk][0], acc[0][1]);
+                acc[1][1] = Elt<T>::mfma(br[kk], a0[kk][1], acc[1][1]);
             }
         }
         PP_PRIO(0);
@@ -236,8 +238,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
         if constexpr (mma_on) {
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(br[kk], a1[kk][0], acc[2][1], 0, 0, 0);
-                acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(br[kk], a1[kk][1], acc[3][1], 0, 0, 0);
+                acc[2][1] = Elt<T>::mfma(br[kk], a1[kk][0], acc[2][1]);
+                acc[3][1] = Elt<T>::mfma(br[kk], a1[kk][1], acc[3][1]);
             }
         }
         PP_PRIO(0);
@@ -250,16 +252,16 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
         if constexpr (mma_on) {
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[kk], a1[kk][0], acc[2][0], 0, 0, 0);
-                acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[kk], a1[kk][1], acc[3][0], 0, 0, 0);
+                acc[2][0] = Elt<T>::mfma(bl[kk], a1[kk][0], acc[2][0]);
+                acc[3][0] = Elt<T>::mfma(bl[kk], a1[kk][1], acc[3][0]);
             }
         }
         PP_PRIO(0);
         PP_BARRIER();
     };
 
-    half_t* const Cg = p.C + bz * p.sC;
-    const half_t* const Rg = p.residual ? p.residual + bz * p.sR : nullptr;
+    T* const Cg = reinterpret_cast<T*>(p.C) + bz * p.sC;
+    const T* const Rg = p.residual ? reinterpret_cast<const T*>(p.residual) + bz * p.sR : nullptr;
     char* const ep = smem + 8 * HT + wave * 4096;  // wave-private transposition tile
 
     int id = tile_local;
@@ -329,35 +331,35 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
                     }
                     if (nw + c < p.N) {
                         if (p.bias) {
-                            const h4 b0 = *reinterpret_cast<const h4*>(p.bias + nw + c);
-                            const h4 b1 = *reinterpret_cast<const h4*>(p.bias + nw + 64 + c);
+                            const V4 b0 = *reinterpret_cast<const V4*>(p.bias + nw + c);
+                            const V4 b1 = *reinterpret_cast<const V4*>(p.bias + nw + 64 + c);
 #pragma unroll
                             for (int e = 0; e < 4; ++e) hv[e] += (float)b0[e], gv[e] += (float)b1[e];
                         }
                         if (p.rowbias) {
                             const half_t* rb = p.rowbias + (long)grp * p.rowbias_ld + nw + c;
-                            const h4 b0 = *reinterpret_cast<const h4*>(rb);
-                            const h4 b1 = *reinterpret_cast<const h4*>(rb + 64);
+                            const V4 b0 = *reinterpret_cast<const V4*>(rb);
+                            const V4 b1 = *reinterpret_cast<const V4*>(rb + 64);
 #pragma unroll
                             for (int e = 0; e < 4; ++e) hv[e] += (float)b0[e], gv[e] += (float)b1[e];
                         }
                     }
-                    h4 o;
+                    V4 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float hq = (float)(half_t)hv[e], gq = (float)(half_t)gv[e];
-                        if constexpr ((DBG & 64) != 0) o[e] = (half_t)(hq * gq);  // ablation: no erf
-                        else o[e] = (half_t)(hq * (float)(half_t)ds_gelu_erf(gq));
+                        const float hq = (float)(T)hv[e], gq = (float)(T)gv[e];
+                        if constexpr ((DBG & 64) != 0) o[e] = (T)(hq * gq);  // ablation: no erf
+                        else o[e] = (T)(hq * (float)(T)ds_gelu_erf(gq));
                     }
                     // 64-byte rows: chunk (c>>3) of row l31 sits at slot chunk ^ ((row>>2)&3)
-                    *reinterpret_cast<h4*>(ep + l31 * 64 + ((((c >> 3) ^ (l31 >> 2)) & 3) << 4) + ((c >> 2) & 1) * 8) = o;
+                    *reinterpret_cast<V4*>(ep + l31 * 64 + ((((c >> 3) ^ (l31 >> 2)) & 3) << 4) + ((c >> 2) & 1) * 8) = o;
                 }
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const int row = i * 16 + (lane_e >> 2), ch = lane_e & 3;
-                    const h8 v = *reinterpret_cast<const h8*>(ep + row * 64 + (((ch ^ (row >> 2)) & 3) << 4));
+                    const V8 v = *reinterpret_cast<const V8*>(ep + row * 64 + (((ch ^ (row >> 2)) & 3) << 4));
                     const int m = mb + row, n = no + ch * 8;
-                    if (m < p.M && n < (p.N >> 1)) *reinterpret_cast<h8*>(Cg + (long)m * p.ldc + n) = v;
+                    if (m < p.M && n < (p.N >> 1)) *reinterpret_cast<V8*>(Cg + (long)m * p.ldc + n) = v;
                 }
             }
         } else {
@@ -377,44 +379,44 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
                         for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][4 * g + e];
                         if (nw + c < p.N) {
                             if (p.bias) {
-                                const h4 bv = *reinterpret_cast<const h4*>(p.bias + nw + c);
+                                const V4 bv = *reinterpret_cast<const V4*>(p.bias + nw + c);
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) v[e] += (float)bv[e];
                             }
                             if (p.rowbias) {
-                                const h4 bv = *reinterpret_cast<const h4*>(p.rowbias + (long)grp * p.rowbias_ld + nw + c);
+                                const V4 bv = *reinterpret_cast<const V4*>(p.rowbias + (long)grp * p.rowbias_ld + nw + c);
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) v[e] += (float)bv[e];
                             }
                         }
-                        h4 o;
+                        V4 o;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = (half_t)v[e];
+                        for (int e = 0; e < 4; ++e) o[e] = (T)v[e];
                         // 128-byte rows: chunk (c>>3) of row l31 sits at slot chunk ^ ((row>>1)&7)
-                        *reinterpret_cast<h4*>(ep + l31 * 128 + ((((c >> 3) ^ (l31 >> 1)) & 7) << 4) + ((c >> 2) & 1) * 8) = o;
+                        *reinterpret_cast<V4*>(ep + l31 * 128 + ((((c >> 3) ^ (l31 >> 1)) & 7) << 4) + ((c >> 2) & 1) * 8) = o;
                     }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int row = i * 8 + (lane_e >> 3), ch = lane_e & 7;
-                    h8 v = *reinterpret_cast<const h8*>(ep + row * 128 + (((ch ^ (row >> 1)) & 7) << 4));
+                    V8 v = *reinterpret_cast<const V8*>(ep + row * 128 + (((ch ^ (row >> 1)) & 7) << 4));
                     const int m = mb + row, n = nw + ch * 8;
                     if (m < p.M && n < p.N) {
                         if (p.epi == EPI_GELU) {
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) v[e] = (half_t)ds_gelu_erf((float)v[e]);
+                            for (int e = 0; e < 8; ++e) v[e] = (T)ds_gelu_erf((float)v[e]);
                         } else if (p.epi == EPI_QUICK_GELU) {
 #pragma unroll
                             for (int e = 0; e < 8; ++e) {
                                 const float f = (float)v[e];
-                                v[e] = (half_t)(f / (1.0f + __expf(-1.702f * f)));
+                                v[e] = (T)(f / (1.0f + __expf(-1.702f * f)));
                             }
                         }
                         if (Rg) {
-                            const h8 rv = *reinterpret_cast<const h8*>(Rg + (long)m * p.ldr + n);
+                            const V8 rv = *reinterpret_cast<const V8*>(Rg + (long)m * p.ldr + n);
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rv[e]);
+                            for (int e = 0; e < 8; ++e) v[e] = (T)((float)v[e] + (float)rv[e]);
                         }
-                        *reinterpret_cast<h8*>(Cg + (long)m * p.ldc + n) = v;
+                        *reinterpret_cast<V8*>(Cg + (long)m * p.ldc + n) = v;
                     }
                 }
             }
@@ -450,10 +452,11 @@ int ds_launch_gemm_pp(const GemmParams& p0, int batch, hipStream_t stream) {
     const size_t lds = 8 * HT + 8 * 4096;
     typedef void (*kern_t)(const GemmParams);
     static const struct { int dbg; kern_t k; } table[] = {
-        {0, gemm_pp_kernel<0>},   {1, gemm_pp_kernel<1>},   {2, gemm_pp_kernel<2>},   {3, gemm_pp_kernel<3>},
-        {4, gemm_pp_kernel<4>},   {6, gemm_pp_kernel<6>},   {8, gemm_pp_kernel<8>},   {16, gemm_pp_kernel<16>},
-        {17, gemm_pp_kernel<17>}, {18, gemm_pp_kernel<18>}, {20, gemm_pp_kernel<20>}, {22, gemm_pp_kernel<22>},
-        {24, gemm_pp_kernel<24>}, {48, gemm_pp_kernel<48>}, {49, gemm_pp_kernel<49>}, {64, gemm_pp_kernel<64>}};
+        {0, gemm_pp_kernel<half_t, 0>},   {1, gemm_pp_kernel<half_t, 1>},   {2, gemm_pp_kernel<half_t, 2>},   {3, gemm_pp_kernel<half_t, 3>},
+        {4, gemm_pp_kernel<half_t, 4>},   {6, gemm_pp_kernel<half_t, 6>},   {8, gemm_pp_kernel<half_t, 8>},   {16, gemm_pp_kernel<half_t, 16>},
+        {17, gemm_pp_kernel<half_t, 17>}, {18, gemm_pp_kernel<half_t, 18>}, {20, gemm_pp_kernel<half_t, 20>}, {22, gemm_pp_kernel<half_t, 22>},
+        {24, gemm_pp_kernel<half_t, 24>}, {48, gemm_pp_kernel<half_t, 48>}, {49, gemm_pp_kernel<half_t, 49>}, {64, gemm_pp_kernel<half_t, 64>},
+        {-1, gemm_pp_kernel<bf16_t, 0>}};  // -1: the bf16 build (VAE decoder), no ablation variants
     if (g_pp_blocks == 0) {
         for (const auto& e : table)
             DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(e.k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -466,7 +469,7 @@ int ds_launch_gemm_pp(const GemmParams& p0, int batch, hipStream_t stream) {
     dim3 grid(tiles < g_pp_blocks ? tiles : g_pp_blocks, 1, batch);
     kern_t kern = nullptr;
     for (const auto& e : table)
-        if (e.dbg == (p.debug & 127)) kern = e.k;
+        if (e.dbg == (p.dtype == DS_DTYPE_BF16 ? -1 : (p.debug & 127))) kern = e.k;
     DS_REQUIRE(kern != nullptr, "gemm_pp: no ablation build for gemm_debug=%d", p.debug);
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, p);
     DS_LAUNCH_CHECK();

@@ -43,6 +43,7 @@ __device__ __forceinline__ GnGeom gn_geom(int C, int HW) {
     return g;
 }
 
+template <typename T>
 __global__ __launch_bounds__(256) void gn_stats_kernel(GroupNormParams p) {
     __shared__ float red[256 * 16];
     const int C = p.C1 + p.C2;
@@ -53,16 +54,16 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GroupNormParams p) {
     for (int e = 0; e < 8; ++e) s[e] = ss[e] = 0.f;
     if (g.active) {
         const bool first = g.c < p.C1;
-        const half_t* src = first ? p.x1 + (long)b * p.HW * p.C1 + g.c : p.x2 + (long)b * p.HW * p.C2 + (g.c - p.C1);
+        const T* src = reinterpret_cast<const T*>(first ? p.x1 + (long)b * p.HW * p.C1 + g.c : p.x2 + (long)b * p.HW * p.C2 + (g.c - p.C1));
         const int ld = first ? p.C1 : p.C2;
         int row = g.row_start;
         const long step = (long)g.R * ld;
         for (; row + 3 * g.R < g.row_end; row += 4 * g.R) {  // 4 independent 16-byte loads in flight per lane
-            const half_t* q = src + (long)row * ld;
-            const h8 v0 = *reinterpret_cast<const h8*>(q);
-            const h8 v1 = *reinterpret_cast<const h8*>(q + step);
-            const h8 v2 = *reinterpret_cast<const h8*>(q + 2 * step);
-            const h8 v3 = *reinterpret_cast<const h8*>(q + 3 * step);
+            const T* q = src + (long)row * ld;
+            const typename Elt<T>::v8 v0 = *reinterpret_cast<const typename Elt<T>::v8*>(q);
+            const typename Elt<T>::v8 v1 = *reinterpret_cast<const typename Elt<T>::v8*>(q + step);
+            const typename Elt<T>::v8 v2 = *reinterpret_cast<const typename Elt<T>::v8*>(q + 2 * step);
+            const typename Elt<T>::v8 v3 = *reinterpret_cast<const typename Elt<T>::v8*>(q + 3 * step);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float f0 = (float)v0[e], f1 = (float)v1[e], f2 = (float)v2[e], f3 = (float)v3[e];
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GroupNormParams p) {
             }
         }
         for (; row < g.row_end; row += g.R) {
-            const h8 v = *reinterpret_cast<const h8*>(src + (long)row * ld);
+            const typename Elt<T>::v8 v = *reinterpret_cast<const typename Elt<T>::v8*>(src + (long)row * ld);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float f = (float)v[e];
@@ -104,6 +105,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GroupNormParams p) {
 }
 
 // one block per batch item; wave w handles groups w, w+4, ...
+template <typename T>
 __global__ __launch_bounds__(256) void gn_finalize_kernel(GroupNormParams p, int nchunks) {
     const int C = p.C1 + p.C2;
     const int b = blockIdx.x;
@@ -129,13 +131,14 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(GroupNormParams p, int
         const float rstd = rsqrtf(var + p.eps);
         for (int cc = lane; cc < cpg; cc += 64) {
             const int c = g * cpg + cc;
-            const float a = rstd * (float)p.gamma[c];
+            const float a = rstd * (float)reinterpret_cast<const T*>(p.gamma)[c];
             tabA[c] = a;
-            tabS[c] = (float)p.beta[c] - mean * a;
+            tabS[c] = (float)reinterpret_cast<const T*>(p.beta)[c] - mean * a;
         }
     }
 }
 
+template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_kernel(GroupNormParams p, int nchunks_stats) {
     const int C = p.C1 + p.C2;
     const GnGeom g = gn_geom(C, p.HW);
@@ -150,36 +153,36 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GroupNormParams p, int nc
         s[e] = tabS[g.c + e];
     }
     const bool first = g.c < p.C1;
-    const half_t* src = first ? p.x1 + (long)b * p.HW * p.C1 + g.c : p.x2 + (long)b * p.HW * p.C2 + (g.c - p.C1);
+    const T* src = reinterpret_cast<const T*>(first ? p.x1 + (long)b * p.HW * p.C1 + g.c : p.x2 + (long)b * p.HW * p.C2 + (g.c - p.C1));
     const int ld = first ? p.C1 : p.C2;
-    half_t* dst = p.y + (long)b * p.HW * C + g.c;
-    auto norm8 = [&](const h8& v) {
-        h8 o;
+    T* dst = reinterpret_cast<T*>(p.y) + (long)b * p.HW * C + g.c;
+    auto norm8 = [&](const typename Elt<T>::v8& v) {
+        typename Elt<T>::v8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float f = fmaf(a[e], (float)v[e], s[e]);
             if (p.silu) f = ds_silu(f);
-            o[e] = (half_t)f;
+            o[e] = (T)f;
         }
         return o;
     };
     int row = g.row_start;
     const long step = (long)g.R * ld, dstep = (long)g.R * C;
     for (; row + 3 * g.R < g.row_end; row += 4 * g.R) {  // 4 independent 16-byte loads in flight per lane
-        const half_t* q = src + (long)row * ld;
-        const h8 v0 = *reinterpret_cast<const h8*>(q);
-        const h8 v1 = *reinterpret_cast<const h8*>(q + step);
-        const h8 v2 = *reinterpret_cast<const h8*>(q + 2 * step);
-        const h8 v3 = *reinterpret_cast<const h8*>(q + 3 * step);
-        half_t* d = dst + (long)row * C;
-        *reinterpret_cast<h8*>(d) = norm8(v0);
-        *reinterpret_cast<h8*>(d + dstep) = norm8(v1);
-        *reinterpret_cast<h8*>(d + 2 * dstep) = norm8(v2);
-        *reinterpret_cast<h8*>(d + 3 * dstep) = norm8(v3);
+        const T* q = src + (long)row * ld;
+        const typename Elt<T>::v8 v0 = *reinterpret_cast<const typename Elt<T>::v8*>(q);
+        const typename Elt<T>::v8 v1 = *reinterpret_cast<const typename Elt<T>::v8*>(q + step);
+        const typename Elt<T>::v8 v2 = *reinterpret_cast<const typename Elt<T>::v8*>(q + 2 * step);
+        const typename Elt<T>::v8 v3 = *reinterpret_cast<const typename Elt<T>::v8*>(q + 3 * step);
+        T* d = dst + (long)row * C;
+        *reinterpret_cast<typename Elt<T>::v8*>(d) = norm8(v0);
+        *reinterpret_cast<typename Elt<T>::v8*>(d + dstep) = norm8(v1);
+        *reinterpret_cast<typename Elt<T>::v8*>(d + 2 * dstep) = norm8(v2);
+        *reinterpret_cast<typename Elt<T>::v8*>(d + 3 * dstep) = norm8(v3);
     }
     for (; row < g.row_end; row += g.R) {
-        const h8 v = *reinterpret_cast<const h8*>(src + (long)row * ld);
-        *reinterpret_cast<h8*>(dst + (long)row * C) = norm8(v);
+        const typename Elt<T>::v8 v = *reinterpret_cast<const typename Elt<T>::v8*>(src + (long)row * ld);
+        *reinterpret_cast<typename Elt<T>::v8*>(dst + (long)row * C) = norm8(v);
     }
 }
 
@@ -248,9 +251,15 @@ int ds_launch_groupnorm(const GroupNormParams& p, hipStream_t stream) {
     const int nch = gn_chunks(p.HW);
     const int nslab = ((C >> 3) + 255) / 256;
     dim3 grid(nslab, nch, p.B);
-    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), 0, stream, p);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(p.B, (p.groups + 3) / 4), dim3(256), 0, stream, p, nch);
-    hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(256), 0, stream, p, nch);
+    if (p.dtype == DS_DTYPE_BF16) {
+        hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, grid, dim3(256), 0, stream, p);
+        hipLaunchKernelGGL(gn_finalize_kernel<bf16_t>, dim3(p.B, (p.groups + 3) / 4), dim3(256), 0, stream, p, nch);
+        hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, grid, dim3(256), 0, stream, p, nch);
+    } else {
+        hipLaunchKernelGGL(gn_stats_kernel<half_t>, grid, dim3(256), 0, stream, p);
+        hipLaunchKernelGGL(gn_finalize_kernel<half_t>, dim3(p.B, (p.groups + 3) / 4), dim3(256), 0, stream, p, nch);
+        hipLaunchKernelGGL(gn_apply_kernel<half_t>, grid, dim3(256), 0, stream, p, nch);
+    }
     DS_LAUNCH_CHECK();
     return 0;
 }

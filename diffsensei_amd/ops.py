@@ -284,3 +284,85 @@ def pad_rows(x: Tensor, row_off: int, rows_in: int, rows_out: int) -> Tensor:
     y = torch.empty((B, rows_out, Cc), dtype=torch.float16, device=x.device)
     check(_lib.load().ds_pad_rows_f16(_p(x), _p(y), B, rows_in, rows_out, row_off, T, Cc, _stream()), "ds_pad_rows_f16")
     return y
+
+
+# ------------------------------------------------------------------------------------------------ bf16 (VAE decoder)
+_BF = torch.bfloat16
+
+
+def conv3x3_bf16(x: Tensor, w: Tensor, bias: Tensor, upsample: bool = False, residual: Optional[Tensor] = None) -> Tensor:
+    """x: [B,H,W,Cin] bf16 NHWC, w: [Cout,3,3,Cin] -> [B,Ho,Wo,Cout] (stride 1; upsample = nearest x2 in front)."""
+    _chk(x, w, bias, residual, dtype=_BF)
+    B, H, W, Cin = x.shape
+    Cout = w.shape[0]
+    Ho, Wo = (2 * H, 2 * W) if upsample else (H, W)
+    y = torch.empty((B, Ho, Wo, Cout), dtype=_BF, device=x.device)
+    check(_lib.load().ds_conv3x3_bf16(_p(x), _p(w), _p(bias), _p(residual), _p(y), B, H, W, Cin, Cout, int(upsample),
+                                      _stream()), "ds_conv3x3_bf16")
+    return y
+
+
+def gemm_bf16(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, residual: Optional[Tensor] = None) -> Tensor:
+    """y = x @ w.T + bias (+ residual), all bf16; M, N multiples of 16, K of 128."""
+    _chk(x, w, bias, residual, dtype=_BF)
+    M, K = x.shape
+    N = w.shape[0]
+    y = torch.empty((M, N), dtype=_BF, device=x.device)
+    check(_lib.load().ds_gemm_bf16(_p(x), K, _p(w), K, _p(bias), _p(residual), N, _p(y), N, M, N, K, _stream()),
+          "ds_gemm_bf16")
+    return y
+
+
+def gemm_batched_nt_bf16(a: Tensor, b: Tensor) -> Tensor:
+    """out[z] = a @ b[z].T ; a: [M,K] shared, b: [Z,N,K] -> [Z,M,N] (V^T[z] = Wv @ X_z^T)."""
+    _chk(a, b, dtype=_BF)
+    Z, N, K = b.shape
+    M = a.shape[0]
+    out = torch.empty((Z, M, N), dtype=_BF, device=b.device)
+    check(_lib.load().ds_gemm_bf16_batched(_p(a), K, 0, _p(b), K, N * K, _p(out), N, M * N, M, N, K, Z, _stream()),
+          "ds_gemm_bf16_batched")
+    return out
+
+
+def groupnorm_bf16(x: Tensor, gamma: Tensor, beta: Tensor, groups: int, eps: float, silu: bool) -> Tensor:
+    """x: [B,HW,C] bf16 -> GroupNorm (+SiLU)."""
+    _chk(x, gamma, beta, dtype=_BF)
+    B, HW, C = x.shape
+    L = _lib.load()
+    ws = torch.empty(L.ds_groupnorm_workspace_bytes(B, C), dtype=torch.uint8, device=x.device)
+    y = torch.empty_like(x)
+    check(L.ds_groupnorm_bf16(_p(x), _p(y), _p(gamma), _p(beta), _p(ws), B, HW, C, groups, eps, int(silu), _stream()),
+          "ds_groupnorm_bf16")
+    return y
+
+
+def wide_attention_bf16(q: Tensor, k: Tensor, vt: Tensor, scale: float) -> Tensor:
+    """Single head of dim 512: q, k [B,N,512], vt [B,512,N] -> [B,N,512]."""
+    _chk(q, k, vt, dtype=_BF)
+    B, N, D = q.shape
+    assert D == 512 and vt.shape == (B, 512, N)
+    o = torch.empty_like(q)
+    check(_lib.load().ds_wide_attn_bf16(_p(q), _p(k), _p(vt), _p(o), B, N, scale, _stream()), "ds_wide_attn_bf16")
+    return o
+
+
+def vae_conv_in(latents: Tensor, pq_w: Tensor, pq_b: Tensor, w: Tensor, bias: Tensor, scaling_factor: float) -> Tensor:
+    """latents fp32 NCHW [B,4,H,W]; pq_w [4,4], pq_b [4] fp32; w [C,3,3,4], bias [C] bf16 -> [B,H,W,C] bf16."""
+    _chk(latents, pq_w, pq_b, dtype=torch.float32)
+    _chk(w, bias, dtype=_BF)
+    B, _, H, W = latents.shape
+    C = w.shape[0]
+    y = torch.empty((B, H, W, C), dtype=_BF, device=latents.device)
+    check(_lib.load().ds_vae_conv_in_bf16(_p(latents), _p(pq_w), _p(pq_b), _p(w), _p(bias), _p(y), B, H, W, C,
+                                          scaling_factor, _stream()), "ds_vae_conv_in_bf16")
+    return y
+
+
+def vae_conv_out(x: Tensor, w: Tensor, bias: Tensor, denormalize: bool = False) -> Tensor:
+    """x [B,H,W,C] bf16, w [3,3,3,C], bias [3] bf16 -> image fp32 NCHW [B,3,H,W] (denormalize: (y/2+0.5).clamp(0,1))."""
+    _chk(x, w, bias, dtype=_BF)
+    B, H, W, C = x.shape
+    img = torch.empty((B, 3, H, W), dtype=torch.float32, device=x.device)
+    check(_lib.load().ds_vae_conv_out_bf16(_p(x), _p(w), _p(bias), _p(img), B, H, W, C, int(denormalize), _stream()),
+          "ds_vae_conv_out_bf16")
+    return img

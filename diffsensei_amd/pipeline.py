@@ -24,6 +24,7 @@ import torch
 
 from .encoders import ClipTextEngine, ClipVisionEngine, ViTMAEEngine
 from .unet import UNetMangaModel, dialog_pixel_boxes
+from .vae import VaeDecoderEngine
 
 Tensor = torch.Tensor
 
@@ -41,7 +42,7 @@ def _black_image():
 class DiffSenseiPipeline:
     def __init__(self, vae, text_encoder, text_encoder_2, tokenizer, tokenizer_2, scheduler, unet: UNetMangaModel,
                  image_encoder, feature_extractor=None, force_zeros_for_empty_prompt: bool = True):
-        self.vae = vae
+        self.vae = self._as_vae_engine(vae)
         self.tokenizer, self.tokenizer_2 = tokenizer, tokenizer_2
         self.scheduler, self.unet = scheduler, unet
         self.text_encoder = self._as_text_engine(text_encoder)
@@ -88,6 +89,14 @@ class DiffSenseiPipeline:
         if m is None or isinstance(m, ClipVisionEngine):
             return m
         return ClipVisionEngine.from_transformers(m, self.unet.device)
+
+    def _as_vae_engine(self, m):
+        """A diffusers AutoencoderKL is re-laid-out for the HIP decoder; anything else with `.decode` is used as is."""
+        if m is None or isinstance(m, VaeDecoderEngine):
+            return m
+        if hasattr(m, "state_dict") and hasattr(getattr(m, "config", None), "block_out_channels"):
+            return VaeDecoderEngine.from_diffusers(m, self.unet.device)
+        return m
 
     def _as_text_engine(self, m):
         if m is None or isinstance(m, ClipTextEngine):
@@ -309,9 +318,15 @@ class DiffSenseiPipeline:
                 raise ValueError("no VAE registered: call with output_type='latent'")
             return StableDiffusionXLPipelineOutput(images=out_latents)
         scaling = getattr(getattr(self.vae, "config", None), "scaling_factor", 0.13025)
-        image = self.vae.decode(out_latents.float() / scaling, return_dict=False)[0]
+        if isinstance(self.vae, VaeDecoderEngine):  # reference :339-367 incl. postprocess' denormalize, all on the HIP kernels
+            image = self.vae.decode(out_latents, return_dict=False, scaling_factor=scaling, denormalize=True)[0]
+        else:
+            image = self.vae.decode(out_latents.float() / scaling, return_dict=False)[0]
+            image = (image / 2 + 0.5).clamp(0, 1)
         if output_type == "pt":
             return StableDiffusionXLPipelineOutput(images=image)
-        image = (image / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1).float().cpu().numpy()
+        image = image.permute(0, 2, 3, 1).float().cpu().numpy()
+        if output_type == "np":
+            return StableDiffusionXLPipelineOutput(images=image)
         from PIL import Image
         return StableDiffusionXLPipelineOutput(images=[Image.fromarray((im * 255).round().astype("uint8")) for im in image])

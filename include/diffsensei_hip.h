@@ -48,6 +48,33 @@ int ds_gemm_f16(const void* x, int64_t ldx, const void* x2, int64_t ldx2, int k1
 int ds_gemm_f16_batched(const void* x, int64_t ldx, int64_t sx, const void* w, int64_t ldw, int64_t sw, void* y,
                         int64_t ldy, int64_t sy, int M, int N, int K, int batch, void* stream);
 
+/* ---- VAE decoder (bf16 storage, fp32 accumulate): replaces AutoencoderKL.decode reached from reference
+ * src/pipelines/pipeline_diffsensei.py:339-367 (the reference upcasts the VAE to fp32 because fp16 overflows).
+ * Same layouts as the f16 entry points; all tensors bf16 unless noted. */
+/* y = conv3x3(x[B,H,W,Cin], w[Cout,3,3,Cin]) + bias (+ residual); stride 1; upsample != 0 = nearest x2 in front.
+ * H_out % 8 == 0, W_out % 16 == 0, Cin % 64 == 0.  ResnetBlock2D.conv1/conv2, Upsample2D.conv of the decoder. */
+int ds_conv3x3_bf16(const void* x, const void* w, const void* bias, const void* residual, void* y, int B, int H,
+                    int W, int Cin, int Cout, int upsample, void* stream);
+/* y[M,N] = x[M,K] @ w[N,K]^T + bias (+ residual); M, N % 16 == 0, K % 128 == 0: conv_shortcut (1x1), to_q/k/out */
+int ds_gemm_bf16(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias, const void* residual,
+                 int64_t ldr, void* y, int64_t ldy, int M, int N, int K, void* stream);
+/* batched (element strides, 0 = shared operand): V^T[b] = Wv @ X_b^T */
+int ds_gemm_bf16_batched(const void* x, int64_t ldx, int64_t sx, const void* w, int64_t ldw, int64_t sw, void* y,
+                         int64_t ldy, int64_t sy, int M, int N, int K, int batch, void* stream);
+/* GroupNorm (+SiLU) over [B,HW,C]; ws: ds_groupnorm_workspace_bytes(B, C) */
+int ds_groupnorm_bf16(const void* x, void* y, const void* gamma, const void* beta, void* ws, int B, int HW, int C,
+                      int groups, float eps, int silu, void* stream);
+/* single-head attention, head dim 512: q,k,o [B,N,512], vt [B,512,N]; N % 8 == 0.  Decoder mid_block.attentions.0 */
+int ds_wide_attn_bf16(const void* q, const void* k, const void* vt, void* o, int B, int N, float scale, void* stream);
+/* y[B,H,W,C] = conv_in(post_quant_conv(latents / scaling_factor)); latents fp32 NCHW [B,4,H,W]; post_quant_w [4,4],
+ * post_quant_b [4] fp32; w [C,3,3,4], bias [C] bf16 */
+int ds_vae_conv_in_bf16(const float* latents, const float* post_quant_w, const float* post_quant_b, const void* w,
+                        const void* bias, void* y, int B, int H, int W, int C, float scaling_factor, void* stream);
+/* image fp32 NCHW [B,3,H,W] = conv_out(x[B,H,W,C]); w [3,3,3,C], bias [3] bf16; denormalize != 0 also applies
+ * VaeImageProcessor.denormalize, (x / 2 + 0.5).clamp(0, 1) (pipeline_diffsensei.py:367 postprocess) */
+int ds_vae_conv_out_bf16(const void* x, const void* w, const void* bias, float* image, int B, int H, int W, int C,
+                         int denormalize, void* stream);
+
 /* 3x3 convolution, pad 1, NHWC: y[B,Ho,Wo,Cout] = conv(x[B,H,W,Cin], w[Cout,3,3,Cin]) + bias
  * (+ rowbias[b, :] per image — the resnet time_emb_proj term) (+ residual).  stride in {1,2};
  * upsample != 0 fuses a nearest x2 upsample in front (diffusers Upsample2D).  Cin % 64 == 0.

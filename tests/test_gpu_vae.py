@@ -1,0 +1,119 @@
+"""GPU: the bf16 VAE-decoder kernels through the C ABI vs plain PyTorch fp32 references of the same ops, and the
+whole `VaeDecoderEngine.decode` vs the fp32 CPU oracle (oracle/vae_ref.py).
+
+Tolerances: inputs are rounded to bf16 first and the reference is computed in fp32 from those values, so what is
+left is the kernels' own bf16 output rounding (2^-9 relative) and accumulation order -> max |err| <= 1e-2 * max|ref|
+per op; the full decoder compounds ~40 bf16-rounded layers -> relative L2 <= 3e-2 on the image.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+BF = torch.bfloat16
+
+
+def _r(shape, g, scale=1.0):
+    return (torch.randn(shape, generator=g) * scale).to(BF)
+
+
+def _close(got, ref, tol=1e-2, what=""):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    assert torch.isfinite(got).all(), what
+    err = (got - ref).abs().max().item()
+    den = max(ref.abs().max().item(), 1e-3)
+    assert err <= tol * den, f"{what}: max err {err:.4g} vs max|ref| {den:.4g}"
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,up", [(2, 16, 16, 128, 128, False), (1, 8, 16, 512, 256, True),
+                                               (1, 32, 48, 256, 192, False)])
+def test_conv3x3_bf16(hip_lib, B, H, W, Cin, Cout, up):
+    from diffsensei_amd import ops
+    g = torch.Generator().manual_seed(B * H + Cin + Cout)
+    x, w, b = _r((B, Cin, H, W), g), _r((Cout, Cin, 3, 3), g, 1 / math.sqrt(9 * Cin)), _r((Cout,), g)
+    xi = F.interpolate(x.float(), scale_factor=2.0, mode="nearest") if up else x.float()
+    ref = F.conv2d(xi, w.float(), b.float(), padding=1)
+    res = _r(tuple(ref.shape), g)
+    x_n = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    w_n = w.permute(0, 2, 3, 1).contiguous().to(DEV)
+    y = ops.conv3x3_bf16(x_n, w_n, b.to(DEV), upsample=up)
+    _close(y.permute(0, 3, 1, 2), ref, what="conv bf16")
+    y2 = ops.conv3x3_bf16(x_n, w_n, b.to(DEV), upsample=up, residual=res.permute(0, 2, 3, 1).contiguous().to(DEV))
+    _close(y2.permute(0, 3, 1, 2), ref.to(BF).float() + res.float(), what="conv bf16 + residual")
+
+
+def test_gemm_and_groupnorm_bf16(hip_lib):
+    from diffsensei_amd import ops
+    g = torch.Generator().manual_seed(3)
+    M, N, K = 1040, 256, 512
+    x, w, b, r = _r((M, K), g), _r((N, K), g, 1 / math.sqrt(K)), _r((N,), g), _r((M, N), g)
+    ref = (x.float() @ w.float().t() + b.float()).to(BF).float() + r.float()
+    _close(ops.gemm_bf16(x.to(DEV), w.to(DEV), b.to(DEV), r.to(DEV)), ref, what="gemm bf16")
+    # V^T form: out[z] = a @ b[z]^T
+    a, bb = _r((512, 512), g, 1 / math.sqrt(512)), _r((2, 272, 512), g)
+    _close(ops.gemm_batched_nt_bf16(a.to(DEV), bb.to(DEV)), torch.einsum("ck,znk->zcn", a.float(), bb.float()), what="V^T")
+    # GroupNorm (+SiLU), eps 1e-6, large-magnitude activations (the reason the decoder is not fp16)
+    xg = (_r((2, 32 * 24, 256), g).float() * 300.0 + 1000.0).to(BF)
+    gam, bet = _r((256,), g), _r((256,), g)
+    refn = F.group_norm(xg.float().transpose(1, 2), 32, gam.float(), bet.float(), 1e-6).transpose(1, 2)
+    _close(ops.groupnorm_bf16(xg.to(DEV), gam.to(DEV), bet.to(DEV), 32, 1e-6, False), refn, tol=2e-2, what="gn")
+    _close(ops.groupnorm_bf16(xg.to(DEV), gam.to(DEV), bet.to(DEV), 32, 1e-6, True), F.silu(refn), tol=2e-2, what="gn+silu")
+
+
+@pytest.mark.parametrize("B,N", [(2, 256), (1, 1000), (1, 2048)])
+def test_wide_attention_bf16(hip_lib, B, N):
+    from diffsensei_amd import ops
+    g = torch.Generator().manual_seed(N)
+    q, k, v = _r((B, N, 512), g), _r((B, N, 512), g), _r((B, N, 512), g)
+    scale = 1 / math.sqrt(512)
+    ref = torch.softmax(q.float() @ k.float().transpose(1, 2) * scale, -1) @ v.float()
+    got = ops.wide_attention_bf16(q.to(DEV), k.to(DEV), v.transpose(1, 2).contiguous().to(DEV), scale)
+    _close(got, ref, tol=2e-2, what="wide attention")
+
+
+def test_vae_conv_in_out(hip_lib):
+    from diffsensei_amd import ops
+    g = torch.Generator().manual_seed(9)
+    B, H, W, C = 2, 16, 32, 512
+    lat = torch.randn(B, 4, H, W, generator=g)
+    pqw, pqb = torch.randn(4, 4, generator=g) * 0.5, torch.randn(4, generator=g) * 0.1
+    w, b = _r((C, 4, 3, 3), g, 1 / 6.0), _r((C,), g)
+    sf = 0.13025
+    z = F.conv2d(lat / sf, pqw.view(4, 4, 1, 1), pqb)
+    ref = F.conv2d(z, w.float(), b.float(), padding=1)
+    got = ops.vae_conv_in(lat.to(DEV), pqw.to(DEV), pqb.to(DEV), w.permute(0, 2, 3, 1).contiguous().to(DEV), b.to(DEV), sf)
+    _close(got.permute(0, 3, 1, 2), ref, what="post_quant + conv_in")
+    x = _r((B, 128, H, W), g)
+    wo, bo = _r((3, 128, 3, 3), g, 1 / math.sqrt(9 * 128)), _r((3,), g)
+    refo = F.conv2d(x.float(), wo.float(), bo.float(), padding=1)
+    xo = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    wn = wo.permute(0, 2, 3, 1).contiguous().to(DEV)
+    _close(ops.vae_conv_out(xo, wn, bo.to(DEV)), refo, tol=2e-3, what="conv_out")
+    _close(ops.vae_conv_out(xo, wn, bo.to(DEV), denormalize=True), (refo / 2 + 0.5).clamp(0, 1), tol=2e-3, what="denorm")
+
+
+def test_decoder_engine_vs_oracle(hip_lib):
+    """Whole decode at the SDXL VAE widths (128,256,512,512), latent 16x16 -> 128x128 image, batch 2."""
+    from diffsensei_amd.vae import VaeConfig, VaeDecoderEngine, random_state_dict, vae_param_shapes
+    from oracle.vae_ref import vae_decode
+    cfg = VaeConfig()
+    sd = {k: v.to(BF).float() for k, v in random_state_dict(cfg, 1).items()}  # both sides see bf16-representable weights
+    eng = VaeDecoderEngine.from_state_dict(sd, cfg, DEV)
+    g = torch.Generator().manual_seed(4)
+    lat = torch.randn(2, 4, 16, 16, generator=g) * 0.18215 * 5
+    ref = vae_decode(sd, lat / cfg.scaling_factor, cfg.layers_per_block, cfg.norm_num_groups, cfg.eps)
+    got = eng.decode(lat.to(DEV), return_dict=False, scaling_factor=cfg.scaling_factor)[0]
+    assert got.shape == ref.shape == (2, 3, 128, 128) and got.dtype == torch.float32
+    rel = ((got.cpu() - ref).norm() / ref.norm()).item()
+    assert rel <= 3e-2, rel
+    same = eng.decode((lat / cfg.scaling_factor).half().to(DEV), return_dict=True).sample      # plain vae.decode protocol
+    assert ((same.cpu() - ref).norm() / ref.norm()).item() <= 3e-2
+    den = eng.decode(lat.to(DEV), return_dict=False, scaling_factor=cfg.scaling_factor, denormalize=True)[0]
+    assert torch.equal(den, (got / 2 + 0.5).clamp(0, 1))
+    assert len(eng.tensors()) == len(vae_param_shapes(cfg)) + 1
+    with pytest.raises(ValueError):
+        eng.decode(torch.zeros(1, 4, 12, 16, device=DEV))

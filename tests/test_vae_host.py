@@ -1,0 +1,30 @@
+"""CPU: the VAE decoder's host side (parameter inventory in diffusers' key names) and the fp32 oracle's structure."""
+import torch
+
+from diffsensei_amd.vae import VaeConfig, random_state_dict, vae_param_shapes
+
+
+def test_param_inventory_matches_diffusers_decoder_layout():
+    sh = vae_param_shapes(VaeConfig())
+    assert len(sh) == 140
+    assert sh["decoder.conv_in.weight"] == (512, 4, 3, 3) and sh["decoder.conv_out.weight"] == (3, 128, 3, 3)
+    assert sh["decoder.up_blocks.2.resnets.0.conv_shortcut.weight"] == (256, 512, 1, 1)
+    assert sh["decoder.up_blocks.3.resnets.0.conv_shortcut.weight"] == (128, 256, 1, 1)
+    assert "decoder.up_blocks.3.upsamplers.0.conv.weight" not in sh and "decoder.up_blocks.2.upsamplers.0.conv.weight" in sh
+    assert sh["decoder.mid_block.attentions.0.to_out.0.weight"] == (512, 512)
+    n = sum(int(torch.tensor(s).prod()) for s in sh.values())
+    assert 49_000_000 < n < 50_000_000  # the SDXL VAE decoder (+ post_quant_conv) has 49.5 M parameters
+
+
+def test_oracle_decode_structure():
+    from oracle.vae_ref import vae_decode
+    cfg = VaeConfig(block_out_channels=(32, 32, 64, 64), layers_per_block=1, norm_num_groups=8)
+    sd = random_state_dict(cfg, 0)
+    z = torch.randn(2, 4, 6, 10, generator=torch.Generator().manual_seed(1))
+    img = vae_decode(sd, z, cfg.layers_per_block, cfg.norm_num_groups, cfg.eps)
+    assert img.shape == (2, 3, 48, 80) and torch.isfinite(img).all()
+    # batch items are independent, and conv_out's bias is a plain per-channel offset
+    assert torch.allclose(vae_decode(sd, z[1:], 1, 8, cfg.eps), img[1:], atol=1e-5)
+    sd2 = dict(sd)
+    sd2["decoder.conv_out.bias"] = sd["decoder.conv_out.bias"] + torch.tensor([1.0, -2.0, 0.5])
+    assert torch.allclose(vae_decode(sd2, z, 1, 8, cfg.eps) - img, torch.tensor([1.0, -2.0, 0.5]).view(1, 3, 1, 1).expand_as(img), atol=1e-5)
