@@ -11,8 +11,8 @@ plan.  Inputs are synthetic and already resident in HBM where tensors are involv
 images are 224x224 uint8 that go through the reference's CPU image processors).  Weights: seeded random at the true
 SDXL / CLIP-H / ViT-MAE / Resampler shapes (no checkpoint is reachable offline; throughput is value independent).
 The timed region also runs both SDXL text encoders (CLIP-L + OpenCLIP bigG shapes, HIP engine) on the prompt and the
-negative prompt (token ids from a synthetic tokenizer: no vocabulary files offline).  NOT in the timed region
-(SURVEY.md §8f "next", stated in `config.timed_region`): the VAE decode (latents are the output).
+negative prompt (token ids from a synthetic tokenizer: no vocabulary files offline) and ends with the SDXL VAE decode +
+denormalisation on the bf16 HIP decoder (output: [0,1] fp32 images on the device; `--no-vae` stops at the latents).
 
 N > 1: one process per GPU, weights broadcast from rank 0 over RCCL once (time reported, outside the timed region),
 each rank serves its own requests with no data-path collective -> "scaling": "weak".  Timing: barrier +
@@ -45,7 +45,7 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def build_pipeline(device, num_gpus, rank, seed=0):
+def build_pipeline(device, num_gpus, rank, seed=0, with_vae=True):
     """Reference construction recipe (scripts/demo/gradio_wo_mllm.py:161-200) with synthetic weights."""
     from transformers import CLIPVisionConfig, CLIPVisionModel, ViTMAEConfig, ViTMAEModel
     from diffsensei_amd.distributed import broadcast_tensors
@@ -80,10 +80,13 @@ def build_pipeline(device, num_gpus, rank, seed=0):
     with torch.device("cpu"):
         te1 = ClipTextEngine.from_transformers(CLIPTextModel(t1).eval(), device)
         te2 = ClipTextEngine.from_transformers(CLIPTextModelWithProjection(t2).eval(), device)
+    # SDXL VAE decoder (49.5 M parameters) at its true shapes, random init, bf16 HIP engine
+    from diffsensei_amd.vae import VaeConfig, VaeDecoderEngine
+    vae = VaeDecoderEngine.init_random(VaeConfig(), seed + 2, device) if with_vae else None
     t_init = time.perf_counter() - t0
     bstats = {"bytes": 0, "seconds": 0.0, "buckets": 0}
     if num_gpus > 1:
-        tensors = list(unet._sd.values()) + list(resampler._sd.values())
+        tensors = list(unet._sd.values()) + list(resampler._sd.values()) + (vae.tensors() if vae is not None else [])
         for eng in (te1, te2):
             for L in eng.layers:
                 tensors += [getattr(L, s) for s in L.__slots__]
@@ -98,7 +101,7 @@ def build_pipeline(device, num_gpus, rank, seed=0):
         dist.barrier()
         bstats = broadcast_tensors(tensors, src=0)
     tok = SyntheticTokenizer()
-    pipe = DiffSenseiPipeline(vae=None, text_encoder=te1, text_encoder_2=te2, tokenizer=tok, tokenizer_2=tok,
+    pipe = DiffSenseiPipeline(vae=vae, text_encoder=te1, text_encoder_2=te2, tokenizer=tok, tokenizer_2=tok,
                               scheduler=EulerDiscreteScheduler(), unet=unet, image_encoder=clip)
     pipe.register_manga_modules(magi_image_encoder=magi, image_proj_model=resampler)
     return pipe, {"init_s": round(t_init, 2), "broadcast_bytes": bstats["bytes"],
@@ -116,7 +119,7 @@ class SyntheticTokenizer:
         return type("Enc", (), {"input_ids": torch.tensor([ids])})()
 
 
-def synthetic_request(device, size, seed):
+def synthetic_request(device, size, seed, output_type="pt"):
     import numpy as np
     from PIL import Image
     g = torch.Generator().manual_seed(seed)
@@ -128,7 +131,7 @@ def synthetic_request(device, size, seed):
         ip_bbox=[[0.05, 0.10, 0.50, 0.95], [0.50, 0.10, 0.95, 0.95]], ip_scale=0.6,
         dialog_bbox=[[0.05, 0.02, 0.30, 0.15], [0.65, 0.02, 0.95, 0.15]],
         negative_prompt="think lines, pure black background, colored, lowres, bad anatomy, worst quality, low quality",
-        generator=torch.Generator().manual_seed(seed), output_type="latent")
+        generator=torch.Generator().manual_seed(seed), output_type=output_type)
 
 
 def profile_forward_ops(pipe, reps=3):
@@ -175,6 +178,7 @@ def main():
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-vae", action="store_true", help="stop at the latents (the round-1 timed region)")
     args = ap.parse_args()
 
     from diffsensei_amd.distributed import init_from_env
@@ -188,9 +192,9 @@ def main():
     if world > 1:
         dist.barrier()
 
-    pipe, setup = build_pipeline(device, world, rank)
+    pipe, setup = build_pipeline(device, world, rank, with_vae=not args.no_vae)
     ns = args.num_samples
-    req = synthetic_request(device, args.size, seed=1234 + rank)
+    req = synthetic_request(device, args.size, seed=1234 + rank, output_type="latent" if args.no_vae else "pt")
 
     def one_step():
         out = pipe(num_samples=ns, **req)
@@ -212,7 +216,9 @@ def main():
         t = torch.tensor([dt], device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    assert torch.isfinite(lat.float()).all(), "non-finite latents"
+    assert torch.isfinite(lat.float()).all(), "non-finite output"
+    if not args.no_vae:
+        assert lat.shape == (ns, 3, args.size, args.size) and float(lat.min()) >= 0.0 and float(lat.max()) <= 1.0
     panels = world * args.steps * ns
     value = panels / dt
 
@@ -264,11 +270,12 @@ def main():
             "config": {"workload": f"{args.size}x{args.size}, 50-step Euler, CFG 7.5, 2 character refs (padded to 4) + "
                                    f"2 dialog boxes, num_samples={ns} per call (UNet batch {2 * ns}), one call per step",
                        "timed_region": "2 SDXL text encoders (prompt + negative prompt), CLIP-H + ViT-MAE + Resampler "
-                                       "character encoding, 50 x (UNet + CFG + scheduler step); VAE decode excluded "
-                                       "(output: latents)",
+                                       "character encoding, 50 x (UNet + CFG + scheduler step)" +
+                                       ("; VAE decode excluded (output: latents)" if args.no_vae else
+                                        ", SDXL VAE decode + denormalize (bf16 HIP engine; output: [0,1] fp32 images on the device)"),
                        "num_samples": ns, "unet_batch": 2 * ns, "hipgraph": pipe.last_run_info.get("graph"),
                        "kernel_launches_per_denoise_step": pipe.last_run_info.get("ops_per_step"),
-                       "weights": "seeded random at SDXL UNet / CLIP-L + bigG text / CLIP-H / ViT-MAE / Resampler shapes", **setup},
+                       "weights": "seeded random at SDXL UNet / CLIP-L + bigG text / CLIP-H / ViT-MAE / Resampler / VAE decoder shapes", **setup},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         if extra:

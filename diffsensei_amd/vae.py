@@ -218,6 +218,15 @@ class VaeDecoderEngine:
         B, _, h, w = z.shape
         if h % 16 or w % 16:
             raise ValueError(f"latent sides must be multiples of 16 (got {h}x{w}): the conv kernel works on 8x16 patches")
+        # the conv kernel addresses its input with 32-bit element offsets: the widest full-resolution activation
+        # ([chunk, 8h, 8w, C1]) bounds how many images go through one launch sequence (7 at 1024^2 -> chunks of 4)
+        per_image = (8 * h) * (8 * w) * max(self.config.block_out_channels[1], self.config.block_out_channels[0])
+        chunk = max(1, min(B, (2 ** 31 - 1) // per_image))
+        chunk = 1 << (chunk.bit_length() - 1)
+        if B > chunk:
+            parts = [self.decode(z[i:i + chunk], False, generator, scaling_factor, denormalize)[0] for i in range(0, B, chunk)]
+            img = torch.cat(parts)
+            return DecoderOutput(img) if return_dict else (img,)
         lat = z.to(self.device, torch.float32).contiguous()
         x = ops.vae_conv_in(lat, self.w["post_quant_conv.weight"], self.w["post_quant_conv.bias"],
                             self.w["decoder.conv_in.weight"], self.w["decoder.conv_in.bias"], scaling_factor)
