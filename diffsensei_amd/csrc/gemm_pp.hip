@@ -101,7 +101,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     const int cbh = geglu ? 64 : 32;
     const half_t* gA[2];
     const half_t* gB[2];
+    int krot = 0;
     auto set_tile = [&](int id, int& m0, int& n0) {
+        krot = (id & 31) % nk;
         int tm, tn;
         tile_coords(id, p.tiles_m, p.tiles_n, tm, tn);
         if constexpr ((DBG & 32) != 0) tm = tn = 0;  // ablation: every block works on tile (0,0): all operand loads hit L2
@@ -120,7 +122,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     char* const sdst = smem + wave * 2048;
     auto stage = [&](int op, int half, int buf, int kt) {
         char* d = sdst + ((op * 2 + half) * 2 + buf) * HT;
-        const char* s = reinterpret_cast<const char*>((op == 0 ? gA[half] : gB[half]) + kt * 64);
+        int kp = kt;
+        if constexpr ((DBG & 128) != 0) {  // experiment: rotate the k order per tile so the tiles sharing a panel de-phase
+            kp = kt + krot;
+            kp -= kp >= nk ? nk : 0;
+        }
+        const char* s = reinterpret_cast<const char*>((op == 0 ? gA[half] : gB[half]) + kp * 64);
         const unsigned o0 = op == 0 ? oA[0] : oB[0], o1 = op == 0 ? oA[1] : oB[1];
         if constexpr ((DBG & 2) != 0) return;
         __builtin_amdgcn_global_load_lds((glb_void*)(s + (size_t)o0), (lds_void*)d, 16, 0, 0);
@@ -455,7 +462,7 @@ int ds_launch_gemm_pp(const GemmParams& p0, int batch, hipStream_t stream) {
         {0, gemm_pp_kernel<half_t, 0>},   {1, gemm_pp_kernel<half_t, 1>},   {2, gemm_pp_kernel<half_t, 2>},   {3, gemm_pp_kernel<half_t, 3>},
         {4, gemm_pp_kernel<half_t, 4>},   {6, gemm_pp_kernel<half_t, 6>},   {8, gemm_pp_kernel<half_t, 8>},   {16, gemm_pp_kernel<half_t, 16>},
         {17, gemm_pp_kernel<half_t, 17>}, {18, gemm_pp_kernel<half_t, 18>}, {20, gemm_pp_kernel<half_t, 20>}, {22, gemm_pp_kernel<half_t, 22>},
-        {24, gemm_pp_kernel<half_t, 24>}, {48, gemm_pp_kernel<half_t, 48>}, {49, gemm_pp_kernel<half_t, 49>}, {64, gemm_pp_kernel<half_t, 64>},
+        {24, gemm_pp_kernel<half_t, 24>}, {48, gemm_pp_kernel<half_t, 48>}, {49, gemm_pp_kernel<half_t, 49>}, {64, gemm_pp_kernel<half_t, 64>}, {128, gemm_pp_kernel<half_t, 128>},
         {-1, gemm_pp_kernel<bf16_t, 0>}};  // -1: the bf16 build (VAE decoder), no ablation variants
     if (g_pp_blocks == 0) {
         for (const auto& e : table)
@@ -469,7 +476,7 @@ int ds_launch_gemm_pp(const GemmParams& p0, int batch, hipStream_t stream) {
     dim3 grid(tiles < g_pp_blocks ? tiles : g_pp_blocks, 1, batch);
     kern_t kern = nullptr;
     for (const auto& e : table)
-        if (e.dbg == (p.dtype == DS_DTYPE_BF16 ? -1 : (p.debug & 127))) kern = e.k;
+        if (e.dbg == (p.dtype == DS_DTYPE_BF16 ? -1 : (p.debug & 255))) kern = e.k;
     DS_REQUIRE(kern != nullptr, "gemm_pp: no ablation build for gemm_debug=%d", p.debug);
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, p);
     DS_LAUNCH_CHECK();

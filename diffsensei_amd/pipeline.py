@@ -10,9 +10,10 @@ What runs where
   * character encoders (CLIP-H, Magi ViT-MAE) + Resampler: HIP engines (`encoders.py`, `resampler.py`);
   * the two SDXL CLIP text encoders (`encode_prompt`): HIP engine (`encoders.ClipTextEngine`),
     transformers models passed to the constructor are re-laid-out for it; tokenisation stays on the host;
-  * the VAE decoder is NOT part of this path yet (the reference runs it in fp32 because fp16
-    overflows; these kernels are fp16): any object with the diffusers `decode` protocol can be passed in, or the caller
-    asks for `output_type="latent"`.
+  * the VAE decode + denormalisation (reference :339-367): HIP engine `vae.VaeDecoderEngine`
+    (bf16 storage / fp32 math where the reference upcasts the VAE to fp32); a diffusers `AutoencoderKL` passed to the
+    constructor is re-laid-out for it, any other object with the `decode` protocol is used as is;
+    `output_type` in {"pil", "np", "pt", "latent"}.
 """
 from __future__ import annotations
 

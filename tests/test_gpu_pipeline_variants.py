@@ -91,6 +91,29 @@ def test_text_only_request_runs_the_ip_branch(pipe):
     assert _rel(out, ref) <= 5e-2, _rel(out, ref)
 
 
+def test_call_returns_images_through_the_hip_vae(pipe):
+    """Whole `__call__` to images (reference :339-367): VAE decode + denormalize on the bf16 HIP decoder; "pt"/"np"/"pil"."""
+    from PIL import Image
+    from diffsensei_amd.vae import VaeConfig, VaeDecoderEngine
+    p, cfg, sd, rs, clip, mae, common = pipe
+    vae = VaeDecoderEngine.init_random(VaeConfig(), 3, DEV)
+    lat0 = torch.randn(2, 4, 16, 16, generator=torch.Generator().manual_seed(2)).half()
+    kw = {k: v for k, v in common.items() if k != "output_type"}
+    kw.update(ip_images=[], ip_bbox=[], dialog_bbox=[], num_samples=2)
+    lat = p(latents=lat0.clone(), output_type="latent", **kw).images
+    p.vae = vae
+    try:
+        pt = p(latents=lat0.clone(), output_type="pt", **kw).images
+        npy = p(latents=lat0.clone(), output_type="np", **kw).images
+        pil = p(latents=lat0.clone(), **kw).images
+    finally:
+        p.vae = None
+    assert pt.shape == (2, 3, 128, 128) and pt.dtype == torch.float32 and 0.0 <= float(pt.min()) and float(pt.max()) <= 1.0
+    assert torch.equal(pt, vae.decode(lat, return_dict=False, scaling_factor=vae.config.scaling_factor, denormalize=True)[0])
+    assert npy.shape == (2, 128, 128, 3)
+    assert len(pil) == 2 and isinstance(pil[0], Image.Image) and pil[0].size == (128, 128)
+
+
 def test_mllm_handoff_ip_image_embeds(pipe):
     p, cfg, sd, rs, clip, mae, common = pipe
     g = torch.Generator().manual_seed(2)

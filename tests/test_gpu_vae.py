@@ -117,3 +117,4 @@ def test_decoder_engine_vs_oracle(hip_lib):
     assert len(eng.tensors()) == len(vae_param_shapes(cfg)) + 1
     with pytest.raises(ValueError):
         eng.decode(torch.zeros(1, 4, 12, 16, device=DEV))
+

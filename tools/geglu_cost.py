@@ -6,14 +6,14 @@ import torch
 from diffsensei_amd import _lib, ops
 lib = _lib.load()
 g = torch.Generator(device="cuda").manual_seed(0)
-for (M, N, K) in [(16384, 10240, 1280), (65536, 5120, 640)]:
+for (M, N, K) in [(32768, 10240, 1280), (131072, 5120, 640), (32768, 1280, 5120), (32768, 2560, 1280)]:
     x = (torch.randn(M, K, generator=g, device="cuda") * 0.5).half()
     w = (torch.randn(N, K, generator=g, device="cuda") * K ** -0.5).half()
     b = (torch.randn(N, generator=g, device="cuda") * 0.5).half()
     y = torch.empty(M, N // 2, dtype=torch.float16, device="cuda")
     for rnd in range(3):
         row = []
-        for variant, dbg in ((3, 0), (3, 64), (8, 0)):
+        for variant, dbg in ((3, 0), (3, 128), (3, 0), (3, 128)):
             lib.ds_set_option(b"gemm_variant", variant)
             lib.ds_set_option(b"gemm_debug", dbg)
             ops.gemm(x, w, b, geglu=True, out=y)

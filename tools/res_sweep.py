@@ -7,9 +7,11 @@ import bench
 dev = torch.device("cuda", 0)
 pipe, _ = bench.build_pipeline(dev, 1, 0)
 rows = []
-for size, ns, steps in [(512, 8, 10), (768, 4, 10), (1024, 4, 10), (1536, 2, 6), (2048, 1, 4)]:
+for size, ns, steps in [(512, 8, 10), (768, 4, 10), (1024, 4, 10), (1536, 2, 6), (2048, 1, 4),
+                        (512, 32, 6), (768, 16, 6), (1536, 8, 4), (2048, 4, 4)]:
     req = bench.synthetic_request(dev, size, seed=size)
     req["num_inference_steps"] = steps
+    req["output_type"] = "latent"                    # denoise loop only (the VAE decode is timed by tools/vae_bench.py)
     pipe(num_samples=ns, **req)                      # warm-up builds + captures the plan for this bucket
     torch.cuda.synchronize()
     t0 = time.perf_counter()
