@@ -238,6 +238,19 @@ class DiffSenseiPipeline:
                  latents: Optional[Tensor] = None, prompt_embeds: Optional[Tensor] = None,
                  negative_prompt_embeds: Optional[Tensor] = None, pooled_prompt_embeds: Optional[Tensor] = None,
                  negative_pooled_prompt_embeds: Optional[Tensor] = None, output_type: str = "pil"):
+        cond = self._conditioning(prompt, prompt_2, height, width, num_inference_steps, guidance_scale, negative_prompt,
+                                  negative_prompt_2, num_samples, generator, original_size, crops_coords_top_left,
+                                  target_size, ip_images, ip_image_embeds, ip_bbox, ip_scale, dialog_bbox, latents,
+                                  prompt_embeds, negative_prompt_embeds, pooled_prompt_embeds,
+                                  negative_pooled_prompt_embeds)
+        out_latents = self._denoise([cond], num_inference_steps, guidance_scale, ip_scale)
+        return StableDiffusionXLPipelineOutput(images=self._postprocess(out_latents, output_type))
+
+    # ---- one request's conditioning tensors (reference :205-309), `num_samples` rows each, conditional and negative
+    def _conditioning(self, prompt, prompt_2, height, width, num_inference_steps, guidance_scale, negative_prompt,
+                      negative_prompt_2, num_samples, generator, original_size, crops_coords_top_left, target_size,
+                      ip_images, ip_image_embeds, ip_bbox, ip_scale, dialog_bbox, latents, prompt_embeds,
+                      negative_prompt_embeds, pooled_prompt_embeds, negative_pooled_prompt_embeds):
         height = height or self.default_sample_size * self.vae_scale_factor
         width = width or self.default_sample_size * self.vae_scale_factor
         original_size = original_size or (height, width)
@@ -268,23 +281,38 @@ class DiffSenseiPipeline:
         lat = self.prepare_latents(num_samples, self.unet.config.in_channels, height, width, torch.float16, device,
                                    generator, latents)
         neg_img, img, neg_bbox, bbox = self.prepare_ip_image_embeds(ip_images, ip_image_embeds, list(ip_bbox), num_samples)
+        add_time_ids = torch.tensor([list(original_size) + list(crops_coords_top_left) + list(target_size)],
+                                    dtype=torch.float16, device=device).repeat(num_samples, 1)
+        neg_dialog, dialog = self.prepare_dialog_bbox(list(dialog_bbox), num_samples)
+        to = lambda t: t.to(device)
+        return {"n": num_samples, "lat": lat, "time_ids": add_time_ids,
+                "pos": (to(prompt_embeds), to(pooled_prompt_embeds), to(img), to(bbox), to(dialog)),
+                "neg": (to(negative_prompt_embeds), to(negative_pooled_prompt_embeds), to(neg_img), to(neg_bbox),
+                        to(neg_dialog))}
+
+    # ---- the denoising loop over one UNet batch assembled from >= 1 requests of the same shape (reference :310-337)
+    def _denoise(self, conds, num_inference_steps, guidance_scale, ip_scale) -> Tensor:
+        device = self._execution_device
+        self._guidance_scale = guidance_scale
+        do_cfg = self.do_classifier_free_guidance
+        self.scheduler.set_timesteps(num_inference_steps, device=device)
+        lat = torch.cat([c["lat"] for c in conds], dim=0)
+        num_samples = lat.shape[0]
         H, W = lat.shape[-2], lat.shape[-1]
         aspect_ratio = H / W
-        add_time_ids = torch.tensor([list(original_size) + list(crops_coords_top_left) + list(target_size)],
-                                    dtype=torch.float16, device=device)
-        neg_dialog, dialog = self.prepare_dialog_bbox(list(dialog_bbox), num_samples)
-        add_text_embeds = pooled_prompt_embeds
-        if do_cfg:
-            prompt_embeds = torch.cat([negative_prompt_embeds, prompt_embeds], dim=0)
-            add_text_embeds = torch.cat([negative_pooled_prompt_embeds, add_text_embeds], dim=0)
+        cat = lambda side, i: torch.cat([c[side][i] for c in conds], dim=0)
+        prompt_embeds, add_text_embeds, img, bbox, dialog = (cat("pos", i) for i in range(5))
+        add_time_ids = torch.cat([c["time_ids"] for c in conds], dim=0)
+        if do_cfg:  # CFG batch layout: all negative rows, then all conditional rows (reference :300-309)
+            prompt_embeds = torch.cat([cat("neg", 0), prompt_embeds], dim=0)
+            add_text_embeds = torch.cat([cat("neg", 1), add_text_embeds], dim=0)
             add_time_ids = torch.cat([add_time_ids, add_time_ids], dim=0)
-            img = torch.cat([neg_img, img], dim=0)
-            dialog = torch.cat([neg_dialog, dialog], dim=0)
-            bbox = torch.cat([neg_bbox, bbox], dim=0)
-        add_time_ids = add_time_ids.repeat(num_samples, 1)
-        enc = torch.cat([prompt_embeds.to(device), img.to(device)], dim=1)
+            img = torch.cat([cat("neg", 2), img], dim=0)
+            bbox = torch.cat([cat("neg", 3), bbox], dim=0)
+            dialog = torch.cat([cat("neg", 4), dialog], dim=0)
+        enc = torch.cat([prompt_embeds, img], dim=1)
 
-        # ---- denoising loop: one plan replay per step
+        # one plan replay per step
         B = enc.shape[0]
         eng = self.unet.engine(B, H, W, aspect_ratio)
         eng.build_sampler(num_samples, self.scheduler.kind, do_cfg)
@@ -312,22 +340,60 @@ class DiffSenseiPipeline:
                     eng.step_plan.run(st.cuda_stream)
         torch.cuda.current_stream(device).wait_stream(st)
         self.last_run_info = {"graph": graph, "ops_per_step": eng.step_plan.n, "batch": B, "latent_hw": (H, W)}
-        out_latents = eng.latents.clone()
+        return eng.latents.clone()
 
+    # ---- reference :339-367: VAE decode + image_processor.postprocess
+    def _postprocess(self, out_latents: Tensor, output_type: str):
         if output_type == "latent" or self.vae is None:
             if output_type != "latent" and self.vae is None:
                 raise ValueError("no VAE registered: call with output_type='latent'")
-            return StableDiffusionXLPipelineOutput(images=out_latents)
+            return out_latents
         scaling = getattr(getattr(self.vae, "config", None), "scaling_factor", 0.13025)
-        if isinstance(self.vae, VaeDecoderEngine):  # reference :339-367 incl. postprocess' denormalize, all on the HIP kernels
+        if isinstance(self.vae, VaeDecoderEngine):  # incl. postprocess' denormalize, all on the HIP kernels
             image = self.vae.decode(out_latents, return_dict=False, scaling_factor=scaling, denormalize=True)[0]
         else:
             image = self.vae.decode(out_latents.float() / scaling, return_dict=False)[0]
             image = (image / 2 + 0.5).clamp(0, 1)
         if output_type == "pt":
-            return StableDiffusionXLPipelineOutput(images=image)
+            return image
         image = image.permute(0, 2, 3, 1).float().cpu().numpy()
         if output_type == "np":
-            return StableDiffusionXLPipelineOutput(images=image)
+            return image
         from PIL import Image
-        return StableDiffusionXLPipelineOutput(images=[Image.fromarray((im * 255).round().astype("uint8")) for im in image])
+        return [Image.fromarray((im * 255).round().astype("uint8")) for im in image]
+
+    # ---- several requests of one shape in ONE UNet batch (serving front-end)
+    @torch.no_grad()
+    def generate_batch(self, requests: List[dict], output_type: str = "pil") -> List[Any]:
+        """Each request: the keyword arguments of `__call__` (without `output_type`).  All must share height, width,
+        num_inference_steps, guidance_scale and ip_scale (`serving.bucket_key`); prompts, character references, boxes,
+        seeds and `num_samples` are per request.  Returns one `.images`-like object per request, in order."""
+        if not requests:
+            return []
+        key = lambda r: (r.get("height"), r.get("width"), r.get("num_inference_steps", 40), r.get("guidance_scale", 5.0),
+                         r.get("ip_scale", 1.0))
+        if any(key(r) != key(requests[0]) for r in requests):
+            raise ValueError("generate_batch: requests must share height/width/steps/guidance_scale/ip_scale")
+        names = ("prompt", "prompt_2", "height", "width", "num_inference_steps", "guidance_scale", "negative_prompt",
+                 "negative_prompt_2", "num_samples", "generator", "original_size", "crops_coords_top_left", "target_size",
+                 "ip_images", "ip_image_embeds", "ip_bbox", "ip_scale", "dialog_bbox", "latents", "prompt_embeds",
+                 "negative_prompt_embeds", "pooled_prompt_embeds", "negative_pooled_prompt_embeds")
+        defaults = dict(prompt_2=None, height=None, width=None, num_inference_steps=40, guidance_scale=5.0,
+                        negative_prompt=None, negative_prompt_2=None, num_samples=1, generator=None, original_size=None,
+                        crops_coords_top_left=(0, 0), target_size=None, ip_images=[], ip_image_embeds=None, ip_bbox=[],
+                        ip_scale=1.0, dialog_bbox=[], latents=None, prompt_embeds=None, negative_prompt_embeds=None,
+                        pooled_prompt_embeds=None, negative_pooled_prompt_embeds=None)
+        conds = []
+        for r in requests:
+            unknown = set(r) - set(names)
+            if unknown:
+                raise TypeError(f"generate_batch: unknown request fields {sorted(unknown)}")
+            conds.append(self._conditioning(*[r[n] if n in r else defaults[n] for n in names]))
+        r0 = requests[0]
+        out = self._denoise(conds, r0.get("num_inference_steps", 40), r0.get("guidance_scale", 5.0), r0.get("ip_scale", 1.0))
+        images = self._postprocess(out, output_type)
+        res, off = [], 0
+        for c in conds:
+            res.append(images[off:off + c["n"]])
+            off += c["n"]
+        return res

@@ -114,6 +114,42 @@ def test_call_returns_images_through_the_hip_vae(pipe):
     assert len(pil) == 2 and isinstance(pil[0], Image.Image) and pil[0].size == (128, 128)
 
 
+def test_generate_batch_equals_separate_calls(pipe):
+    """Serving front-end: three different requests of one bucket in ONE UNet batch (per-request prompts, references,
+    boxes, seeds, num_samples) must give what three separate `__call__`s give.  Every kernel treats batch rows
+    independently; the only difference is which GEMM tiling the larger M selects (bit-identical kernels), so the
+    tolerance is the fp16 noise floor."""
+    from PIL import Image
+    import numpy as np
+    from diffsensei_amd.serving import BucketBatcher
+    p, cfg, sd, rs, clip, mae, common = pipe
+    rng = np.random.RandomState(3)
+    img = lambda: Image.fromarray(rng.randint(0, 256, (224, 224, 3), dtype=np.uint8))
+    g = torch.Generator().manual_seed(11)
+    base = {k: v for k, v in common.items() if k not in ("output_type", "prompt_embeds", "pooled_prompt_embeds")}
+    pe = lambda: torch.randn(1, 77, cfg.cross_attention_dim, generator=g).half()
+    pool = lambda: torch.randn(1, 128, generator=g).half()
+    lat = lambda n: torch.randn(n, 4, 16, 16, generator=g).half()
+    reqs = [dict(base, prompt_embeds=pe(), pooled_prompt_embeds=pool(), latents=lat(1), ip_images=[img()],
+                 ip_bbox=[[0.1, 0.1, 0.6, 0.9]], dialog_bbox=[[0.0, 0.0, 0.3, 0.2]], ip_scale=0.6),
+            dict(base, prompt_embeds=pe(), pooled_prompt_embeds=pool(), latents=lat(2), num_samples=2, ip_images=[],
+                 ip_bbox=[], dialog_bbox=[], ip_scale=0.6),
+            dict(base, prompt_embeds=pe(), pooled_prompt_embeds=pool(), latents=lat(1), ip_images=[img(), img()],
+                 ip_bbox=[[0.0, 0.0, 0.5, 1.0], [0.5, 0.0, 1.0, 1.0]], dialog_bbox=[], ip_scale=0.6)]
+    clone = lambda r: {k: (v.clone() if torch.is_tensor(v) else (list(v) if isinstance(v, list) else v)) for k, v in r.items()}
+    single = [p(output_type="latent", **clone(r)).images for r in reqs]
+    b = BucketBatcher(p, max_panels=8)
+    for r in reqs:
+        b.submit(**clone(r))
+    outs = b.run(output_type="latent")
+    assert b.last_plan == [[0, 1, 2]] and p.last_run_info["batch"] == 8     # 4 panels x CFG in one plan
+    for s_, o in zip(single, outs):
+        assert o.shape == s_.shape
+        assert _rel(o, s_) <= 2e-3, _rel(o, s_)
+    with pytest.raises(ValueError):
+        p.generate_batch([clone(reqs[0]), dict(clone(reqs[1]), height=256, width=256)])
+
+
 def test_mllm_handoff_ip_image_embeds(pipe):
     p, cfg, sd, rs, clip, mae, common = pipe
     g = torch.Generator().manual_seed(2)
