@@ -17,7 +17,7 @@ pixel count, no data-path collective) and run one batcher per rank.
 """
 from __future__ import annotations
 
-from typing import Any, Dict, List, Tuple
+from typing import Any, Dict, List, Optional, Tuple
 
 
 def bucket_key(request: dict) -> Tuple:
@@ -26,9 +26,10 @@ def bucket_key(request: dict) -> Tuple:
             float(request.get("guidance_scale", 5.0)), float(request.get("ip_scale", 1.0)))
 
 
-def plan_batches(requests: List[dict], max_panels: int) -> List[List[int]]:
+def plan_batches(requests: List[dict], max_panels: int, max_pixels: Optional[int] = None) -> List[List[int]]:
     """Indices of `requests` grouped into batches: same bucket, at most `max_panels` panels (sum of num_samples) per
-    batch, submission order kept inside a bucket, buckets ordered by decreasing pixel count (the long jobs first)."""
+    batch - and at most `max_pixels` output pixels if given, so small resolutions get proportionally larger batches -
+    submission order kept inside a bucket, buckets ordered by decreasing pixel count (the long jobs first)."""
     if max_panels < 1:
         raise ValueError("max_panels must be >= 1")
     buckets: Dict[Tuple, List[int]] = {}
@@ -37,12 +38,15 @@ def plan_batches(requests: List[dict], max_panels: int) -> List[List[int]]:
     order = sorted(buckets, key=lambda k: -((k[0] or 0) * (k[1] or 0)))
     batches: List[List[int]] = []
     for k in order:
+        cap = max_panels
+        if max_pixels is not None and k[0] and k[1]:
+            cap = max(1, min(max_panels, max_pixels // (k[0] * k[1])))
         cur, panels = [], 0
         for i in buckets[k]:
             n = int(requests[i].get("num_samples", 1) or 1)
-            if n > max_panels:
-                raise ValueError(f"request {i}: num_samples {n} exceeds max_panels {max_panels}")
-            if cur and panels + n > max_panels:
+            if n > cap:
+                raise ValueError(f"request {i}: num_samples {n} exceeds the batch cap {cap} of its bucket")
+            if cur and panels + n > cap:
                 batches.append(cur)
                 cur, panels = [], 0
             cur.append(i)
@@ -55,9 +59,10 @@ def plan_batches(requests: List[dict], max_panels: int) -> List[List[int]]:
 class BucketBatcher:
     """Collects requests, then runs them bucket by bucket through `pipe.generate_batch`."""
 
-    def __init__(self, pipe, max_panels: int = 16):
+    def __init__(self, pipe, max_panels: int = 16, max_pixels: Optional[int] = None):
         self.pipe = pipe
         self.max_panels = max_panels
+        self.max_pixels = max_pixels
         self._pending: List[dict] = []
         self.last_plan: List[List[int]] = []
 
@@ -74,7 +79,7 @@ class BucketBatcher:
     def run(self, output_type: str = "pil") -> List[Any]:
         """Run everything queued; returns the per-request outputs indexed by ticket and empties the queue."""
         reqs, self._pending = self._pending, []
-        self.last_plan = plan_batches(reqs, self.max_panels)
+        self.last_plan = plan_batches(reqs, self.max_panels, self.max_pixels)
         results: List[Any] = [None] * len(reqs)
         for batch in self.last_plan:
             outs = self.pipe.generate_batch([reqs[i] for i in batch], output_type=output_type)
