@@ -21,7 +21,7 @@
 #include "ds_common.h"
 #include "ds_kernels.h"
 
-static int g_gemm_variant = 0;  // 0 auto; A/B: 1 register staging, 2 two-buffer glds, 8/9 one-buffer glds (BM 128/64), 7 BM 64, 4 ring, 5/6 producer-consumer
+static int g_gemm_variant = 0;  // 0 auto; A/B: 1 register staging, 2 two-buffer glds, 3 ping-pong 256x256, 7 two-buffer BM 64, 8/9 one-buffer glds (BM 128/64), 10 halo conv
 void ds_gemm_set_variant(int v) { g_gemm_variant = v; }
 static int g_gemm_debug = 0;  // ablation switches, see GemmParams::debug
 void ds_gemm_set_debug(int v) { g_gemm_debug = v; }
@@ -336,466 +336,6 @@ __global__ __launch_bounds__(256, (BM > 128 ? 1 : (STAGES == 1 ? (BM == 64 ? 4 :
     epilogue<BM, BM / 2, 256>(p, acc, smem, m0, n0, bz, wm, wn, l31, lhi, tid);
 }
 
-// ---------------------------------------------------------------------------------------------- 8-wave, 3-stage ring
-// Tile 256 x 128 x 64, 512 threads = 8 waves (4 along M x 2 along N, 64x64 per wave, two waves per SIMD), one block
-// per CU.  Three LDS stages (3 x 48 KiB): the DMA of tile t+2 is issued while tile t is multiplied, and the wait is
-// COUNTED — s_waitcnt vmcnt(6) retires exactly the oldest tile (6 LDS-DMA pieces per wave per tile) and leaves the
-// next one in flight across the barrier.  A raw s_barrier is used: __syncthreads() would drain vmcnt to 0.
-template <bool CONV>
-__global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const GemmParams p) {
-    constexpr int BM = 256, ASEG = 4, BSEG = 2, STAGE = (BM + BN) * 128;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    typedef __attribute__((address_space(3))) void lds_void;
-    typedef const __attribute__((address_space(1))) void glb_void;
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    int tm, tn;
-    tile_coords(tile, p.tiles_m, p.tiles_n, tm, tn);
-    const int m0 = tm * BM, n0 = tn * BN;
-    const long bz = blockIdx.z;
-    const int lrow = lane >> 3, slot = lane & 7;
-
-    const half_t* a1[ASEG];
-    const half_t* a2[ASEG];
-    int a_pb[ASEG], a_oy[ASEG], a_ox[ASEG], a_ch[ASEG];
-#pragma unroll
-    for (int j = 0; j < ASEG; ++j) {
-        const int row = (wave * ASEG + j) * 8 + lrow;
-        const int chunk = slot ^ ((row >> 1) & 7);
-        const int m = min(m0 + row, p.M - 1);
-        a_ch[j] = chunk * 8;
-        if constexpr (CONV) {
-            const int hw = p.Hout * p.Wout;
-            const int b = m / hw, rem = m - b * hw;
-            a_oy[j] = rem / p.Wout;
-            a_ox[j] = rem - a_oy[j] * p.Wout;
-            a_pb[j] = b * p.Hin * p.Win;
-            a1[j] = a2[j] = p.A;
-        } else {
-            a1[j] = p.A + bz * p.sA + (long)m * p.lda + chunk * 8;
-            a2[j] = p.A2 ? p.A2 + bz * p.sA2 + (long)m * p.lda2 + chunk * 8 : a1[j];
-            a_pb[j] = a_oy[j] = a_ox[j] = 0;
-        }
-    }
-    const half_t* wrow[BSEG];
-#pragma unroll
-    for (int j = 0; j < BSEG; ++j) {
-        const int row = (wave * BSEG + j) * 8 + lrow;
-        const int chunk = slot ^ ((row >> 1) & 7);
-        const int n = min(n0 + row, p.N - 1);
-        wrow[j] = p.W + bz * p.sW + (long)n * p.ldw + chunk * 8;
-    }
-
-    auto issue = [&](int kt, int stage) {
-        const int k0 = kt * BK;
-        char* dA = smem + stage * STAGE + wave * ASEG * 1024;
-        char* dB = smem + stage * STAGE + BM * 128 + wave * BSEG * 1024;
-        if constexpr (CONV) {
-            const int tap = k0 / p.Cin;
-            const int ci0 = k0 - tap * p.Cin;
-            const int ky = tap / 3, kx = tap - 3 * ky;
-#pragma unroll
-            for (int j = 0; j < ASEG; ++j) {
-                int iy, ix;
-                bool ok;
-                if (p.upsample) {
-                    const int uy = a_oy[j] + ky - 1, ux = a_ox[j] + kx - 1;
-                    ok = (uy >= 0) & (uy < p.Hout) & (ux >= 0) & (ux < p.Wout);
-                    iy = uy >> 1;
-                    ix = ux >> 1;
-                } else {
-                    iy = a_oy[j] * p.cstride + ky - 1;
-                    ix = a_ox[j] * p.cstride + kx - 1;
-                    ok = (iy >= 0) & (iy < p.Hin) & (ix >= 0) & (ix < p.Win);
-                }
-                const long off = ((long)a_pb[j] + (long)iy * p.Win + ix) * p.Cin + ci0 + a_ch[j];
-                const void* src = ok ? (const void*)(p.A + off) : (const void*)g_zero_page;
-                __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(dA + j * 1024), 16, 0, 0);
-            }
-        } else {
-            const bool first = k0 < p.K1;
-#pragma unroll
-            for (int j = 0; j < ASEG; ++j) {
-                const half_t* src = first ? a1[j] + k0 : a2[j] + (k0 - p.K1);
-                __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(dA + j * 1024), 16, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < BSEG; ++j)
-            __builtin_amdgcn_global_load_lds((glb_void*)(wrow[j] + k0), (lds_void*)(dB + j * 1024), 16, 0, 0);
-    };
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int nk = p.K / BK;
-    const int l31 = lane & 31, lhi = lane >> 5;
-    issue(0, 0);
-    if (nk > 1) issue(1, 1);
-    int stage = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        // retire tile kt (oldest); tile kt+1, if any, stays in flight across the barrier
-        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // every wave's pieces of tile kt landed; every wave is done with tile kt-1
-        if (kt + 2 < nk) issue(kt + 2, stage == 0 ? 2 : stage - 1);  // (kt+2)%3 == (kt-1)%3: the stage just released
-        const char* base = smem + stage * STAGE;
-        mma_tile<64>(base, base + BM * 128, acc, wm, wn, l31, lhi);
-        stage = stage == 2 ? 0 : stage + 1;
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __syncthreads();
-    epilogue<BM, 64, 512>(p, acc, smem, m0, n0, bz, wm, wn, l31, lhi, tid);
-}
-
-// ---------------------------------------------------------------------------------------------- producer / consumer
-// Measured on MI355X (profiles/r01_pmc_ff1gemm_*): a CU sustains only ~22 B/clk of L2->LDS tile traffic however the
-// loads are issued, and LDS-DMA instructions are slow to ISSUE, so (a) the tile a CU works on must be as large as
-// LDS allows and (b) the waves that feed the matrix pipe must never issue VMEM.  Hence: tile 256 x BNT x 64,
-// 12 waves = 8 CONSUMER waves (4 x 2, each 64 x BNT/2, ds_read + MFMA only, two per SIMD) + 4 PRODUCER waves (one
-// per SIMD) that do nothing but issue global_load_lds for the tile(s) ahead and wait for them.  One raw s_barrier per
-// k-tile hands a landed stage to the consumers and a drained stage back to the producers.
-// BNT = 256: 2 stages x 64 KiB (128 flop/B of tile traffic);  BNT = 128: 3 stages x 48 KiB (85 flop/B).
-template <int BNT, bool CONV>
-__global__ __launch_bounds__(768, 3) void gemm_ws_kernel(const GemmParams p) {
-    constexpr int BM = 256;
-    constexpr int WC = BNT / 2, NI = WC / 32;
-    constexpr int STAGES = BNT == 256 ? 2 : 3;
-    constexpr int STAGE = (BM + BNT) * 128;
-    constexpr int ASEG = 8, BSEG = BNT / 32;  // 1-KiB DMA pieces per producer wave per k-tile
-    constexpr int NPIECE = ASEG + BSEG;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    typedef __attribute__((address_space(3))) void lds_void;
-    typedef const __attribute__((address_space(1))) void glb_void;
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    int tm, tn;
-    tile_coords(tile, p.tiles_m, p.tiles_n, tm, tn);
-    const int m0 = tm * BM, n0 = tn * BNT;
-    const long bz = blockIdx.z;
-    const int nk = p.K / BK;
-    const int l31 = lane & 31, lhi = lane >> 5;
-    const int wm = (wave & 7) >> 1, wn = wave & 1;  // consumer grid 4 x 2
-    constexpr int NPASS = 2 * (BNT / 128);          // epilogue passes (two barriers each)
-
-    if (wave >= 8) {
-        // ================================================================ producer
-        const int pw = wave - 8;
-        const int lrow = lane >> 3, slot = lane & 7;
-        const half_t* a1[ASEG];
-        const half_t* a2[ASEG];
-        int a_pb[ASEG], a_oy[ASEG], a_ox[ASEG], a_ch[ASEG];
-#pragma unroll
-        for (int j = 0; j < ASEG; ++j) {
-            const int row = (pw * ASEG + j) * 8 + lrow;
-            const int chunk = slot ^ ((row >> 1) & 7);
-            const int m = min(m0 + row, p.M - 1);
-            a_ch[j] = chunk * 8;
-            if constexpr (CONV) {
-                const int hw = p.Hout * p.Wout;
-                const int b = m / hw, rem = m - b * hw;
-                a_oy[j] = rem / p.Wout;
-                a_ox[j] = rem - a_oy[j] * p.Wout;
-                a_pb[j] = b * p.Hin * p.Win;
-                a1[j] = a2[j] = p.A;
-            } else {
-                a1[j] = p.A + bz * p.sA + (long)m * p.lda + chunk * 8;
-                a2[j] = p.A2 ? p.A2 + bz * p.sA2 + (long)m * p.lda2 + chunk * 8 : a1[j];
-                a_pb[j] = a_oy[j] = a_ox[j] = 0;
-            }
-        }
-        const half_t* wrow[BSEG];
-#pragma unroll
-        for (int j = 0; j < BSEG; ++j) {
-            const int row = (pw * BSEG + j) * 8 + lrow;
-            const int chunk = slot ^ ((row >> 1) & 7);
-            const int n = min(n0 + row, p.N - 1);
-            wrow[j] = p.W + bz * p.sW + (long)n * p.ldw + chunk * 8;
-        }
-        auto issue = [&](int kt, int stage) {
-            const int k0 = kt * BK;
-            char* dA = smem + stage * STAGE + pw * ASEG * 1024;
-            char* dB = smem + stage * STAGE + BM * 128 + pw * BSEG * 1024;
-            if constexpr (CONV) {
-                const int tap = k0 / p.Cin;
-                const int ci0 = k0 - tap * p.Cin;
-                const int ky = tap / 3, kx = tap - 3 * ky;
-#pragma unroll
-                for (int j = 0; j < ASEG; ++j) {
-                    int iy, ix;
-                    bool ok;
-                    if (p.upsample) {
-                        const int uy = a_oy[j] + ky - 1, ux = a_ox[j] + kx - 1;
-                        ok = (uy >= 0) & (uy < p.Hout) & (ux >= 0) & (ux < p.Wout);
-                        iy = uy >> 1;
-                        ix = ux >> 1;
-                    } else {
-                        iy = a_oy[j] * p.cstride + ky - 1;
-                        ix = a_ox[j] * p.cstride + kx - 1;
-                        ok = (iy >= 0) & (iy < p.Hin) & (ix >= 0) & (ix < p.Win);
-                    }
-                    const long off = ((long)a_pb[j] + (long)iy * p.Win + ix) * p.Cin + ci0 + a_ch[j];
-                    const void* src = ok ? (const void*)(p.A + off) : (const void*)g_zero_page;
-                    __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(dA + j * 1024), 16, 0, 0);
-                }
-            } else {
-                const bool first = k0 < p.K1;
-#pragma unroll
-                for (int j = 0; j < ASEG; ++j) {
-                    const half_t* src = first ? a1[j] + k0 : a2[j] + (k0 - p.K1);
-                    __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(dA + j * 1024), 16, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < BSEG; ++j)
-                __builtin_amdgcn_global_load_lds((glb_void*)(wrow[j] + k0), (lds_void*)(dB + j * 1024), 16, 0, 0);
-        };
-        // prologue: fill the ring, hand tile 0 over
-        issue(0, 0);
-        if (STAGES == 3 && nk > 1) {
-            issue(1, 1);
-            if constexpr (NPIECE == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        int stage = STAGES - 1;  // stage that receives tile kt + STAGES - 1
-        for (int kt = 0; kt < nk; ++kt) {
-            const int nxt = kt + STAGES - 1;
-            if (nxt < nk && !(p.debug & 2)) issue(nxt, stage);
-            // tile kt+1 must have landed before the consumers are released into iteration kt+1
-            if (STAGES == 3 && nxt < nk) {
-                if constexpr (NPIECE == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            stage = stage + 1 == STAGES ? 0 : stage + 1;
-        }
-        // producers own no accumulators; with the LDS-staged epilogue they only keep its barriers company
-        if constexpr (BNT != 256) {
-#pragma unroll
-            for (int q = 0; q < NPASS; ++q) {
-                __syncthreads();
-                __syncthreads();
-            }
-        }
-        return;
-    }
-    // ================================================================ consumer (waves 0..7 = threads 0..511)
-    f32x16 acc[2][NI];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    {
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        int stage = 0;
-        for (int kt = 0; kt < nk; ++kt) {
-            const char* base = smem + stage * STAGE;
-            if (!(p.debug & 1)) mma_tile<64, WC>(base, base + BM * 128, acc, wm, wn, l31, lhi);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            stage = stage + 1 == STAGES ? 0 : stage + 1;
-        }
-    }
-
-    if constexpr (BNT == 256) {
-        // ---- register epilogue: a consumer wave owns 64 rows x 128 columns = exactly one packed GEGLU tile (hidden
-        // columns in fragments ni = 0,1, their gates in ni = 2,3 of the SAME lane), so bias / activation / residual /
-        // GEGLU all happen in registers and each lane stores 8-byte row pieces.  No LDS, no barrier, no spill.
-        half_t* Cg = p.C + bz * p.sC;
-        const half_t* Rg = p.residual ? p.residual + bz * p.sR : nullptr;
-        const int nw = n0 + wn * 128;  // first column of this wave
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-            const int m = m0 + wm * 64 + mi * 32 + l31;
-            const bool m_ok = m < p.M;
-            const int grp = p.rowbias ? ((m_ok ? m : p.M - 1) / p.rows_per_group) : 0;
-            auto value = [&](int ni, int g, float (&v)[4]) {  // acc + bias (+ per-image bias), rounded to f16
-                const int n = nw + ni * 32 + 8 * g + 4 * lhi;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][4 * g + e];
-                if (n < p.N) {
-                    if (p.bias) {
-                        const h4 bv = *reinterpret_cast<const h4*>(p.bias + n);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += (float)bv[e];
-                    }
-                    if (p.rowbias) {
-                        const h4 bv = *reinterpret_cast<const h4*>(p.rowbias + (long)grp * p.rowbias_ld + n);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += (float)bv[e];
-                    }
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = (float)(half_t)v[e];
-            };
-            if (p.epi == EPI_GEGLU) {
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        float hv[4], gv[4];
-                        value(ni, g, hv);
-                        value(ni + 2, g, gv);
-                        const int n = (nw >> 1) + ni * 32 + 8 * g + 4 * lhi;
-                        if (m_ok && n < (p.N >> 1)) {
-                            h4 o;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) o[e] = (half_t)(hv[e] * (float)(half_t)ds_gelu_erf(gv[e]));
-                            *reinterpret_cast<h4*>(Cg + (long)m * p.ldc + n) = o;
-                        }
-                    }
-            } else {
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        float v[4];
-                        value(ni, g, v);
-                        const int n = nw + ni * 32 + 8 * g + 4 * lhi;
-                        if (m_ok && n < p.N) {
-                            if (p.epi == EPI_GELU) {
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) v[e] = (float)(half_t)ds_gelu_erf(v[e]);
-                            } else if (p.epi == EPI_QUICK_GELU) {
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) v[e] = (float)(half_t)(v[e] / (1.0f + __expf(-1.702f * v[e])));
-                            }
-                            if (Rg) {
-                                const h4 rv = *reinterpret_cast<const h4*>(Rg + (long)m * p.ldr + n);
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
-                            }
-                            h4 o;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) o[e] = (half_t)v[e];
-                            *reinterpret_cast<h4*>(Cg + (long)m * p.ldc + n) = o;
-                        }
-                    }
-            }
-        }
-        return;
-    }
-
-    // ---- epilogue: (256 / 128) x (BNT / 128) passes of a 128 x 128 staging tile; consumers park, 512 threads store
-    char* sC = smem;
-    half_t* Cg = p.C + bz * p.sC;
-    const half_t* Rg = p.residual ? p.residual + bz * p.sR : nullptr;
-#pragma unroll
-    for (int hm = 0; hm < 2; ++hm) {
-#pragma unroll
-        for (int hn = 0; hn < BNT / 128; ++hn) {
-            __syncthreads();
-            const bool mine = wave < 8 && (wm >> 1) == hm && (BNT == 128 || wn == hn);
-            if (mine) {
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi) {
-                    const int ms = (wm & 1) * 64 + mi * 32 + l31;
-                    const int m = m0 + hm * 128 + ms;
-                    const int grp = p.rowbias ? ((m < p.M ? m : p.M - 1) / p.rows_per_group) : 0;
-#pragma unroll
-                    for (int ni = 0; ni < NI; ++ni) {
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const int nl = (BNT == 128 ? wn * 64 : 0) + ni * 32 + 8 * g + 4 * lhi;
-                            const int n = n0 + hn * 128 + nl;
-                            float v[4];
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][4 * g + e];
-                            if (n < p.N) {
-                                if (p.bias) {
-                                    const h4 bv = *reinterpret_cast<const h4*>(p.bias + n);
-#pragma unroll
-                                    for (int e = 0; e < 4; ++e) v[e] += (float)bv[e];
-                                }
-                                if (p.rowbias) {
-                                    const h4 bv = *reinterpret_cast<const h4*>(p.rowbias + (long)grp * p.rowbias_ld + n);
-#pragma unroll
-                                    for (int e = 0; e < 4; ++e) v[e] += (float)bv[e];
-                                }
-                            }
-                            h4 o;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) o[e] = (half_t)v[e];
-                            *reinterpret_cast<h4*>(sC + ms * CS_STRIDE + nl * 2) = o;
-                        }
-                    }
-                }
-            }
-            __syncthreads();
-            if (tid < 512) {
-                const int mh = m0 + hm * 128, nh = n0 + hn * 128;
-                if (p.epi == EPI_GEGLU) {
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const int id = tid + 512 * j;
-                        const int row = id >> 3, c = id & 7;
-                        const int m = mh + row, n = (nh >> 1) + c * 8;
-                        if (m < p.M && n < (p.N >> 1)) {
-                            const h8 hv = *reinterpret_cast<const h8*>(sC + row * CS_STRIDE + c * 16);
-                            const h8 gv = *reinterpret_cast<const h8*>(sC + row * CS_STRIDE + 128 + c * 16);
-                            h8 o;
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) {
-                                const half_t ge = (half_t)ds_gelu_erf((float)gv[e]);
-                                o[e] = (half_t)((float)hv[e] * (float)ge);
-                            }
-                            *reinterpret_cast<h8*>(Cg + (long)m * p.ldc + n) = o;
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int id = tid + 512 * j;
-                        const int row = id >> 4, c = id & 15;
-                        const int m = mh + row, n = nh + c * 8;
-                        if (m < p.M && n < p.N) {
-                            h8 v = *reinterpret_cast<const h8*>(sC + row * CS_STRIDE + c * 16);
-                            if (p.epi == EPI_GELU) {
-#pragma unroll
-                                for (int e = 0; e < 8; ++e) v[e] = (half_t)ds_gelu_erf((float)v[e]);
-                            } else if (p.epi == EPI_QUICK_GELU) {
-#pragma unroll
-                                for (int e = 0; e < 8; ++e) {
-                                    const float f = (float)v[e];
-                                    v[e] = (half_t)(f / (1.0f + __expf(-1.702f * f)));
-                                }
-                            }
-                            if (Rg) {
-                                const h8 rv = *reinterpret_cast<const h8*>(Rg + (long)m * p.ldr + n);
-#pragma unroll
-                                for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rv[e]);
-                            }
-                            *reinterpret_cast<h8*>(Cg + (long)m * p.ldc + n) = v;
-                        }
-                    }
-                }
-            }
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------- register staging
 template <int BM, bool CONV>
 __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const GemmParams p) {
@@ -958,46 +498,10 @@ int launch_glds1(const GemmParams& p0, int batch, hipStream_t stream) {
     return 0;
 }
 
-template <bool CONV>
-int launch_ring(const GemmParams& p0, int batch, hipStream_t stream) {
-    GemmParams p = p0;
-    p.tiles_m = (p.M + 255) / 256;
-    p.tiles_n = (p.N + BN - 1) / BN;
-    const size_t lds = 3 * (256 + BN) * 128;
-    static bool attr_set = false;
-    if (!attr_set) {
-        DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring_kernel<CONV>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
-    dim3 grid(p.tiles_m * p.tiles_n, 1, batch);
-    hipLaunchKernelGGL(gemm_ring_kernel<CONV>, grid, dim3(512), lds, stream, p);
-    DS_LAUNCH_CHECK();
-    return 0;
-}
-
-template <int BNT, bool CONV>
-int launch_ws(const GemmParams& p0, int batch, hipStream_t stream) {
-    GemmParams p = p0;
-    p.tiles_m = (p.M + 255) / 256;
-    p.tiles_n = (p.N + BNT - 1) / BNT;
-    const size_t lds = (BNT == 256 ? 2 : 3) * (256 + BNT) * 128;
-    static bool attr_set = false;
-    if (!attr_set) {
-        DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ws_kernel<BNT, CONV>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
-    dim3 grid(p.tiles_m * p.tiles_n, 1, batch);
-    hipLaunchKernelGGL((gemm_ws_kernel<BNT, CONV>), grid, dim3(768), lds, stream, p);
-    DS_LAUNCH_CHECK();
-    return 0;
-}
-
-enum Kind { K_REG, K_GLDS2, K_GLDS1, K_RING, K_WS, K_PP, K_HALO };
+enum Kind { K_REG, K_GLDS2, K_GLDS1, K_PP, K_HALO };
 struct Choice {
     Kind kind;
-    int bm;   // rows of the block tile (K_WS: BNT)
+    int bm;   // rows of the block tile
 };
 
 // Dispatch (measured on MI355X, profiles/r01_gemm_variants_microbench.txt).  What pays on this chip is the number of
@@ -1008,7 +512,6 @@ struct Choice {
 // g_gemm_variant != 0 forces one family for A/B runs.
 Choice choose(const GemmParams& p, int batch) {
     const long tiles128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * batch;
-    const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 127) / 128) * batch;
     const bool conv = p.conv != 0;
     const bool small = tiles128 < 384 || p.M <= 64;
     const bool dma_ok = p.K % 64 == 0;
@@ -1032,17 +535,6 @@ Choice choose(const GemmParams& p, int batch) {
         case 7: c.kind = K_GLDS2; c.bm = 64; return c;
         case 8: c.kind = K_GLDS1; return c;
         case 9: c.kind = K_GLDS1; c.bm = 64; return c;
-        case 4:
-            if (tiles256 >= 192 && p.K >= 128) { c.kind = K_RING; c.bm = 256; return c; }
-            break;
-        case 5: {
-            const long t = (long)((p.M + 255) / 256) * ((p.N + 255) / 256) * batch;
-            if (t >= 128 && p.K >= 128) { c.kind = K_WS; c.bm = 256; return c; }
-            break;
-        }
-        case 6:
-            if (tiles256 >= 192 && p.K >= 128) { c.kind = K_WS; c.bm = 128; return c; }
-            break;
         default: break;
     }
     if (g_gemm_variant != 0) {  // forced family did not apply to this shape
@@ -1081,10 +573,6 @@ const char* ds_gemm_kernel_name(const GemmParams& p, int batch) {
     switch (c.kind) {
         case K_PP: return "gemm_pp_kernel<0>";
         case K_HALO: return "conv_halo_kernel";
-        case K_WS:
-            if (c.bm == 256) return conv ? "gemm_ws_kernel<256,true>" : "gemm_ws_kernel<256,false>";
-            return conv ? "gemm_ws_kernel<128,true>" : "gemm_ws_kernel<128,false>";
-        case K_RING: return conv ? "gemm_ring_kernel<true>" : "gemm_ring_kernel<false>";
         case K_GLDS1:
             if (c.bm == 128) return conv ? "gemm_glds_kernel<128,true,1>" : "gemm_glds_kernel<128,false,1>";
             return conv ? "gemm_glds_kernel<64,true,1>" : "gemm_glds_kernel<64,false,1>";
@@ -1126,10 +614,6 @@ int ds_launch_gemm(const GemmParams& p_in, int batch, hipStream_t stream) {
     switch (c.kind) {
         case K_PP: return ds_launch_gemm_pp(p, batch, stream);
         case K_HALO: return ds_launch_conv_halo(p, stream);
-        case K_WS:
-            if (c.bm == 256) return conv ? launch_ws<256, true>(p, batch, stream) : launch_ws<256, false>(p, batch, stream);
-            return conv ? launch_ws<128, true>(p, batch, stream) : launch_ws<128, false>(p, batch, stream);
-        case K_RING: return conv ? launch_ring<true>(p, batch, stream) : launch_ring<false>(p, batch, stream);
         case K_GLDS1:
             if (c.bm == 128)
                 return conv ? launch_glds1<128, true>(p, batch, stream) : launch_glds1<128, false>(p, batch, stream);

@@ -28,7 +28,8 @@ const char* ds_last_error(void);
 int ds_version(void);
 /* number of HIP devices visible / properties of the current one (sanity for loaders) */
 int ds_device_info(int* cu_count, int* lds_bytes, char* arch_name, int arch_name_len);
-/* tuning knobs (process-wide): "gemm_variant" = 0 auto | 1 register-staged only | 2 LDS-DMA, BM<=128 | 3 LDS-DMA, BM=256 */
+/* tuning knobs (process-wide): "gemm_variant" = 0 auto | 1 register-staged only | 2, 7 two-buffer LDS-DMA | 8, 9 one-buffer
+ * LDS-DMA | 3 256x256 ping-pong | 10 halo-patch conv (A/B runs; 0 in production) */
 int ds_set_option(const char* key, int value);
 
 /* ------------------------------------------------------------------------------------------------
