@@ -208,7 +208,195 @@ __global__ __launch_bounds__(256, 3) void conv_halo_kernel(const GemmParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Large-batch variant: 16 x 16 output pixels (M tile = 256) x 128 channels per block.  The 8 x 16 kernel above still
+// moves 36 B/clk/CU through L2 -> LDS (its W tile serves only 128 pixels), i.e. it sits on the same fill limit as the
+// 128 x 128 GEMMs; doubling the pixels per W tile takes that to 20 B/clk/CU (204 flop/B).  Waves 2 x 2, each
+// 128 pixels x 64 channels (acc 128 VGPRs, 0.75 KiB of fragment reads per MFMA instead of 1).  LDS: 18 x 18 halo patch
+// 44 KiB + TWO W buffers (the next k-tile's W is in flight under the current tile's MFMAs, one barrier per k-tile) =
+// 76 KiB -> two blocks per CU.  The patch is single-buffered: at a slice boundary the block waits for the new patch
+// while the co-resident block computes.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int PH2 = 16;
+constexpr int HROWS2 = (PH2 + 2) * HWD;   // 324 patch pixels
+constexpr int NPIECE2 = (HROWS2 + 7) / 8;  // 41 LDS-DMA pieces of 8 rows
+constexpr int PPW2 = (NPIECE2 + 3) / 4;    // 11 per wave
+constexpr int PBYTES2 = PPW2 * 4 * 1024;   // 44 KiB
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void conv_halo256_kernel(const GemmParams p) {
+    typedef typename Elt<T>::v8 V8;
+    typedef typename Elt<T>::v4 V4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const sP = smem;
+    char* const sW = smem + PBYTES2;  // two buffers of BN * 128 bytes
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int lrow = lane >> 3, slot = lane & 7;
+
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    int tm, tn;
+    tile_coords(tile, p.tiles_m, p.tiles_n, tm, tn);
+    const int tiles_x = p.Wout / PW, tiles_y = p.Hout / PH2;
+    const int tx = tm % tiles_x, ty = (tm / tiles_x) % tiles_y, b = tm / (tiles_x * tiles_y);
+    const int oy0 = ty * PH2, ox0 = tx * PW, n0 = tn * BN;
+
+    int poff[PPW2];  // element offset of the lane's chunk at channel 0; -1: zero page (halo / pad rows)
+#pragma unroll
+    for (int j = 0; j < PPW2; ++j) {
+        const int q = (wave * PPW2 + j) * 8 + lrow;
+        const int qy = q / HWD, qx = q - qy * HWD;
+        const int uy = oy0 - 1 + qy, ux = ox0 - 1 + qx;
+        const bool ok = (q < HROWS2) & (uy >= 0) & (uy < p.Hout) & (ux >= 0) & (ux < p.Wout);
+        const int iy = p.upsample ? uy >> 1 : uy, ix = p.upsample ? ux >> 1 : ux;
+        const int chunk = slot ^ ((q >> 1) & 7);
+        poff[j] = ok ? ((b * p.Hin + iy) * p.Win + ix) * p.Cin + chunk * 8 : -1;
+    }
+    int woff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = (wave * 4 + j) * 8 + lrow;
+        const int chunk = slot ^ ((row >> 1) & 7);
+        const int n = min(n0 + row, p.N - 1);
+        woff[j] = n * (int)p.ldw + chunk * 8;
+    }
+    auto issue_patch = [&](int ci0) {
+        char* d = sP + wave * PPW2 * 1024;
+#pragma unroll
+        for (int j = 0; j < PPW2; ++j) {
+            if (wave * PPW2 + j >= NPIECE2) continue;  // wave-uniform: the last wave owns fewer pieces
+            const void* src = poff[j] >= 0 ? (const void*)(p.A + poff[j] + ci0) : (const void*)g_halo_zero_page;
+            __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(d + j * 1024), 16, 0, 0);
+        }
+    };
+    auto issue_w = [&](int k0, int buf) {
+        char* d = sW + buf * (BN * 128) + wave * 4 * 1024;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_global_load_lds((glb_void*)(p.W + k0 + woff[j]), (lds_void*)(d + j * 1024), 16, 0, 0);
+    };
+
+    int q0[4];  // GEMM row r = 128 wm + 32 mi + l31  <->  patch pixel (r >> 4, r & 15)
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) q0[mi] = (wm * 8 + mi * 2 + (l31 >> 4)) * HWD + (l31 & 15);
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int slices = p.Cin / 64;
+    const int nkt = slices * 9;
+    issue_patch(0);
+    issue_w(0, 0);
+    int s = 0, tap = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (tap == 0 && kt > 0) {  // every wave is done with the previous slice's patch once it arrives here
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            issue_patch(s * 64);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // W(kt) (and a new patch) have landed
+        __builtin_amdgcn_s_barrier();                      // ... everywhere; and buffer (kt+1)&1 has been drained
+        asm volatile("" ::: "memory");
+        if (kt + 1 < nkt) {
+            const int ntap = tap == 8 ? 0 : tap + 1, ns = tap == 8 ? s + 1 : s;
+            issue_w(ntap * p.Cin + ns * 64, (kt + 1) & 1);
+        }
+        const char* cW = sW + (kt & 1) * (BN * 128);
+        const int ky = tap / 3, kx = tap - 3 * ky;
+        const int shift = ky * HWD + kx;
+        int abase[4];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int q = q0[mi] + shift;
+            abase[mi] = q * 128 + ((lhi ^ ((q >> 1) & 7)) << 4);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            V8 af[4], bf[2];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) af[mi] = *reinterpret_cast<const V8*>(sP + (abase[mi] ^ (kk << 5)));
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const int r = wn * 64 + ni * 32 + l31;
+                bf[ni] = *reinterpret_cast<const V8*>(cW + r * 128 + swz(r, kk * 2 + lhi));
+            }
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = Elt<T>::mfma(bf[ni], af[mi], acc[mi][ni]);
+        }
+        if (tap == 8) {
+            tap = 0;
+            ++s;
+        } else {
+            ++tap;
+        }
+    }
+    __syncthreads();
+
+    // ---- epilogue: as the 8 x 16 kernel, 256 rows
+    char* const sC = smem;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int ms = wm * 128 + mi * 32 + l31;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int nl = wn * 64 + ni * 32 + 8 * g + 4 * lhi;
+                const int n = n0 + nl;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][4 * g + e];
+                if (n < p.N) {
+                    if (p.bias) {
+                        const V4 bv = *reinterpret_cast<const V4*>(p.bias + n);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += (float)bv[e];
+                    }
+                    if (p.rowbias) {
+                        const V4 bv = *reinterpret_cast<const V4*>(p.rowbias + (long)b * p.rowbias_ld + n);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += (float)bv[e];
+                    }
+                }
+                V4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (T)v[e];
+                *reinterpret_cast<V4*>(sC + ms * CS_STRIDE + nl * 2) = o;
+            }
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int j = 0; j < 16; ++j) {
+        const int id = tid + 256 * j;
+        const int row = id >> 4, c = id & 15;
+        const long m = ((long)b * p.Hout + oy0 + (row >> 4)) * p.Wout + ox0 + (row & 15);
+        const int n = n0 + c * 8;
+        if (n < p.N) {
+            V8 v = *reinterpret_cast<const V8*>(sC + row * CS_STRIDE + c * 16);
+            if (p.residual) {
+                const V8 rv = *reinterpret_cast<const V8*>(p.residual + m * p.ldr + n);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (T)((float)v[e] + (float)rv[e]);
+            }
+            *reinterpret_cast<V8*>(p.C + m * p.ldc + n) = v;
+        }
+    }
+}
+
+int g_halo_variant = 0;  // 0 auto, 1 force the 8 x 16 kernel, 2 force the 16 x 16 kernel (where its shape rule holds)
+
 }  // namespace
+
+void ds_conv_halo_set_variant(int v) { g_halo_variant = v; }
 
 // Shapes the kernel takes: stride 1 (optionally the fused x2 upsample), output height % 8 == 0 and width % 16 == 0,
 // Cin % 64 == 0, plain epilogue, and an input small enough for 32-bit element offsets.
@@ -223,8 +411,28 @@ int ds_launch_conv_halo(const GemmParams& p0, hipStream_t stream) {
     GemmParams p = p0;
     DS_REQUIRE(ds_conv_halo_applicable(p), "conv_halo: shape not supported");
     const int batch = p.M / (p.Hout * p.Wout);
-    p.tiles_m = batch * (p.Hout / PH) * (p.Wout / PW);
     p.tiles_n = (p.N + BN - 1) / BN;
+    // 16 x 16 patches once they still fill the chip twice over (two blocks per CU): large batches / resolutions
+    const long tiles256 = (long)batch * (p.Hout / PH2) * (p.Wout / PW) * p.tiles_n;
+    const bool big = p.Hout % PH2 == 0 && (g_halo_variant == 2 || (g_halo_variant == 0 && tiles256 >= 1024));
+    if (big) {
+        p.tiles_m = batch * (p.Hout / PH2) * (p.Wout / PW);
+        const size_t lds2 = PBYTES2 + 2 * BN * 128;  // 76 KiB; the 256 x 272 B epilogue tile fits inside
+        static bool attr_set = false;
+        if (!attr_set) {
+            DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo256_kernel<half_t>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+            DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo256_kernel<bf16_t>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+            attr_set = true;
+        }
+        dim3 grid2(p.tiles_m * p.tiles_n);
+        if (p.dtype == DS_DTYPE_BF16) hipLaunchKernelGGL(conv_halo256_kernel<bf16_t>, grid2, dim3(256), lds2, stream, p);
+        else hipLaunchKernelGGL(conv_halo256_kernel<half_t>, grid2, dim3(256), lds2, stream, p);
+        DS_LAUNCH_CHECK();
+        return 0;
+    }
+    p.tiles_m = batch * (p.Hout / PH) * (p.Wout / PW);
     const size_t lds = PROWS * 128 + BN * 128;  // 40 KiB; the 128 x 272 B epilogue tile fits inside
     dim3 grid(p.tiles_m * p.tiles_n);
     if (p.dtype == DS_DTYPE_BF16) hipLaunchKernelGGL(conv_halo_kernel<bf16_t>, grid, dim3(256), lds, stream, p);
