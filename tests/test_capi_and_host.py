@@ -156,3 +156,20 @@ def test_plan_builds_on_host_for_tiny_config(hip_lib):
     assert pk.temb_total == sum(r.cout for r in pk.resnets)
     with pytest.raises(ValueError):
         UNetEngine(pk, 2, 18, 16)
+
+
+def test_committed_bench_line_follows_the_contract():
+    """The round-end bench line kept under profiles/ carries every key the driver's contract names."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01_bench_default_ns16_final.json")
+    line = json.loads(open(path).read().strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["unit"] == "panels/s" and line["higher_is_better"] is True and line["scaling"] == "weak"
+    assert "workload" in line["config"] and "model" not in line["config"]
+    r = line["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["traffic"]
+    c = line["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
