@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256, 3) void conv_halo_kernel(const GemmParams p) {
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     int tm, tn;
     tile_coords(tile, p.tiles_m, p.tiles_n, tm, tn);
-    const int tiles_x = p.Wout / PW, tiles_y = p.Hout / PH;
+    const int tiles_x = (p.Wout + PW - 1) / PW, tiles_y = (p.Hout + PH - 1) / PH;  // ragged edges: masked stores
     const int tx = tm % tiles_x, ty = (tm / tiles_x) % tiles_y, b = tm / (tiles_x * tiles_y);
     const int oy0 = ty * PH, ox0 = tx * PW, n0 = tn * BN;
 
@@ -194,9 +194,10 @@ __global__ __launch_bounds__(256, 3) void conv_halo_kernel(const GemmParams p) {
     for (int j = 0; j < 8; ++j) {
         const int id = tid + 256 * j;
         const int row = id >> 4, c = id & 15;
-        const long m = ((long)b * p.Hout + oy0 + (row >> 4)) * p.Wout + ox0 + (row & 15);
+        const int oy = oy0 + (row >> 4), ox = ox0 + (row & 15);
+        const long m = ((long)b * p.Hout + oy) * p.Wout + ox;
         const int n = n0 + c * 8;
-        if (n < p.N) {
+        if (n < p.N && oy < p.Hout && ox < p.Wout) {
             V8 v = *reinterpret_cast<const V8*>(sC + row * CS_STRIDE + c * 16);
             if (p.residual) {
                 const V8 rv = *reinterpret_cast<const V8*>(p.residual + m * p.ldr + n);
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo256_kernel(const GemmParams p
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     int tm, tn;
     tile_coords(tile, p.tiles_m, p.tiles_n, tm, tn);
-    const int tiles_x = p.Wout / PW, tiles_y = p.Hout / PH2;
+    const int tiles_x = (p.Wout + PW - 1) / PW, tiles_y = (p.Hout + PH2 - 1) / PH2;
     const int tx = tm % tiles_x, ty = (tm / tiles_x) % tiles_y, b = tm / (tiles_x * tiles_y);
     const int oy0 = ty * PH2, ox0 = tx * PW, n0 = tn * BN;
 
@@ -378,9 +379,10 @@ __global__ __launch_bounds__(256, 2) void conv_halo256_kernel(const GemmParams p
     for (int j = 0; j < 16; ++j) {
         const int id = tid + 256 * j;
         const int row = id >> 4, c = id & 15;
-        const long m = ((long)b * p.Hout + oy0 + (row >> 4)) * p.Wout + ox0 + (row & 15);
+        const int oy = oy0 + (row >> 4), ox = ox0 + (row & 15);
+        const long m = ((long)b * p.Hout + oy) * p.Wout + ox;
         const int n = n0 + c * 8;
-        if (n < p.N) {
+        if (n < p.N && oy < p.Hout && ox < p.Wout) {
             V8 v = *reinterpret_cast<const V8*>(sC + row * CS_STRIDE + c * 16);
             if (p.residual) {
                 const V8 rv = *reinterpret_cast<const V8*>(p.residual + m * p.ldr + n);
@@ -398,11 +400,11 @@ int g_halo_variant = 0;  // 0 auto, 1 force the 8 x 16 kernel, 2 force the 16 x 
 
 void ds_conv_halo_set_variant(int v) { g_halo_variant = v; }
 
-// Shapes the kernel takes: stride 1 (optionally the fused x2 upsample), output height % 8 == 0 and width % 16 == 0,
-// Cin % 64 == 0, plain epilogue, and an input small enough for 32-bit element offsets.
+// Shapes the kernel takes: stride 1 (optionally the fused x2 upsample), Cin % 64 == 0, plain epilogue, an input small
+// enough for 32-bit element offsets; any output height / width (edge patches are masked).
 bool ds_conv_halo_applicable(const GemmParams& p) {
     if (!p.conv || p.cstride != 1 || p.epi != EPI_NONE || p.Hout <= 0 || p.Wout <= 0) return false;
-    if (p.Hout % PH != 0 || p.Wout % PW != 0 || p.Cin % 64 != 0 || p.N % 8 != 0) return false;
+    if (p.Cin % 64 != 0 || p.N % 8 != 0) return false;
     const long batch = p.M / ((long)p.Hout * p.Wout);
     return batch * p.Hin * p.Win * p.Cin < (1L << 31);
 }
@@ -413,10 +415,11 @@ int ds_launch_conv_halo(const GemmParams& p0, hipStream_t stream) {
     const int batch = p.M / (p.Hout * p.Wout);
     p.tiles_n = (p.N + BN - 1) / BN;
     // 16 x 16 patches once they still fill the chip twice over (two blocks per CU): large batches / resolutions
-    const long tiles256 = (long)batch * (p.Hout / PH2) * (p.Wout / PW) * p.tiles_n;
-    const bool big = p.Hout % PH2 == 0 && (g_halo_variant == 2 || (g_halo_variant == 0 && tiles256 >= 1024));
+    const int ty8 = (p.Hout + PH - 1) / PH, ty16 = (p.Hout + PH2 - 1) / PH2, txs = (p.Wout + PW - 1) / PW;
+    const long tiles256 = (long)batch * ty16 * txs * p.tiles_n;
+    const bool big = g_halo_variant == 2 || (g_halo_variant == 0 && tiles256 >= 1024);
     if (big) {
-        p.tiles_m = batch * (p.Hout / PH2) * (p.Wout / PW);
+        p.tiles_m = batch * ty16 * txs;
         const size_t lds2 = PBYTES2 + 2 * BN * 128;  // 76 KiB; the 256 x 272 B epilogue tile fits inside
         static bool attr_set = false;
         if (!attr_set) {
@@ -432,7 +435,7 @@ int ds_launch_conv_halo(const GemmParams& p0, hipStream_t stream) {
         DS_LAUNCH_CHECK();
         return 0;
     }
-    p.tiles_m = batch * (p.Hout / PH) * (p.Wout / PW);
+    p.tiles_m = batch * ty8 * txs;
     const size_t lds = PROWS * 128 + BN * 128;  // 40 KiB; the 128 x 272 B epilogue tile fits inside
     dim3 grid(p.tiles_m * p.tiles_n);
     if (p.dtype == DS_DTYPE_BF16) hipLaunchKernelGGL(conv_halo_kernel<bf16_t>, grid, dim3(256), lds, stream, p);

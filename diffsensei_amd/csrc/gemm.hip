@@ -604,7 +604,7 @@ int ds_launch_gemm(const GemmParams& p_in, int batch, hipStream_t stream) {
     Choice c = choose(p, batch);
     if (p.dtype != DS_DTYPE_F16) {  // bf16 (VAE decoder): only the two kernels that are templated on the element type
         if (conv) {
-            DS_REQUIRE(ds_conv_halo_applicable(p), "conv3x3 bf16: needs stride 1, H %% 8 == 0, W %% 16 == 0, Cin %% 64 == 0");
+            DS_REQUIRE(ds_conv_halo_applicable(p), "conv3x3 bf16: needs stride 1 and Cin %% 64 == 0");
             c.kind = K_HALO;
         } else {
             DS_REQUIRE(ds_gemm_pp_applicable(p), "gemm bf16: needs M, N %% 16 == 0 and K %% 128 == 0 (M=%d N=%d K=%d)", p.M, p.N, p.K);

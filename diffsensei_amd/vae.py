@@ -12,8 +12,8 @@ Layout: NHWC between kernels.  Kernels: `conv_halo_kernel<bf16>` (every 3x3 conv
 `vae_conv_in_kernel` (post_quant_conv + conv_in), `vae_conv_out_kernel`.  No torch arithmetic on the data path: the
 only host-side math is the one-off weight re-layout (and folding the V bias through to_out, see `_pack`).
 
-Shape rules of the kernels: latent sides multiples of 16 (8-row x 16-column conv patches at every level), channel
-widths multiples of 128, mid-block width exactly 512 (SDXL / SD VAE).
+Shape rules of the kernels: latent height x width a multiple of 16 (any image side that is a multiple of 32 qualifies;
+conv patches at ragged edges are masked), channel widths multiples of 128, mid-block width exactly 512 (SDXL / SD VAE).
 """
 from __future__ import annotations
 
@@ -216,8 +216,8 @@ class VaeDecoderEngine:
         if z.dim() != 4 or z.shape[1] != self.config.latent_channels:
             raise ValueError(f"expected latents [B,{self.config.latent_channels},h,w], got {tuple(z.shape)}")
         B, _, h, w = z.shape
-        if h % 16 or w % 16:
-            raise ValueError(f"latent sides must be multiples of 16 (got {h}x{w}): the conv kernel works on 8x16 patches")
+        if (h * w) % 16:
+            raise ValueError(f"latent height x width must be a multiple of 16 (got {h}x{w}): rows of the projection GEMMs")
         # the conv kernel addresses its input with 32-bit element offsets: the widest full-resolution activation
         # ([chunk, 8h, 8w, C1]) bounds how many images go through one launch sequence (7 at 1024^2 -> chunks of 4)
         per_image = (8 * h) * (8 * w) * max(self.config.block_out_channels[1], self.config.block_out_channels[0])

@@ -53,7 +53,7 @@ int ds_gemm_f16_batched(const void* x, int64_t ldx, int64_t sx, const void* w, i
  * src/pipelines/pipeline_diffsensei.py:339-367 (the reference upcasts the VAE to fp32 because fp16 overflows).
  * Same layouts as the f16 entry points; all tensors bf16 unless noted. */
 /* y = conv3x3(x[B,H,W,Cin], w[Cout,3,3,Cin]) + bias (+ residual); stride 1; upsample != 0 = nearest x2 in front.
- * H_out % 8 == 0, W_out % 16 == 0, Cin % 64 == 0.  ResnetBlock2D.conv1/conv2, Upsample2D.conv of the decoder. */
+ * Cin % 64 == 0.  ResnetBlock2D.conv1/conv2, Upsample2D.conv of the decoder. */
 int ds_conv3x3_bf16(const void* x, const void* w, const void* bias, const void* residual, void* y, int B, int H,
                     int W, int Cin, int Cout, int upsample, void* stream);
 /* y[M,N] = x[M,K] @ w[N,K]^T + bias (+ residual); M, N % 16 == 0, K % 128 == 0: conv_shortcut (1x1), to_q/k/out */

@@ -173,7 +173,8 @@ def test_gemm_batched_vt(hip_lib):
 @pytest.mark.parametrize("B,H,W,Cin,Cout,stride,up", [(2, 16, 16, 64, 128, 1, False), (1, 32, 24, 128, 64, 1, False),
                                                        (2, 16, 16, 64, 64, 2, False), (2, 8, 12, 128, 128, 1, True),
                                                        (2, 64, 64, 320, 320, 1, False), (1, 32, 32, 1920, 640, 1, False),
-                                                       (2, 8, 16, 128, 192, 1, True), (3, 24, 48, 64, 320, 1, False)])
+                                                       (2, 8, 16, 128, 192, 1, True), (3, 24, 48, 64, 320, 1, False),
+                                                       (2, 20, 24, 64, 128, 1, False), (1, 9, 13, 64, 64, 1, True)])
 def test_conv3x3(hip_lib, B, H, W, Cin, Cout, stride, up):
     ops = _ops(hip_lib)
     g = torch.Generator().manual_seed(B * H + Cin + Cout + stride)

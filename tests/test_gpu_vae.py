@@ -30,7 +30,8 @@ def _close(got, ref, tol=1e-2, what=""):
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,up", [(2, 16, 16, 128, 128, False), (1, 8, 16, 512, 256, True),
-                                               (1, 32, 48, 256, 192, False)])
+                                               (1, 32, 48, 256, 192, False), (2, 20, 24, 128, 128, False),
+                                               (1, 12, 20, 256, 128, True)])
 def test_conv3x3_bf16(hip_lib, B, H, W, Cin, Cout, up):
     from diffsensei_amd import ops
     g = torch.Generator().manual_seed(B * H + Cin + Cout)
@@ -115,6 +116,12 @@ def test_decoder_engine_vs_oracle(hip_lib):
     den = eng.decode(lat.to(DEV), return_dict=False, scaling_factor=cfg.scaling_factor, denormalize=True)[0]
     assert torch.equal(den, (got / 2 + 0.5).clamp(0, 1))
     assert len(eng.tensors()) == len(vae_param_shapes(cfg)) + 1
+    # ragged latent (12 x 20 -> 96 x 160 image): edge patches of the conv kernels are masked
+    lat2 = torch.randn(1, 4, 12, 20, generator=g) * 0.9
+    ref2 = vae_decode(sd, lat2 / cfg.scaling_factor, cfg.layers_per_block, cfg.norm_num_groups, cfg.eps)
+    got2 = eng.decode(lat2.to(DEV), return_dict=False, scaling_factor=cfg.scaling_factor)[0]
+    assert got2.shape == ref2.shape == (1, 3, 96, 160)
+    assert ((got2.cpu() - ref2).norm() / ref2.norm()).item() <= 3e-2
     with pytest.raises(ValueError):
-        eng.decode(torch.zeros(1, 4, 12, 16, device=DEV))
+        eng.decode(torch.zeros(1, 4, 6, 10, device=DEV))
 
