@@ -132,3 +132,30 @@ def run_sharded(requests: Sequence[PanelRequest], worker: Callable[[PanelRequest
     for d in gathered:
         out.update(d)
     return out
+
+
+def run_sharded_batched(requests: Sequence[PanelRequest], pipe, max_panels: int = 16, max_pixels: Optional[int] = None,
+                        output_type: str = "pil", gather: bool = True):
+    """`run_sharded` for a whole queue: every rank pushes its shard through a `serving.BucketBatcher`, so requests of
+    one (size, steps, guidance) bucket share UNet batches on that rank (BASELINE.json configs[3]: mixed-resolution
+    queue over the GPUs of a node).  `PanelRequest.payload` holds the other `__call__` keyword arguments."""
+    from .serving import BucketBatcher
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    mine = shard_requests(requests, world)[rank]
+    batcher = BucketBatcher(pipe, max_panels=max_panels, max_pixels=max_pixels)
+    for r in mine:
+        batcher.submit(height=r.height, width=r.width, num_inference_steps=r.num_inference_steps,
+                       num_samples=r.num_samples, **r.payload)
+    outs = batcher.run(output_type=output_type)
+    results = {r.request_id: o for r, o in zip(mine, outs)}
+    if not gather or world == 1:
+        return results
+    gathered: List[Optional[dict]] = [None] * world if rank == 0 else None
+    dist.gather_object(results, gathered, dst=0)
+    if rank != 0:
+        return None
+    out = {}
+    for d in gathered:
+        out.update(d)
+    return out

@@ -78,3 +78,48 @@ def test_shard_requests_balanced_and_deterministic():
     for s in a:
         assert [(r.height, r.width) for r in s] == sorted((r.height, r.width) for r in s)
     assert shard_requests([], 4) == [[], [], [], []]
+
+
+def _worker_batched(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from diffsensei_amd.distributed import PanelRequest, init_from_env, run_sharded_batched
+    init_from_env("gloo")
+    calls = []
+
+    class FakePipe:  # records the UNet batches the front-end forms on this rank
+        def generate_batch(self, requests, output_type="pil"):
+            calls.append([(r["height"], r["prompt"]) for r in requests])
+            return [f"{r['prompt']}@{rank}" for r in requests]
+
+    sizes = [512, 768, 1024, 1536, 1024, 512, 768, 1024, 512, 512]
+    reqs = [PanelRequest(i, s, s, 50, 1, payload={"prompt": f"p{i}", "guidance_scale": 7.5}) for i, s in enumerate(sizes)]
+    out = run_sharded_batched(reqs, FakePipe(), max_panels=4, output_type="pt", gather=True)
+    dist.barrier()
+    q.put((rank, calls, out))
+    dist.destroy_process_group()
+
+
+def test_sharded_bucketed_serving_world2():
+    """configs[3] control flow: a mixed-resolution queue is sharded over 2 ranks (no data-path collective), each rank
+    batches its shard per resolution bucket, rank 0 gathers every request's result exactly once."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_batched, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    (_, calls0, out0), (_, calls1, out1) = res
+    assert out1 is None and sorted(out0) == list(range(10))
+    served = [pr for c in calls0 + calls1 for b in [c] for (_, pr) in b]
+    assert sorted(served) == sorted(f"p{i}" for i in range(10))              # every request on exactly one rank
+    for c in calls0 + calls1:
+        assert len({h for h, _ in c}) == 1 and len(c) <= 4                   # a batch never mixes buckets, panel cap
+    assert calls0 and calls1                                                 # both ranks got work
+    for i in range(10):
+        assert out0[i].startswith(f"p{i}@")
