@@ -319,7 +319,92 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
         const int l31 = lane_e & 31, lhi = lane_e >> 5;
-        if (geglu) {
+        // Interior tiles (all of them on the UNet's shapes) take a branch-free epilogue: the generic code below tests
+        // bias / row bias / bounds per 4 values, and every test became a branch with an s_waitcnt vmcnt(0) behind each
+        // bias or residual load - loads, converts and stores ran strictly one after the other (4-8 us per tile, all of
+        // it with the matrix pipe idle).  Here the bias values are fetched once per tile, and the four residual loads of a
+        // 32-row piece are in flight while the piece is transposed through LDS.
+        const bool fast = cm0 + 256 <= p.M && cn0 + 256 <= p.N && !p.rowbias && (geglu || p.epi == EPI_NONE);
+        if (fast && geglu) {
+            const int nw = cn0 + (wc >> 1) * 128 + (wc & 1) * 32;
+            const int no = (cn0 >> 1) + wc * 32;
+            V4 bh[4], bg[4];  // kept packed: the accumulators still occupy 128 registers here
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bh[g] = bg[g] = V4{0, 0, 0, 0};
+            if (p.bias) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    bh[g] = *reinterpret_cast<const V4*>(p.bias + nw + 8 * g + 4 * lhi);
+                    bg[g] = *reinterpret_cast<const V4*>(p.bias + nw + 64 + 8 * g + 4 * lhi);
+                }
+            }
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const int mb = cm0 + (mi >> 1) * 128 + wr * 64 + (mi & 1) * 32;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c = 8 * g + 4 * lhi;
+                    V4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float hq = (float)(T)(acc[mi][0][4 * g + e] + (float)bh[g][e]);
+                        const float gq = (float)(T)(acc[mi][1][4 * g + e] + (float)bg[g][e]);
+                        o[e] = (T)(hq * (float)(T)ds_gelu_erf(gq));
+                    }
+                    *reinterpret_cast<V4*>(ep + l31 * 64 + ((((c >> 3) ^ (l31 >> 2)) & 3) << 4) + ((c >> 2) & 1) * 8) = o;
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int row = i * 16 + (lane_e >> 2), ch = lane_e & 3;
+                    const V8 v = *reinterpret_cast<const V8*>(ep + row * 64 + (((ch ^ (row >> 2)) & 3) << 4));
+                    *reinterpret_cast<V8*>(Cg + (long)(mb + row) * p.ldc + no + ch * 8) = v;
+                }
+            }
+        } else if (fast) {
+            const int nw = cn0 + wc * 64;
+            V4 bv[2][4];
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) bv[ni][g] = V4{0, 0, 0, 0};
+            if (p.bias) {
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        bv[ni][g] = *reinterpret_cast<const V4*>(p.bias + nw + ni * 32 + 8 * g + 4 * lhi);
+            }
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const int mb = cm0 + (mi >> 1) * 128 + wr * 64 + (mi & 1) * 32;
+                V8 rv[4];
+                if (Rg) {  // all four 16-byte pieces of the residual rows go out before the transposition
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        rv[i] = *reinterpret_cast<const V8*>(Rg + (long)(mb + i * 8 + (lane_e >> 3)) * p.ldr + nw + (lane_e & 7) * 8);
+                }
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int c = ni * 32 + 8 * g + 4 * lhi;
+                        V4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = (T)(acc[mi][ni][4 * g + e] + (float)bv[ni][g][e]);
+                        *reinterpret_cast<V4*>(ep + l31 * 128 + ((((c >> 3) ^ (l31 >> 1)) & 7) << 4) + ((c >> 2) & 1) * 8) = o;
+                    }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = i * 8 + (lane_e >> 3), ch = lane_e & 7;
+                    V8 v = *reinterpret_cast<const V8*>(ep + row * 128 + (((ch ^ (row >> 1)) & 7) << 4));
+                    if (Rg) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = (T)((float)v[e] + (float)rv[i][e]);
+                    }
+                    *reinterpret_cast<V8*>(Cg + (long)(mb + row) * p.ldc + nw + ch * 8) = v;
+                }
+            }
+        } else if (geglu) {
             const int nw = cn0 + (wc >> 1) * 128 + (wc & 1) * 32;  // hidden strip; gates 64 columns further
             const int no = (cn0 >> 1) + wc * 32;                   // first output column of the wave
 #pragma unroll
