@@ -158,7 +158,29 @@ __global__ __launch_bounds__(256, 3) void conv_halo_kernel(const GemmParams p) {
     // ---- epilogue: bias (+ per-image bias), round to f16, park the 128 x 128 tile in LDS, then whole 16-byte pieces
     // of output rows (+ residual).  D layout (operands swapped): lane holds row ..+(lane&31); register r is column
     // (r&3) + 8*(r>>2) + 4*(lane>>5) of its 32-column fragment.
+    // (no branch / s_waitcnt per 4 values: biases fetched once with clamped addresses, residual pieces requested in
+    // batches of four before they are needed - see conv_halo256_kernel)
     char* const sC = smem;
+    V4 b0[2][4], b1[2][4];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) b0[ni][g] = b1[ni][g] = V4{0, 0, 0, 0};
+    if (p.bias) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                b0[ni][g] = *reinterpret_cast<const V4*>(p.bias + min(n0 + wn * 64 + ni * 32 + 8 * g + 4 * lhi, p.N - 4));
+    }
+    if (p.rowbias) {
+        const half_t* rb = p.rowbias + (long)b * p.rowbias_ld;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                b1[ni][g] = *reinterpret_cast<const V4*>(rb + min(n0 + wn * 64 + ni * 32 + 8 * g + 4 * lhi, p.N - 4));
+    }
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
         const int ms = wm * 64 + mi * 32 + l31;
@@ -167,44 +189,45 @@ __global__ __launch_bounds__(256, 3) void conv_halo_kernel(const GemmParams p) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int nl = wn * 64 + ni * 32 + 8 * g + 4 * lhi;
-                const int n = n0 + nl;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][4 * g + e];
-                if (n < p.N) {
-                    if (p.bias) {
-                        const V4 bv = *reinterpret_cast<const V4*>(p.bias + n);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += (float)bv[e];
-                    }
-                    if (p.rowbias) {
-                        const V4 bv = *reinterpret_cast<const V4*>(p.rowbias + (long)b * p.rowbias_ld + n);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += (float)bv[e];
-                    }
-                }
                 V4 o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (T)v[e];
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[mi][ni][4 * g + e];
+                    v += (float)b0[ni][g][e];
+                    v += (float)b1[ni][g][e];
+                    o[e] = (T)v;
+                }
                 *reinterpret_cast<V4*>(sC + ms * CS_STRIDE + nl * 2) = o;
             }
     }
     __syncthreads();
+    const T* const Rp = reinterpret_cast<const T*>(p.residual);
+#pragma unroll 1
+    for (int j0 = 0; j0 < 8; j0 += 4) {
+        long mrow[4];
+        int ncol[4];
+        bool ok[4];
+        V8 rv[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int id = tid + 256 * j;
-        const int row = id >> 4, c = id & 15;
-        const int oy = oy0 + (row >> 4), ox = ox0 + (row & 15);
-        const long m = ((long)b * p.Hout + oy) * p.Wout + ox;
-        const int n = n0 + c * 8;
-        if (n < p.N && oy < p.Hout && ox < p.Wout) {
+        for (int u = 0; u < 4; ++u) {
+            const int id = tid + 256 * (j0 + u);
+            const int row = id >> 4, c = id & 15;
+            const int oy = oy0 + (row >> 4), ox = ox0 + (row & 15);
+            ok[u] = (n0 + c * 8 < p.N) & (oy < p.Hout) & (ox < p.Wout);
+            mrow[u] = ((long)b * p.Hout + min(oy, p.Hout - 1)) * p.Wout + min(ox, p.Wout - 1);
+            ncol[u] = min(n0 + c * 8, p.N - 8);
+            if (Rp) rv[u] = *reinterpret_cast<const V8*>(Rp + mrow[u] * p.ldr + ncol[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int id = tid + 256 * (j0 + u);
+            const int row = id >> 4, c = id & 15;
             V8 v = *reinterpret_cast<const V8*>(sC + row * CS_STRIDE + c * 16);
-            if (p.residual) {
-                const V8 rv = *reinterpret_cast<const V8*>(p.residual + m * p.ldr + n);
+            if (Rp) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (T)((float)v[e] + (float)rv[e]);
+                for (int e = 0; e < 8; ++e) v[e] = (T)((float)v[e] + (float)rv[u][e]);
             }
-            *reinterpret_cast<V8*>(p.C + m * p.ldc + n) = v;
+            if (ok[u]) *reinterpret_cast<V8*>(reinterpret_cast<T*>(p.C) + mrow[u] * p.ldc + ncol[u]) = v;
         }
     }
 }
@@ -342,8 +365,31 @@ __global__ __launch_bounds__(256, 2) void conv_halo256_kernel(const GemmParams p
     }
     __syncthreads();
 
-    // ---- epilogue: as the 8 x 16 kernel, 256 rows
+    // ---- epilogue: as the 8 x 16 kernel, 256 rows - but without a branch (and the s_waitcnt vmcnt(0) the compiler puts
+    // behind each conditional load) per 4 values: the bias + per-image bias of the lane's 8 column groups are fetched
+    // once (clamped addresses: masked columns are never stored), and the residual rows are loaded four 16-byte pieces
+    // at a time before they are needed.
     char* const sC = smem;
+    V4 b0[2][4], b1[2][4];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) b0[ni][g] = b1[ni][g] = V4{0, 0, 0, 0};
+    if (p.bias) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                b0[ni][g] = *reinterpret_cast<const V4*>(p.bias + min(n0 + wn * 64 + ni * 32 + 8 * g + 4 * lhi, p.N - 4));
+    }
+    if (p.rowbias) {
+        const half_t* rb = p.rowbias + (long)b * p.rowbias_ld;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                b1[ni][g] = *reinterpret_cast<const V4*>(rb + min(n0 + wn * 64 + ni * 32 + 8 * g + 4 * lhi, p.N - 4));
+    }
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
         const int ms = wm * 128 + mi * 32 + l31;
@@ -352,44 +398,45 @@ __global__ __launch_bounds__(256, 2) void conv_halo256_kernel(const GemmParams p
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int nl = wn * 64 + ni * 32 + 8 * g + 4 * lhi;
-                const int n = n0 + nl;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][4 * g + e];
-                if (n < p.N) {
-                    if (p.bias) {
-                        const V4 bv = *reinterpret_cast<const V4*>(p.bias + n);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += (float)bv[e];
-                    }
-                    if (p.rowbias) {
-                        const V4 bv = *reinterpret_cast<const V4*>(p.rowbias + (long)b * p.rowbias_ld + n);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += (float)bv[e];
-                    }
-                }
                 V4 o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (T)v[e];
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[mi][ni][4 * g + e];
+                    v += (float)b0[ni][g][e];  // same order as the generic kernels: bias, then the per-image bias
+                    v += (float)b1[ni][g][e];
+                    o[e] = (T)v;
+                }
                 *reinterpret_cast<V4*>(sC + ms * CS_STRIDE + nl * 2) = o;
             }
     }
     __syncthreads();
-#pragma unroll 4
-    for (int j = 0; j < 16; ++j) {
-        const int id = tid + 256 * j;
-        const int row = id >> 4, c = id & 15;
-        const int oy = oy0 + (row >> 4), ox = ox0 + (row & 15);
-        const long m = ((long)b * p.Hout + oy) * p.Wout + ox;
-        const int n = n0 + c * 8;
-        if (n < p.N && oy < p.Hout && ox < p.Wout) {
-            V8 v = *reinterpret_cast<const V8*>(sC + row * CS_STRIDE + c * 16);
-            if (p.residual) {
-                const V8 rv = *reinterpret_cast<const V8*>(p.residual + m * p.ldr + n);
+    const T* const Rp = reinterpret_cast<const T*>(p.residual);
+#pragma unroll 1
+    for (int j0 = 0; j0 < 16; j0 += 4) {
+        long mrow[4];
+        int ncol[4];
+        bool ok[4];
+        V8 rv[4];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (T)((float)v[e] + (float)rv[e]);
+        for (int u = 0; u < 4; ++u) {
+            const int id = tid + 256 * (j0 + u);
+            const int row = id >> 4, c = id & 15;
+            const int oy = oy0 + (row >> 4), ox = ox0 + (row & 15);
+            ok[u] = (n0 + c * 8 < p.N) & (oy < p.Hout) & (ox < p.Wout);
+            mrow[u] = ((long)b * p.Hout + min(oy, p.Hout - 1)) * p.Wout + min(ox, p.Wout - 1);
+            ncol[u] = min(n0 + c * 8, p.N - 8);
+            if (Rp) rv[u] = *reinterpret_cast<const V8*>(Rp + mrow[u] * p.ldr + ncol[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int id = tid + 256 * (j0 + u);
+            const int row = id >> 4, c = id & 15;
+            V8 v = *reinterpret_cast<const V8*>(sC + row * CS_STRIDE + c * 16);
+            if (Rp) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (T)((float)v[e] + (float)rv[u][e]);
             }
-            *reinterpret_cast<V8*>(p.C + m * p.ldc + n) = v;
+            if (ok[u]) *reinterpret_cast<V8*>(reinterpret_cast<T*>(p.C) + mrow[u] * p.ldc + ncol[u]) = v;
         }
     }
 }

@@ -76,6 +76,20 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x16 (&acc)[WR /
     char* sC = smem;
     half_t* Cg = p.C + bz * p.sC;
     const half_t* Rg = p.residual ? p.residual + bz * p.sR : nullptr;
+    // the lane's bias values, fetched once (clamped: masked columns are never stored) instead of behind a branch - and
+    // the s_waitcnt vmcnt(0) that follows a conditional load - per 4 values
+    h4 bq[2][4];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bq[ni][g] = h4{0, 0, 0, 0};
+    if (p.bias) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                bq[ni][g] = *reinterpret_cast<const h4*>(p.bias + min(n0 + wn * 64 + ni * 32 + 8 * g + 4 * lhi, p.N - 4));
+    }
 #pragma unroll
     for (int half = 0; half < HALVES; ++half) {
         if (half) __syncthreads();
@@ -94,13 +108,8 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x16 (&acc)[WR /
                     const int n = n0 + nl;
                     float v[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][4 * g + e];
+                    for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][4 * g + e] + (float)bq[ni][g][e];
                     if (n < p.N) {
-                        if (p.bias) {
-                            const h4 bv = *reinterpret_cast<const h4*>(p.bias + n);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] += (float)bv[e];
-                        }
                         if (p.rowbias) {
                             const h4 bv = *reinterpret_cast<const h4*>(p.rowbias + (long)grp * p.rowbias_ld + n);
 #pragma unroll
@@ -138,6 +147,17 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x16 (&acc)[WR /
             }
         } else {
             constexpr int IT = HR * 16 / NT;
+            // the residual pieces of the whole pass are requested up front (clamped addresses; the accumulators are
+            // dead by now, so the registers are there) - not one load / wait / store round trip per 16 bytes
+            h8 rvs[IT];
+            if (Rg) {
+#pragma unroll
+                for (int j = 0; j < IT; ++j) {
+                    const int id = tid + NT * j;
+                    const int m = min(mh + (id >> 4), p.M - 1), n = min(n0 + (id & 15) * 8, p.N - 8);
+                    rvs[j] = *reinterpret_cast<const h8*>(Rg + (long)m * p.ldr + n);
+                }
+            }
 #pragma unroll
             for (int j = 0; j < IT; ++j) {
                 const int id = tid + NT * j;
@@ -156,7 +176,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x16 (&acc)[WR /
                         }
                     }
                     if (Rg) {
-                        const h8 rv = *reinterpret_cast<const h8*>(Rg + (long)m * p.ldr + n);
+                        const h8 rv = rvs[j];
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rv[e]);
                     }
