@@ -22,7 +22,8 @@ class DsOp(C.Structure):
 # opcode values of enum ds_opcode
 OP = dict(GEMM=1, CONV3X3=2, GROUPNORM=3, LAYERNORM=4, SELF_ATTN=5, IP_ATTN=6, CONV_IN=7, CONV_OUT=8, SKINNY=9,
           TIMESTEP_EMBED=10, ADD_TIME_IDS=11, SAMPLER_STEP=12, PREP_INPUT=13, ADVANCE=14, NHWC2NCHW=15, NCHW2NHWC=16,
-          PAD_ROWS=17, SMALL_ATTN=18)
+          PAD_ROWS=17, SMALL_ATTN=18, LLM_GEMV=19, LLM_ATTN=20, LLM_RMSNORM=21, LLM_EMBED=22, LLM_SELECT=23,
+          LLM_ADVANCE=24)
 
 # name -> (restype, argtypes).  Every symbol declared in include/diffsensei_hip.h appears here;
 # tests/test_capi_symbols.py checks the two lists against each other.
@@ -62,6 +63,13 @@ SIGNATURES = {
     "ds_nhwc_to_nchw_f16": (i32, [vp, vp, i32, i32, i32, vp]),
     "ds_nchw_to_nhwc_f16": (i32, [vp, vp, i32, i32, i32, vp]),
     "ds_pad_rows_f16": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "ds_llm_gemv_f16": (i32, [vp, i64, vp, vp, i64, vp, i64, i32, i32, i32, i32, i32, f32, vp]),
+    "ds_llm_attn_f16": (i32, [vp, i64, vp, vp, i64, vp, vp, vp, i64, vp, i32, i32, i32, i32, i32, f32, vp]),
+    "ds_llm_rmsnorm_f16": (i32, [vp, i64, vp, vp, i64, vp, vp, i32, i32, i32, f32, vp]),
+    "ds_llm_embed_f16": (i32, [vp, vp, vp, i32, i32, vp]),
+    "ds_llm_select_f16": (i32, [vp, i32, vp, i32, i32, i32, vp, vp, vp]),
+    "ds_llm_advance": (i32, [vp, i32, vp]),
+    "ds_blend_f16": (i32, [vp, vp, vp, i64, f32, vp]),
     "ds_op_run": (i32, [C.POINTER(DsOp), vp]),
     "ds_op_describe": (i32, [C.POINTER(DsOp), C.c_char_p, i32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "ds_plan_create": (i32, [C.POINTER(DsOp), i32, C.POINTER(vp)]),

@@ -475,8 +475,8 @@ __global__ __launch_bounds__(256, 2) void ip_attn_kernel(const IPAttnParams p, i
 }
 
 // ------------------------------------------------------------------------------------------------
-// Generic small attention (any head_dim <= 128, any token counts) for the once-per-panel encoders:
-// CLIP ViT-H (257 tokens, head_dim 80), ViT-MAE, and the perceiver Resampler
+// Generic small attention (any head_dim <= 256, any token counts) for the once-per-panel encoders:
+// CLIP ViT-H (257 tokens, head_dim 80), ViT-MAE, the perceiver Resampler and the MLLM's QwenResamplers (head_dim 160)
 // (reference src/models/resampler.py:67-72: (q*s)(k*s)^T, fp32 softmax).  One wavefront per query row.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void small_attn_kernel(const half_t* __restrict__ q, const half_t* __restrict__ k,
@@ -577,7 +577,7 @@ int ds_launch_ip_region_flags(const float* bbox, uint8_t* flags, int B, int N, i
 int ds_launch_small_attn(const half_t* q, const half_t* k, const half_t* v, half_t* o, long ldq, long ldk, long ldv,
                          long ldo, long sq, long sk, long sv, long so, int B, int heads, int Nq, int Nk, int D,
                          float scale, hipStream_t stream, int causal) {
-    DS_REQUIRE(D % 8 == 0 && D <= 128, "small_attn: head_dim %d unsupported", D);
+    DS_REQUIRE(D % 8 == 0 && D <= 256, "small_attn: head_dim %d unsupported", D);
     DS_REQUIRE(Nk * 4 * sizeof(float) <= 60000, "small_attn: Nk %d too large", Nk);
     dim3 grid((Nq + 3) / 4, B * heads);
     hipLaunchKernelGGL(small_attn_kernel, grid, dim3(256), (size_t)4 * Nk * sizeof(float), stream, q, k, v, o, ldq,

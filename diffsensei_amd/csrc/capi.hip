@@ -236,6 +236,57 @@ int ds_skinny_linear_f16(const void* x, const void* w, const void* bias, const v
     return ds_launch_skinny_linear(H(x), H(w), H(bias), H(addend), HM(y), M, N, K, silu_in, silu_out, S(stream));
 }
 
+// ---- MLLM pre-pass (llm.hip): LLaMA greedy decoding
+static int llm_gemv_impl(const void* x, int64_t ldx, const void* w, void* y, int64_t ldy, const void* residual,
+                         int64_t ldr, int M, int N, int K, int rms, int swiglu, float eps, hipStream_t st) {
+    LlmGemvParams g;
+    g.x = H(x); g.w = H(w); g.y = HM(y); g.residual = H(residual);
+    g.ldx = ldx; g.ldy = ldy; g.ldr = ldr; g.M = M; g.N = N; g.K = K; g.rms = rms; g.swiglu = swiglu; g.eps = eps;
+    return ds_launch_llm_gemv(g, st);
+}
+
+static int llm_attn_impl(const void* qkv, int64_t ldqkv, void* kc, void* vc, int64_t ldc, const float* rope_cos,
+                         const float* rope_sin, void* out, int64_t ldo, const int32_t* state, int M, int heads,
+                         int kv_heads, int D, int T_max, float scale, hipStream_t st) {
+    LlmAttnParams a;
+    a.qkv = H(qkv); a.kc = HM(kc); a.vc = HM(vc); a.rope_cos = rope_cos; a.rope_sin = rope_sin; a.out = HM(out);
+    a.state = state; a.ldqkv = ldqkv; a.ldc = ldc; a.ldo = ldo;
+    a.M = M; a.heads = heads; a.kv_heads = kv_heads; a.D = D; a.T_max = T_max; a.scale = scale;
+    return ds_launch_llm_attn(a, st);
+}
+
+int ds_llm_gemv_f16(const void* x, int64_t ldx, const void* w, void* y, int64_t ldy, const void* residual,
+                    int64_t ldr, int M, int N, int K, int rms, int swiglu, float eps, void* stream) {
+    return llm_gemv_impl(x, ldx, w, y, ldy, residual, ldr, M, N, K, rms, swiglu, eps, S(stream));
+}
+
+int ds_llm_attn_f16(const void* qkv, int64_t ldqkv, void* k_cache, void* v_cache, int64_t ldc, const float* rope_cos,
+                    const float* rope_sin, void* out, int64_t ldo, const int32_t* state, int M, int heads,
+                    int kv_heads, int D, int T_max, float scale, void* stream) {
+    return llm_attn_impl(qkv, ldqkv, k_cache, v_cache, ldc, rope_cos, rope_sin, out, ldo, state, M, heads, kv_heads, D,
+                         T_max, scale, S(stream));
+}
+
+int ds_llm_rmsnorm_f16(const void* x, int64_t ldx, const void* gamma, void* y, int64_t ldy, void* feat,
+                       const int32_t* state, int M, int Hd, int max_out, float eps, void* stream) {
+    return ds_launch_llm_rmsnorm(H(x), ldx, H(gamma), HM(y), ldy, HM(feat), state, M, Hd, max_out, eps, S(stream));
+}
+
+int ds_llm_embed_f16(const void* table, const int32_t* state, void* out, int Hd, int vocab, void* stream) {
+    return ds_launch_llm_embed(H(table), state, HM(out), Hd, vocab, S(stream));
+}
+
+int ds_llm_select_f16(const void* logits, int V, const int32_t* chain, int n_chain, int out_cap, int adv,
+                      int32_t* state, int32_t* out_ids, void* stream) {
+    return ds_launch_llm_select(H(logits), V, chain, n_chain, out_cap, adv, state, out_ids, S(stream));
+}
+
+int ds_llm_advance(int32_t* state, int rows, void* stream) { return ds_launch_llm_advance(state, rows, S(stream)); }
+
+int ds_blend_f16(const void* a, const void* b, void* out, int64_t n, float scale, void* stream) {
+    return ds_launch_blend(H(a), H(b), HM(out), (long)n, scale, S(stream));
+}
+
 int ds_timestep_embed_f16(const float* table, const int32_t* step_ctr, void* out, int B, int dim, int flip,
                           float freq_shift, void* stream) {
     return ds_launch_timestep_embed(table, step_ctr, HM(out), B, dim, flip, freq_shift, S(stream));
@@ -349,6 +400,22 @@ static int run_op(const ds_op& o, hipStream_t st) {
         case DS_OP_SMALL_ATTN:
             return ds_launch_small_attn(H(p[0]), H(p[1]), H(p[2]), HM(p[3]), l[0], l[1], l[2], l[3], l[4], l[5], l[6],
                                         l[7], i[0], i[1], i[2], i[3], i[4], o.f[0], st);
+        case DS_OP_LLM_GEMV:
+            return llm_gemv_impl(p[0], l[0], p[1], p[2], l[1], p[3], l[2], i[0], i[1], i[2], i[3], i[4], o.f[0], st);
+        case DS_OP_LLM_ATTN:
+            return llm_attn_impl(p[0], l[0], p[1], p[2], l[1], reinterpret_cast<const float*>(p[3]),
+                                 reinterpret_cast<const float*>(p[4]), p[5], l[2], reinterpret_cast<const int32_t*>(p[6]),
+                                 i[0], i[1], i[2], i[3], i[4], o.f[0], st);
+        case DS_OP_LLM_RMSNORM:
+            return ds_launch_llm_rmsnorm(H(p[0]), l[0], H(p[1]), HM(p[2]), l[1], HM(p[3]),
+                                         reinterpret_cast<const int*>(p[4]), i[0], i[1], i[2], o.f[0], st);
+        case DS_OP_LLM_EMBED:
+            return ds_launch_llm_embed(H(p[0]), reinterpret_cast<const int*>(p[1]), HM(p[2]), i[0], i[1], st);
+        case DS_OP_LLM_SELECT:
+            return ds_launch_llm_select(H(p[0]), i[0], reinterpret_cast<const int*>(p[1]), i[1], i[2], i[3],
+                                        reinterpret_cast<int*>(p[2]), reinterpret_cast<int*>(p[3]), st);
+        case DS_OP_LLM_ADVANCE:
+            return ds_launch_llm_advance(reinterpret_cast<int*>(p[0]), i[0], st);
         default:
             ds_set_error("plan: unknown opcode %d", o.code);
             return -4;
@@ -401,6 +468,14 @@ int ds_op_describe(const ds_op* op, char* name, int name_len, double* flops, dou
         case DS_OP_CONV_OUT: nm = "conv_out_kernel"; fl = 2.0 * i[0] * (double)i[1] * i[2] * 9 * i[3] * i[4]; break;
         case DS_OP_SKINNY: nm = "skinny_linear_kernel"; fl = 2.0 * i[0] * (double)i[1] * i[2]; by = 2.0 * i[1] * (double)i[2]; break;
         case DS_OP_SAMPLER_STEP: nm = "sampler_step_kernel"; break;
+        case DS_OP_LLM_GEMV:
+            nm = "llm_gemv_kernel";
+            fl = 2.0 * i[0] * (double)i[1] * i[2] * (i[4] ? 2 : 1);
+            by = 2.0 * ((double)i[1] * i[2] * (i[4] ? 2 : 1) + (double)i[0] * i[2] + (double)i[0] * i[1]);
+            break;
+        case DS_OP_LLM_ATTN: nm = "llm_attn_kernel"; break;
+        case DS_OP_LLM_RMSNORM: nm = "llm_rmsnorm_kernel"; by = 4.0 * i[0] * (double)i[1]; break;
+        case DS_OP_LLM_SELECT: nm = "llm_select_kernel"; by = 2.0 * i[0]; break;
         default: break;
     }
     if (name && name_len > 0) {

@@ -133,3 +133,40 @@ int ds_launch_embed_tokens(const int* ids, const half_t* tok_emb, const half_t* 
                            int D, int vocab, hipStream_t stream);
 int ds_launch_pad_rows(const half_t* x, half_t* y, int B, int rows_in, int rows_out, int row_off, int total_rows,
                        int C, hipStream_t stream);
+
+// ---- MLLM pre-pass: LLaMA greedy decoding (llm.hip) ---------------------------------------------------
+// device-side state block (int32[8]): {tokens in the KV cache, tokens generated, finished, current token,
+//                                      max_new_tokens, eos id, spare, spare}
+struct LlmGemvParams {
+    const half_t* x = nullptr;         // [M,K] rows (ldx)
+    const half_t* w = nullptr;         // [N,K] row-major; SwiGLU: [2N,K] = gate rows then up rows
+    half_t* y = nullptr;               // [M,N] rows (ldy)
+    const half_t* residual = nullptr;  // [M,N] rows (ldr) added after the fp16 rounding; may alias y
+    long ldx = 0, ldy = 0, ldr = 0;
+    int M = 0, N = 0, K = 0;
+    int rms = 0;                       // scale row m by rsqrt(mean(x[m]^2) + eps): RMSNorm whose gain is folded into w
+    int swiglu = 0;                    // y = silu(x.w[n]) * (x.w[n+N])
+    float eps = 1e-6f;
+};
+int ds_launch_llm_gemv(const LlmGemvParams& p, hipStream_t stream);
+
+struct LlmAttnParams {
+    const half_t* qkv = nullptr;       // [M, (heads + 2 kv_heads) * D] rows (ldqkv): q | k | v, not yet rotated
+    half_t* kc = nullptr;              // key cache   [T_max, kv_heads*D] rows (ldc), rotated keys
+    half_t* vc = nullptr;              // value cache [T_max, kv_heads*D]
+    const float* rope_cos = nullptr;   // [T_max, D/2]
+    const float* rope_sin = nullptr;
+    half_t* out = nullptr;             // [M, heads*D] rows (ldo)
+    const int* state = nullptr;        // state[0] = rows already in the cache
+    long ldqkv = 0, ldc = 0, ldo = 0;
+    int M = 0, heads = 0, kv_heads = 0, D = 0, T_max = 0;
+    float scale = 1.0f;
+};
+int ds_launch_llm_attn(const LlmAttnParams& p, hipStream_t stream);
+int ds_launch_llm_rmsnorm(const half_t* x, long ldx, const half_t* gamma, half_t* y, long ldy, half_t* feat,
+                          const int* state, int M, int H, int max_out, float eps, hipStream_t stream);
+int ds_launch_llm_embed(const half_t* table, const int* state, half_t* out, int H, int vocab, hipStream_t stream);
+int ds_launch_llm_select(const half_t* logits, int V, const int* chain, int n_chain, int out_cap, int adv, int* state,
+                         int* out_ids, hipStream_t stream);
+int ds_launch_llm_advance(int* state, int rows, hipStream_t stream);
+int ds_launch_blend(const half_t* a, const half_t* b, half_t* out, long n, float s, hipStream_t stream);

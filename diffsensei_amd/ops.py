@@ -172,7 +172,7 @@ def causal_attention(q: Tensor, k: Tensor, v: Tensor, heads: int, scale: float) 
 
 
 def small_attention(q: Tensor, k: Tensor, v: Tensor, heads: int, scale: float) -> Tensor:
-    """q: [B,Nq,heads*D], k/v: [B,Nk,heads*D] (any D<=128 multiple of 8); k/v may be column-slice views."""
+    """q: [B,Nq,heads*D], k/v: [B,Nk,heads*D] (any D<=256 multiple of 8); k/v may be column-slice views."""
     _chk(q)
     for t in (k, v):
         if not t.is_cuda or t.dtype != torch.float16 or t.stride(2) != 1:
@@ -366,3 +366,79 @@ def vae_conv_out(x: Tensor, w: Tensor, bias: Tensor, denormalize: bool = False) 
     check(_lib.load().ds_vae_conv_out_bf16(_p(x), _p(w), _p(bias), _p(img), B, H, W, C, int(denormalize), _stream()),
           "ds_vae_conv_out_bf16")
     return img
+
+
+# ---- MLLM pre-pass: LLaMA greedy decoding (csrc/llm.hip) ----------------------------------------------------
+def llm_gemv(x: Tensor, w: Tensor, out: Optional[Tensor] = None, residual: Optional[Tensor] = None, rms: bool = False,
+             swiglu: bool = False, eps: float = 1e-6) -> Tensor:
+    """x: [M<=any, K] rows; w: [N,K] (swiglu: [2N,K] gate rows then up rows).  `rms`: rows scaled by 1/rms(x) (the
+    RMSNorm gain is expected to be folded into w).  `residual` may be `out` itself (in-place h += ...)."""
+    _chk(x, w, residual)
+    M, K = x.shape
+    N = w.shape[0] // (2 if swiglu else 1)
+    assert w.shape[1] == K
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float16, device=x.device)
+    _chk(out)
+    check(_lib.load().ds_llm_gemv_f16(_p(x), K, _p(w), _p(out), N, _p(residual), N, M, N, K, int(rms), int(swiglu),
+                                      eps, _stream()), "ds_llm_gemv_f16")
+    return out
+
+
+def llm_attention(qkv: Tensor, k_cache: Tensor, v_cache: Tensor, rope_cos: Tensor, rope_sin: Tensor, state: Tensor,
+                  heads: int, kv_heads: int, scale: float, out: Optional[Tensor] = None) -> Tensor:
+    """qkv: [M,(heads+2*kv_heads)*D] un-rotated; caches [T_max, kv_heads*D]; appends the M rows at state[0].."""
+    _chk(qkv, k_cache, v_cache)
+    _chk(rope_cos, rope_sin, dtype=torch.float32)
+    _chk(state, dtype=torch.int32)
+    M = qkv.shape[0]
+    D = qkv.shape[1] // (heads + 2 * kv_heads)
+    T_max = k_cache.shape[0]
+    assert rope_cos.shape == (T_max, D // 2) and k_cache.shape[1] == kv_heads * D
+    if out is None:
+        out = torch.empty((M, heads * D), dtype=torch.float16, device=qkv.device)
+    check(_lib.load().ds_llm_attn_f16(_p(qkv), qkv.shape[1], _p(k_cache), _p(v_cache), k_cache.shape[1], _p(rope_cos),
+                                      _p(rope_sin), _p(out), heads * D, _p(state), M, heads, kv_heads, D, T_max, scale,
+                                      _stream()), "ds_llm_attn_f16")
+    return out
+
+
+def llm_rmsnorm(x: Tensor, gamma: Tensor, eps: float, out: Optional[Tensor] = None, feat: Optional[Tensor] = None,
+                state: Optional[Tensor] = None) -> Tensor:
+    _chk(x, gamma, feat)
+    M, H = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    check(_lib.load().ds_llm_rmsnorm_f16(_p(x), H, _p(gamma), _p(out), H, _p(feat), _p(state), M, H,
+                                         0 if feat is None else feat.shape[0], eps, _stream()), "ds_llm_rmsnorm_f16")
+    return out
+
+
+def llm_embed(table: Tensor, state: Tensor, out: Tensor) -> Tensor:
+    _chk(table, out)
+    _chk(state, dtype=torch.int32)
+    check(_lib.load().ds_llm_embed_f16(_p(table), _p(state), _p(out), table.shape[1], table.shape[0], _stream()),
+          "ds_llm_embed_f16")
+    return out
+
+
+def llm_select(logits: Tensor, chain: Optional[Tensor], adv: int, state: Tensor, out_ids: Tensor) -> None:
+    """Greedy pick + image-token logits processor + bookkeeping in the device state block (see the header)."""
+    _chk(logits)
+    _chk(chain, state, out_ids, dtype=torch.int32)
+    check(_lib.load().ds_llm_select_f16(_p(logits), logits.numel(), _p(chain), 0 if chain is None else chain.numel(),
+                                        out_ids.numel(), adv, _p(state), _p(out_ids), _stream()), "ds_llm_select_f16")
+
+
+def llm_advance(state: Tensor, rows: int) -> None:
+    _chk(state, dtype=torch.int32)
+    check(_lib.load().ds_llm_advance(_p(state), rows, _stream()), "ds_llm_advance")
+
+
+def blend(a: Tensor, b: Tensor, scale: float) -> Tensor:
+    """a*scale + b*(1-scale) (fp16, same shape, numel % 8 == 0)."""
+    _chk(a, b)
+    assert a.shape == b.shape
+    out = torch.empty_like(a)
+    check(_lib.load().ds_blend_f16(_p(a), _p(b), _p(out), a.numel(), scale, _stream()), "ds_blend_f16")
+    return out

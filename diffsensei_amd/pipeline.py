@@ -135,27 +135,41 @@ class DiffSenseiPipeline:
             self._clip_proc, self._magi_proc = CLIPImageProcessor(), ViTImageProcessor()
         return self._clip_proc, self._magi_proc
 
+    def _encode_refs(self, ip_images, zero_padded: bool):
+        """CLIP penultimate states [1,4,257,1280] and Magi CLS embeddings [1,4,768] of the (black-padded) references."""
+        max_num_ips = self.unet.config.max_num_ips
+        ip_images = list(ip_images)[:max_num_ips]
+        num_ips = len(ip_images)
+        while len(ip_images) < max_num_ips:
+            ip_images.append(_black_image())
+        clip_proc, magi_proc = self._processors()
+        clip_px = clip_proc(images=ip_images, return_tensors="pt").pixel_values
+        magi_px = magi_proc(images=ip_images, return_tensors="pt").pixel_values
+        clip_embeds = self.image_encoder.penultimate_hidden(clip_px).unsqueeze(0)
+        magi_embeds = self.magi_image_encoder.cls_embedding(magi_px).unsqueeze(0)
+        if zero_padded:
+            clip_embeds[0, num_ips:] = 0
+            magi_embeds[0, num_ips:] = 0
+        return clip_embeds, magi_embeds
+
+    def encode_ip_tokens(self, ip_images) -> Tensor:
+        """Resampler tokens [1, num_dummy + max_num_ips*num_vision_tokens, dim] of the references exactly as the MLLM
+        pre-pass computes them (reference scripts/demo/gradio.py:85-98: black padding, padded slots NOT zeroed)."""
+        clip_embeds, magi_embeds = self._encode_refs(ip_images, zero_padded=False)
+        x = self.image_proj_model(clip_embeds, magi_embeds)
+        return x.view(1, -1, x.shape[-1])
+
     # ---- reference :104-154
     def prepare_ip_image_embeds(self, ip_images, ip_image_embeds, ip_bbox, num_samples):
         cfg = self.unet.config
         dev = self._execution_device
         max_num_ips = cfg.max_num_ips
-        ip_images = list(ip_images)[:max_num_ips]
         if ip_image_embeds is not None:
             ip_image_embeds = ip_image_embeds[:max_num_ips]
         ip_bbox = [list(b) for b in ip_bbox][:max_num_ips]
-        num_ips = len(ip_images)
-        while len(ip_images) < max_num_ips:
-            ip_images.append(_black_image())
         while len(ip_bbox) < max_num_ips:
             ip_bbox.append([0.0, 0.0, 0.0, 0.0])
-        clip_proc, magi_proc = self._processors()
-        clip_px = clip_proc(images=ip_images, return_tensors="pt").pixel_values
-        magi_px = magi_proc(images=ip_images, return_tensors="pt").pixel_values
-        clip_embeds = self.image_encoder.penultimate_hidden(clip_px).unsqueeze(0)          # [1,4,257,1280]
-        magi_embeds = self.magi_image_encoder.cls_embedding(magi_px).unsqueeze(0)           # [1,4,768]
-        clip_embeds[0, num_ips:] = 0
-        magi_embeds[0, num_ips:] = 0
+        clip_embeds, magi_embeds = self._encode_refs(ip_images, zero_padded=True)   # [1,4,257,1280], [1,4,768]
         image_embeds = self.image_proj_model(clip_embeds, magi_embeds)
         negative_image_embeds = self.image_proj_model(torch.zeros_like(clip_embeds), torch.zeros_like(magi_embeds))
         bbox = torch.tensor(ip_bbox, dtype=torch.float32).unsqueeze(0).to(dev)

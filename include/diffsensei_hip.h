@@ -116,7 +116,7 @@ int ds_masked_ip_attn_f16(const void* q, int64_t ldq, const void* kt, const void
 int ds_ip_region_flags(const float* bbox, uint8_t* flags, int B, int N, int max_ips, int mask_h, int mask_w,
                        void* stream);
 
-/* generic small attention (head_dim <= 128, arbitrary lengths): encoders + perceiver resampler
+/* generic small attention (head_dim <= 256, arbitrary lengths): encoders + perceiver resampler
  * (reference src/models/resampler.py:67-72).  q/k/v/o: [B,N,ld] with head h at column h*D. */
 int ds_small_attn_f16(const void* q, int64_t ldq, int64_t sq, const void* k, int64_t ldk, int64_t sk, const void* v,
                       int64_t ldv, int64_t sv, void* o, int64_t ldo, int64_t so, int B, int heads, int Nq, int Nk,
@@ -165,6 +165,45 @@ int ds_pad_rows_f16(const void* x, void* y, int B, int rows_in, int rows_out, in
                     void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * MLLM pre-pass: LLaMA greedy decoding with a KV cache.
+ * Replaces, for batch 1, `self.llm.generate(...)` as driven by reference src/models/mllm/seed_x.py:121-136
+ * (LlamaForCausalLM of src/models/mllm/modeling_llama_xformer.py:612-, logits processor of
+ * src/models/mllm/generation.py:19-30).  All kernels read the step-varying scalars from a device-side state block
+ *     int32 state[8] = {rows in the KV cache, tokens generated, finished flag, current token id,
+ *                       max_new_tokens of this call, eos token id, spare, spare}
+ * so one token step is a static launch list (DS_OP_LLM_* above) that replays as a hipGraph.
+ * ---------------------------------------------------------------------------------------------- */
+/* y[M,N] = r_m * (x[M,K] @ w[N,K]^T) (+ residual), r_m = rsqrt(mean(x_m^2)+eps) when `rms` (an RMSNorm whose gain has
+ * been folded into w by the host: LlamaRMSNorm + the q/k/v or gate/up projections, modeling_llama_xformer.py:277-296);
+ * `swiglu`: w is [2N,K] (gate rows, then up rows) and y = silu(x.w_gate) * (x.w_up) (LlamaMLP.forward :166-167).
+ * M <= 16 rows per pass internally; HBM-bound weight streaming, one wavefront per output column. */
+int ds_llm_gemv_f16(const void* x, int64_t ldx, const void* w, void* y, int64_t ldy, const void* residual,
+                    int64_t ldr, int M, int N, int K, int rms, int swiglu, float eps, void* stream);
+/* rotary embedding + KV-cache append + attention for M (<= 16) new rows at positions state[0] .. state[0]+M-1
+ * (LlamaAttention.forward :192-244: causal inside the prompt chunk, every cached key for a single new token).
+ * qkv: [M,(heads+2*kv_heads)*D] un-rotated q|k|v; caches [T_max,kv_heads*D]; rope tables fp32 [T_max,D/2];
+ * D in {64,128}.  Does NOT advance state[0] (ds_llm_select_f16 / ds_llm_advance do, once per step). */
+int ds_llm_attn_f16(const void* qkv, int64_t ldqkv, void* k_cache, void* v_cache, int64_t ldc, const float* rope_cos,
+                    const float* rope_sin, void* out, int64_t ldo, const int32_t* state, int M, int heads,
+                    int kv_heads, int D, int T_max, float scale, void* stream);
+/* LlamaRMSNorm with its gain (the final `model.norm`, :595).  `feat` (may be NULL; M == 1): the row is also stored as
+ * row state[1]-1 of a [max_out,H] buffer - the per-token hidden states seed_x.py:143 gathers. */
+int ds_llm_rmsnorm_f16(const void* x, int64_t ldx, const void* gamma, void* y, int64_t ldy, void* feat,
+                       const int32_t* state, int M, int H, int max_out, float eps, void* stream);
+/* out[0,:] = embed_tokens[state[3]] */
+int ds_llm_embed_f16(const void* table, const int32_t* state, void* out, int H, int vocab, void* stream);
+/* greedy choice with AutoImageTokenGenerationProcessor (generation.py:19-30) folded in; chain = [<img>, <img_0> ..
+ * <img_{n-1}>, </img>] (n_chain ids, 0 = no processor).  Appends to out_ids[state[1]++] (capacity out_cap), sets
+ * state[3], adds `adv` to state[0], raises state[2] on the eos id (state[5]) or after state[4] ids.  A no-op once
+ * state[2] is set. */
+int ds_llm_select_f16(const void* logits, int V, const int32_t* chain, int n_chain, int out_cap, int adv,
+                      int32_t* state, int32_t* out_ids, void* stream);
+int ds_llm_advance(int32_t* state, int rows, void* stream); /* state[0] += rows (prompt chunks before the last) */
+/* out = a*scale + b*(1-scale), n elements (multiple of 8): `img_gen_feat * mllm_scale + image_embeds * (1 - mllm_scale)`
+ * (reference scripts/demo/gradio.py:108-109) */
+int ds_blend_f16(const void* a, const void* b, void* out, int64_t n, float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Plans: a static launch list (one UNet forward, or forward + CFG + scheduler step) built once by the host
  * and replayed with zero host arithmetic — optionally as a captured hipGraph.
  * ---------------------------------------------------------------------------------------------- */
@@ -188,7 +227,14 @@ enum ds_opcode {
     DS_OP_NHWC2NCHW = 15,    /* p: x, y                                   i: B HW C */
     DS_OP_NCHW2NHWC = 16,    /* p: x, y                                   i: B HW C */
     DS_OP_PAD_ROWS = 17,     /* p: x, y                                   i: B rows_in rows_out row_off total_rows C */
-    DS_OP_SMALL_ATTN = 18    /* p: q, k, v, o   l: ldq ldk ldv ldo sq sk sv so   i: B heads Nq Nk D   f: scale */
+    DS_OP_SMALL_ATTN = 18,   /* p: q, k, v, o   l: ldq ldk ldv ldo sq sk sv so   i: B heads Nq Nk D   f: scale */
+    DS_OP_LLM_GEMV = 19,     /* p: x, w, y, residual        l: ldx ldy ldr   i: M N K rms swiglu      f: eps */
+    DS_OP_LLM_ATTN = 20,     /* p: qkv, k_cache, v_cache, rope_cos, rope_sin, out, state   l: ldqkv ldc ldo
+                                i: M heads kv_heads D T_max                                           f: scale */
+    DS_OP_LLM_RMSNORM = 21,  /* p: x, gamma, y, feat, state l: ldx ldy       i: M H max_out           f: eps */
+    DS_OP_LLM_EMBED = 22,    /* p: table, state, out                         i: H vocab */
+    DS_OP_LLM_SELECT = 23,   /* p: logits, chain, state, out_ids             i: V n_chain out_cap adv */
+    DS_OP_LLM_ADVANCE = 24   /* p: state                                     i: rows */
 };
 
 typedef struct ds_op {

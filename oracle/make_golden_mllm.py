@@ -26,8 +26,8 @@ TINY = dict(vocab_size=640, hidden_size=256, intermediate_size=704, num_hidden_l
 N_IMG = 16                                    # image tokens per <img> block (= queries of the output resampler)
 BOI, EOI = 600, 600 + N_IMG + 1
 IMG_IDS = [BOI] + [601 + i for i in range(N_IMG)] + [EOI]
-RES_IN = dict(grid_size=4, embed_dim=256, num_heads=4, kv_dim=96)      # sampler tokens (96) -> LLM width (256)
-RES_OUT = dict(grid_size=4, embed_dim=96, num_heads=4, kv_dim=256)     # LLM hidden (256) -> sampler tokens (96)
+RES_IN = dict(grid_size=4, embed_dim=256, num_heads=4, kv_dim=128)     # sampler tokens (128) -> LLM width (256)
+RES_OUT = dict(grid_size=4, embed_dim=128, num_heads=4, kv_dim=256)    # LLM hidden (256) -> sampler tokens (128)
 MAX_NEW = 28
 
 

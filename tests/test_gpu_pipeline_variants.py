@@ -208,3 +208,56 @@ def test_forward_flop_inventory_matches_survey(hip_lib):
         tot += fl.value
     assert abs(tot / 1e12 - (13.71 - 0.22)) < 0.05, tot / 1e12
     assert len(eng.forward_ops) == 963          # + CFG/scheduler step + counter advance = 965 launches per denoise step
+
+
+def test_mllm_prepass_end_to_end(pipe):
+    """scripts/demo/gradio.py:85-129 as one chain: references -> Resampler tokens -> input resampler -> LLaMA greedy
+    decode (forced 64-token image block) -> output resampler -> blend -> `ip_image_embeds` of the sampler; every stage
+    on the HIP kernels, compared with the same chain through the fp32 oracles."""
+    from PIL import Image
+    from transformers import CLIPImageProcessor, ViTImageProcessor
+    from diffsensei_amd.mllm import ContinuousLVLM, LlamaConfig, LlamaDecodeEngine, QwenResampler, mllm_prepass
+    from oracle import llama_ref as R
+    from oracle import make_golden_mllm as G
+    from oracle.resampler_ref import resampler_forward
+    p, cfg, sd, rs, clip, mae, common = pipe
+    X = cfg.cross_attention_dim
+    n_img = cfg.max_num_ips * cfg.num_vision_tokens                                        # 64
+    chain = [520] + [521 + i for i in range(n_img)] + [521 + n_img]
+    gi = torch.Generator().manual_seed(21)
+    ids = [1] + torch.randint(3, 500, (5,), generator=gi).tolist() + chain + torch.randint(3, 500, (3,), generator=gi).tolist() + [520]
+    input_ids = torch.tensor(ids)
+    mask = torch.zeros(len(ids), dtype=torch.bool)
+    mask[7:7 + n_img] = True
+    res_in_cfg = dict(grid_size=8, embed_dim=256, num_heads=4, kv_dim=X)
+    res_out_cfg = dict(grid_size=8, embed_dim=X, num_heads=4, kv_dim=256)
+    llm_sd, sd_in, sd_out = G.tiny_weights(), G.tiny_resampler(res_in_cfg, 31), G.tiny_resampler(res_out_cfg, 32)
+    lcfg = LlamaConfig(vocab_size=G.TINY["vocab_size"], hidden_size=256, intermediate_size=G.TINY["intermediate_size"],
+                       num_hidden_layers=2, num_attention_heads=2, rms_norm_eps=G.TINY["rms_norm_eps"])
+    agent = ContinuousLVLM(LlamaDecodeEngine(lcfg, llm_sd, DEV, max_positions=192, max_new_tokens=80),
+                           QwenResampler(sd_in, 4, DEV), QwenResampler(sd_out, 4, DEV))
+    imgs = [Image.fromarray(np.random.RandomState(s).randint(0, 256, (224, 224, 3), dtype=np.uint8)) for s in (1, 2)]
+    mllm_scale, max_new, eos = 0.7, n_img + 4, 2
+    got = mllm_prepass(p, agent, input_ids, mask, list(imgs), mllm_scale, img_ids_list=chain, eos_token_id=eos,
+                       max_new_tokens=max_new)
+    assert got.shape == (cfg.max_num_ips, cfg.num_vision_tokens, X) and got.dtype == torch.float16
+    # the same chain in fp32 (padded reference slots are NOT zeroed on this path, gradio.py:91-97)
+    padded = list(imgs) + [Image.new("RGB", (224, 224))] * (cfg.max_num_ips - len(imgs))
+    with torch.no_grad():
+        ce = clip(CLIPImageProcessor()(images=padded, return_tensors="pt").pixel_values,
+                  output_hidden_states=True).hidden_states[-2].unsqueeze(0)
+        me = mae(ViTImageProcessor()(images=padded, return_tensors="pt").pixel_values).last_hidden_state[:, 0].unsqueeze(0)
+        rsd = {k: v.float().cpu() for k, v in rs.state_dict().items()}
+        toks = hq(resampler_forward(rsd, ce, me, 2, 64))[:, cfg.num_vision_tokens:]          # [1,64,X]
+    ref = R.lvlm_generate(llm_sd, R.LlamaRefConfig(**G.TINY), sd_in, sd_out, (4, 4), input_ids, toks, mask, chain, eos,
+                          max_new, n_img)
+    assert ref["output_ids"][:n_img + 1].tolist() == chain[1:], "oracle: forced image block"
+    want = R.blend_ip_embeds(ref["img_gen_feat"], toks, mllm_scale, cfg.max_num_ips, cfg.num_vision_tokens)
+    assert _rel(got, want) <= 3e-2, _rel(got, want)
+    # ... and into the sampler exactly like gradio.py:112-129 (`ip_images=[]`, `ip_image_embeds=`)
+    boxes = [[0.0, 0.0, 0.5, 1.0], [0.5, 0.0, 1.0, 1.0], [0.0] * 4, [0.0] * 4]    # gradio.py:85-89 pads the boxes to 4
+    lat0 = torch.randn(1, 4, 16, 16, generator=torch.Generator().manual_seed(4)).half()
+    out = p(ip_images=[], ip_image_embeds=got, ip_bbox=[list(b) for b in boxes], dialog_bbox=[], ip_scale=0.6,
+            latents=lat0.clone(), **common).images
+    ref_lat = _oracle(cfg, sd, rs, clip, mae, common, [], boxes, [], 1, lat0, ip_embeds=hq(want))
+    assert _rel(out, ref_lat) <= 5e-2, _rel(out, ref_lat)
