@@ -61,6 +61,11 @@ int ds_set_option(const char* key, int value) {
         ds_conv_halo_set_variant(value);
         return 0;
     }
+    if (strcmp(key, "llm_gemv_variant") == 0) {
+        DS_REQUIRE(value >= 0 && value <= 2, "llm_gemv_variant must be 0..2");
+        ds_llm_gemv_set_variant(value);
+        return 0;
+    }
     if (strcmp(key, "gemm_debug") == 0) {
         ds_gemm_set_debug(value);
         return 0;

@@ -124,13 +124,15 @@ __device__ __forceinline__ void rope_chunk(const half_t* row, int c, const float
     for (int e = 0; e < 8; ++e) out[e] = (float)a[e] * cs[d0 + e] + sgn * (float)b[e] * sn[d0 + e];
 }
 
+constexpr int ATT_WAVES = 16;  // one key group per wavefront per iteration: the loop is a chain of dependent loads
+
 template <int D>
-__global__ __launch_bounds__(256) void llm_attn_kernel(LlmAttnParams p) {
+__global__ __launch_bounds__(64 * ATT_WAVES) void llm_attn_kernel(LlmAttnParams p) {
     constexpr int LPK = D / 8, KPW = 64 / LPK, HALF = D / 2;
     extern __shared__ float sm[];
     float* sc = sm;                    // [T_max] scores, then probabilities
-    float* red = sm + p.T_max;         // [4][D]
-    float* misc = red + 4 * D;         // [8]
+    float* red = sm + p.T_max;         // [ATT_WAVES][D]
+    float* misc = red + ATT_WAVES * D;  // [2 * ATT_WAVES]
     const int h = blockIdx.x, r = blockIdx.y;
     const int hkv = h / (p.heads / p.kv_heads);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(256) void llm_attn_kernel(LlmAttnParams p) {
 
     // ---- scores
     float mx = -3.0e38f;
-    for (int g = wave; g * KPW < T; g += 4) {
+    for (int g = wave; g * KPW < T; g += ATT_WAVES) {
         const int j = g * KPW + ks;
         float s = 0.f;
         if (j < T) {
@@ -175,23 +177,27 @@ __global__ __launch_bounds__(256) void llm_attn_kernel(LlmAttnParams p) {
     mx = wave_max(mx);
     if (lane == 0) misc[wave] = mx;
     __syncthreads();
-    mx = fmaxf(fmaxf(misc[0], misc[1]), fmaxf(misc[2], misc[3]));
+#pragma unroll
+    for (int w = 0; w < ATT_WAVES; ++w) mx = fmaxf(mx, misc[w]);
     float sum = 0.f;
-    for (int j = tid; j < T; j += 256) {
+    for (int j = tid; j < T; j += 64 * ATT_WAVES) {
         const float e = __expf(sc[j] - mx);
         sc[j] = e;
         sum += e;
     }
     sum = wave_sum(sum);
-    if (lane == 0) misc[4 + wave] = sum;
+    if (lane == 0) misc[ATT_WAVES + wave] = sum;
     __syncthreads();
-    const float inv = 1.0f / (misc[4] + misc[5] + misc[6] + misc[7]);
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < ATT_WAVES; ++w) tot += misc[ATT_WAVES + w];
+    const float inv = 1.0f / tot;
 
     // ---- P V
     float acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-    for (int g = wave; g * KPW < T; g += 4) {
+    for (int g = wave; g * KPW < T; g += ATT_WAVES) {
         const int j = g * KPW + ks;
         if (j < T) {
             const float pj = (float)(half_t)(sc[j] * inv);  // the reference casts the probabilities to fp16
@@ -213,7 +219,9 @@ __global__ __launch_bounds__(256) void llm_attn_kernel(LlmAttnParams p) {
     }
     __syncthreads();
     if (tid < D) {
-        const float o = red[tid] + red[D + tid] + red[2 * D + tid] + red[3 * D + tid];
+        float o = 0.f;
+#pragma unroll
+        for (int w = 0; w < ATT_WAVES; ++w) o += red[w * D + tid];
         p.out[(long)r * p.ldo + (long)h * D + tid] = (half_t)o;
     }
     // ---- append this row's rotated key and its value (one query head per kv head does it)
@@ -363,8 +371,221 @@ __global__ __launch_bounds__(256) void blend_kernel(const half_t* __restrict__ a
     *reinterpret_cast<h8*>(out + k) = o;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Token-loop variant (M <= 4): the kernel above keeps only ~4 KB of weights in flight per wavefront and spends a third
+// of each wavefront's life on the x prologue - measured 3.9 TB/s on the 13 B model.  Here the block stages x (and the
+// row scales) in LDS once, every wavefront walks several output columns, and each column iteration has 8 KB (plain) /
+// 2 x 4 KB (SwiGLU) of independent 16-byte weight loads in flight before the first dot product.
+// ---------------------------------------------------------------------------------------------------------------
+template <int MC, int SWIGLU>
+__global__ __launch_bounds__(256) void llm_gemv_stream_kernel(LlmGemvParams p) {
+    extern __shared__ char smem_raw[];
+    half_t* xs = reinterpret_cast<half_t*>(smem_raw);               // [MC][K]
+    float* rs = reinterpret_cast<float*>(smem_raw + (size_t)MC * p.K * 2);  // [MC] row scales, then [MC][4] partials
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = p.K;
+    {
+        float ss[MC];
+#pragma unroll
+        for (int m = 0; m < MC; ++m) {
+            ss[m] = 0.f;
+            for (int k = tid * 8; k < K; k += 2048) {
+                h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (m < p.M) v = *reinterpret_cast<const h8*>(p.x + (long)m * p.ldx + k);
+                *reinterpret_cast<h8*>(xs + (long)m * K + k) = v;
+                ss[m] = dot8(v, v, ss[m]);
+            }
+            ss[m] = wave_sum(ss[m]);
+            if (lane == 0) rs[MC + m * 4 + wave] = ss[m];
+        }
+        __syncthreads();
+        if (tid < MC) {
+            const float s = rs[MC + tid * 4] + rs[MC + tid * 4 + 1] + rs[MC + tid * 4 + 2] + rs[MC + tid * 4 + 3];
+            rs[tid] = p.rms ? __builtin_amdgcn_rsqf(s / (float)K + p.eps) : 1.0f;
+        }
+        __syncthreads();
+    }
+    constexpr int U = SWIGLU ? 4 : 8;
+    for (int n = blockIdx.x * 4 + wave; n < p.N; n += gridDim.x * 4) {
+        float acc[MC], acu[MC];
+#pragma unroll
+        for (int m = 0; m < MC; ++m) acc[m] = acu[m] = 0.f;
+        const half_t* wg = p.w + (long)n * K;
+        const half_t* wu = p.w + ((long)n + p.N) * K;
+        for (int k0 = lane * 8; k0 < K; k0 += 512 * U) {
+            h8 wv[U], uv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int k = min(k0 + 512 * u, K - 8);
+                wv[u] = *reinterpret_cast<const h8*>(wg + k);
+                if (SWIGLU) uv[u] = *reinterpret_cast<const h8*>(wu + k);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int k = k0 + 512 * u;
+                if (k < K) {
+#pragma unroll
+                    for (int m = 0; m < MC; ++m) {
+                        const h8 xv = *reinterpret_cast<const h8*>(xs + (long)m * K + k);
+                        acc[m] = dot8(xv, wv[u], acc[m]);
+                        if (SWIGLU) acu[m] = dot8(xv, uv[u], acu[m]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < MC; ++m) {
+            acc[m] = wave_sum(acc[m]) * rs[m];
+            if (SWIGLU) acu[m] = wave_sum(acu[m]) * rs[m];
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int m = 0; m < MC; ++m) {
+                if (m < p.M) {
+                    float o;
+                    if (SWIGLU) {
+                        const float g = (float)(half_t)acc[m], u = (float)(half_t)acu[m];
+                        o = (float)(half_t)ds_silu(g) * u;
+                    } else {
+                        o = (float)(half_t)acc[m];
+                        if (p.residual) o += (float)p.residual[(long)m * p.ldr + n];
+                    }
+                    p.y[(long)m * p.ldy + n] = (half_t)o;
+                }
+            }
+        }
+    }
+}
+
+// Same data path, software-pipelined: the weight loads of the NEXT k-block (or of the next column's first k-block) are
+// issued before the dot products of the current one, and the first block is requested before x is staged, so a
+// wavefront always has 8 KB of weights in flight - no load bubble at block start, between k-blocks or between columns.
+template <int MC, int SWIGLU>
+__global__ __launch_bounds__(256) void llm_gemv_pipe_kernel(LlmGemvParams p) {
+    extern __shared__ char smem_raw[];
+    half_t* xs = reinterpret_cast<half_t*>(smem_raw);
+    float* rs = reinterpret_cast<float*>(smem_raw + (size_t)MC * p.K * 2);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = p.K, N = p.N;
+    constexpr int U = SWIGLU ? 4 : 8;
+    const int NIT = (K + 512 * U - 1) / (512 * U);
+    const int stride = gridDim.x * 4;
+    int n = blockIdx.x * 4 + wave;
+    h8 wa[U], ua[U], wb[U], ub[U];
+    auto issue = [&](int col, int it, h8(&wv)[U], h8(&uv)[U]) {
+        const half_t* wg = p.w + (long)col * K;
+        const half_t* wu = p.w + ((long)col + N) * K;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = min(it * 512 * U + 512 * u + lane * 8, K - 8);
+            wv[u] = *reinterpret_cast<const h8*>(wg + k);
+            if (SWIGLU) uv[u] = *reinterpret_cast<const h8*>(wu + k);
+        }
+    };
+    if (n < N) issue(n, 0, wa, ua);
+    {
+        float ss[MC];
+#pragma unroll
+        for (int m = 0; m < MC; ++m) {
+            ss[m] = 0.f;
+            for (int k = tid * 8; k < K; k += 2048) {
+                h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (m < p.M) v = *reinterpret_cast<const h8*>(p.x + (long)m * p.ldx + k);
+                *reinterpret_cast<h8*>(xs + (long)m * K + k) = v;
+                ss[m] = dot8(v, v, ss[m]);
+            }
+            ss[m] = wave_sum(ss[m]);
+            if (lane == 0) rs[MC + m * 4 + wave] = ss[m];
+        }
+        __syncthreads();
+        if (tid < MC) {
+            const float s = rs[MC + tid * 4] + rs[MC + tid * 4 + 1] + rs[MC + tid * 4 + 2] + rs[MC + tid * 4 + 3];
+            rs[tid] = p.rms ? __builtin_amdgcn_rsqf(s / (float)K + p.eps) : 1.0f;
+        }
+        __syncthreads();
+    }
+    while (n < N) {
+        float acc[MC], acu[MC];
+#pragma unroll
+        for (int m = 0; m < MC; ++m) acc[m] = acu[m] = 0.f;
+        for (int it = 0; it < NIT; ++it) {
+            const bool last = it + 1 == NIT;
+            const int ncol = last ? n + stride : n;
+            if (ncol < N) issue(ncol, last ? 0 : it + 1, wb, ub);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int k = it * 512 * U + 512 * u + lane * 8;
+                if (k < K) {
+#pragma unroll
+                    for (int m = 0; m < MC; ++m) {
+                        const h8 xv = *reinterpret_cast<const h8*>(xs + (long)m * K + k);
+                        acc[m] = dot8(xv, wa[u], acc[m]);
+                        if (SWIGLU) acu[m] = dot8(xv, ua[u], acu[m]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                wa[u] = wb[u];
+                if (SWIGLU) ua[u] = ub[u];
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < MC; ++m) {
+            acc[m] = wave_sum(acc[m]) * rs[m];
+            if (SWIGLU) acu[m] = wave_sum(acu[m]) * rs[m];
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int m = 0; m < MC; ++m) {
+                if (m < p.M) {
+                    float o;
+                    if (SWIGLU) {
+                        const float g = (float)(half_t)acc[m], u = (float)(half_t)acu[m];
+                        o = (float)(half_t)ds_silu(g) * u;
+                    } else {
+                        o = (float)(half_t)acc[m];
+                        if (p.residual) o += (float)p.residual[(long)m * p.ldr + n];
+                    }
+                    p.y[(long)m * p.ldy + n] = (half_t)o;
+                }
+            }
+        }
+        n += stride;
+    }
+}
+
+int g_llm_gemv_variant = 0;  // 0 auto (pipelined), 1 one-column-per-wavefront kernel, 2 un-pipelined streaming kernel
+
+template <int MC, int SWIGLU>
+int launch_gemv_stream(const LlmGemvParams& p, hipStream_t stream) {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -2;
+        cus = prop.multiProcessorCount;
+    }
+    const size_t lds = (size_t)MC * p.K * 2 + (size_t)MC * 5 * sizeof(float);
+    // resident blocks per CU: 8 x 4 wavefronts at <= 64 VGPRs (streaming kernel), 5 at ~90 VGPRs (pipelined kernel);
+    // launching exactly the resident set makes every wavefront walk the same number of columns (no tail round)
+    const size_t by_regs = g_llm_gemv_variant == 2 ? 8 : 5;
+    const int per_cu = (int)min(by_regs, (size_t)(160 * 1024) / (lds + 512));
+    const int blocks = min((p.N + 3) / 4, cus * max(per_cu, 1));
+    if (g_llm_gemv_variant == 2) hipLaunchKernelGGL((llm_gemv_stream_kernel<MC, SWIGLU>), dim3(blocks), dim3(256), lds, stream, p);
+    else hipLaunchKernelGGL((llm_gemv_pipe_kernel<MC, SWIGLU>), dim3(blocks), dim3(256), lds, stream, p);
+    DS_LAUNCH_CHECK();
+    return 0;
+}
+
 template <int SWIGLU>
 int launch_gemv(const LlmGemvParams& p, hipStream_t stream) {
+    const int mcs = p.M == 1 ? 1 : p.M == 2 ? 2 : 4;  // LDS copy of x must fit the default 64 KiB dynamic limit
+    if (p.M <= 4 && g_llm_gemv_variant != 1 && (size_t)mcs * p.K * 2 + 128 <= 64 * 1024) {
+        if (p.M == 1) return launch_gemv_stream<1, SWIGLU>(p, stream);
+        if (p.M == 2) return launch_gemv_stream<2, SWIGLU>(p, stream);
+        return launch_gemv_stream<4, SWIGLU>(p, stream);
+    }
     const int mc = p.M <= 1 ? 1 : p.M <= 2 ? 2 : p.M <= 4 ? 4 : p.M <= 8 ? 8 : 16;
     const dim3 grid((p.N + 3) / 4, (p.M + mc - 1) / mc);
     switch (mc) {
@@ -379,6 +600,8 @@ int launch_gemv(const LlmGemvParams& p, hipStream_t stream) {
 }
 
 }  // namespace
+
+void ds_llm_gemv_set_variant(int v) { g_llm_gemv_variant = v; }
 
 int ds_launch_llm_gemv(const LlmGemvParams& p, hipStream_t stream) {
     DS_REQUIRE(p.M > 0 && p.N > 0 && p.K >= 8 && p.K % 8 == 0, "llm_gemv: bad shape M=%d N=%d K=%d", p.M, p.N, p.K);
@@ -396,10 +619,10 @@ int ds_launch_llm_attn(const LlmAttnParams& p, hipStream_t stream) {
     DS_REQUIRE(p.T_max > 0 && p.T_max <= 8192, "llm_attn: cache length %d (max 8192)", p.T_max);
     DS_REQUIRE(p.ldqkv % 8 == 0 && p.ldc % 8 == 0, "llm_attn: row strides must be multiples of 8");
     DS_REQUIRE(p.qkv && p.kc && p.vc && p.rope_cos && p.rope_sin && p.out && p.state, "llm_attn: null operand");
-    const size_t lds = (size_t)(p.T_max + 4 * p.D + 8) * sizeof(float);
+    const size_t lds = (size_t)(p.T_max + ATT_WAVES * p.D + 2 * ATT_WAVES) * sizeof(float);
     const dim3 grid(p.heads, p.M);
-    if (p.D == 128) hipLaunchKernelGGL(llm_attn_kernel<128>, grid, dim3(256), lds, stream, p);
-    else hipLaunchKernelGGL(llm_attn_kernel<64>, grid, dim3(256), lds, stream, p);
+    if (p.D == 128) hipLaunchKernelGGL(llm_attn_kernel<128>, grid, dim3(64 * ATT_WAVES), lds, stream, p);
+    else hipLaunchKernelGGL(llm_attn_kernel<64>, grid, dim3(64 * ATT_WAVES), lds, stream, p);
     DS_LAUNCH_CHECK();
     return 0;
 }

@@ -17,8 +17,12 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--layers", type=int, default=40)
 ap.add_argument("--prompt", type=int, default=96)
 ap.add_argument("--new", type=int, default=192)
+ap.add_argument("--graph", choices=["both", "on", "off"], default="both")
+ap.add_argument("--gemv-variant", type=int, default=0, help="0 pipelined, 1 one column per wavefront, 2 streaming")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
+from diffsensei_amd import _lib
+assert _lib.load().ds_set_option(b"llm_gemv_variant", a.gemv_variant) == 0
 cfg = LlamaConfig(num_hidden_layers=a.layers)
 t0 = time.perf_counter()
 sd = random_llama_state_dict(cfg, dev, 0)
@@ -28,7 +32,7 @@ torch.cuda.synchronize()
 init_s = time.perf_counter() - t0
 emb = (torch.randn(a.prompt, cfg.hidden_size, device=dev) * 0.5).half()
 rows = []
-for graph in (True, False):
+for graph in {"both": (True, False), "on": (True,), "off": (False,)}[a.graph]:
     eng.use_graph = graph
     for rep in range(2):                                   # rep 0 warms up (and captures)
         torch.cuda.synchronize()
@@ -49,4 +53,4 @@ print(json.dumps({"workload": f"LLaMA-2-13B dims x {a.layers} layers, batch 1 gr
                   "tokens_per_s": round(1e3 / best, 2),
                   "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
                                "frac": round(gbs / 8000.0, 4)},
-                  "ops_per_token": eng.last_run_info["ops_per_token"]}))
+                  "ops_per_token": eng.last_run_info["ops_per_token"], "gemv_variant": a.gemv_variant}))
