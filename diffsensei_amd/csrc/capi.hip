@@ -288,6 +288,10 @@ int ds_llm_select_f16(const void* logits, int V, const int32_t* chain, int n_cha
 
 int ds_llm_advance(int32_t* state, int rows, void* stream) { return ds_launch_llm_advance(state, rows, S(stream)); }
 
+int ds_llm_swiglu_f16(const void* gate_up, void* act, int M, int I, void* stream) {
+    return ds_launch_llm_swiglu(H(gate_up), HM(act), M, I, S(stream));
+}
+
 int ds_blend_f16(const void* a, const void* b, void* out, int64_t n, float scale, void* stream) {
     return ds_launch_blend(H(a), H(b), HM(out), (long)n, scale, S(stream));
 }

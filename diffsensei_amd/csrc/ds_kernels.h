@@ -171,3 +171,4 @@ int ds_launch_llm_select(const half_t* logits, int V, const int* chain, int n_ch
                          int* out_ids, hipStream_t stream);
 int ds_launch_llm_advance(int* state, int rows, hipStream_t stream);
 int ds_launch_blend(const half_t* a, const half_t* b, half_t* out, long n, float s, hipStream_t stream);
+int ds_launch_llm_swiglu(const half_t* gu, half_t* act, int M, int I, hipStream_t stream);

@@ -355,6 +355,20 @@ __global__ __launch_bounds__(1024) void llm_select_kernel(const half_t* __restri
     }
 }
 
+// act[m][n] = silu(gu[m][n]) * gu[m][I+n]  (prompt pass: the gate|up projection comes out of the MFMA GEMM as [M,2I])
+__global__ __launch_bounds__(256) void llm_swiglu_kernel(const half_t* __restrict__ gu, half_t* __restrict__ act,
+                                                         int M, int I) {
+    const long idx = ((long)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (idx >= (long)M * I) return;
+    const long m = idx / I, n = idx - m * I;
+    const h8 g = *reinterpret_cast<const h8*>(gu + m * 2 * I + n);
+    const h8 u = *reinterpret_cast<const h8*>(gu + m * 2 * I + I + n);
+    h8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)(half_t)ds_silu((float)g[e]) * (float)u[e]);
+    *reinterpret_cast<h8*>(act + idx) = o;
+}
+
 __global__ void llm_advance_kernel(int* state, int rows) {
     if (threadIdx.x == 0 && blockIdx.x == 0) state[0] += rows;
 }
@@ -650,6 +664,14 @@ int ds_launch_llm_select(const half_t* logits, int V, const int* chain, int n_ch
     DS_REQUIRE(n_chain == 0 || chain, "llm_select: chain ids missing");
     hipLaunchKernelGGL(llm_select_kernel, dim3(1), dim3(1024), 0, stream, logits, V, chain, n_chain, out_cap, adv, state,
                        out_ids);
+    DS_LAUNCH_CHECK();
+    return 0;
+}
+
+int ds_launch_llm_swiglu(const half_t* gu, half_t* act, int M, int I, hipStream_t stream) {
+    DS_REQUIRE(M > 0 && I >= 8 && I % 8 == 0 && gu && act, "llm_swiglu: bad shape M=%d I=%d", M, I);
+    const long n8 = (long)M * I / 8;
+    hipLaunchKernelGGL(llm_swiglu_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, stream, gu, act, M, I);
     DS_LAUNCH_CHECK();
     return 0;
 }

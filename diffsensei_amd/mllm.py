@@ -95,8 +95,10 @@ class LlamaDecodeEngine:
     """Device-resident LLaMA decoder + KV cache + the captured one-token launch plan."""
 
     def __init__(self, cfg: LlamaConfig, sd: Dict[str, Tensor], device, max_positions: int = 1024,
-                 max_new_tokens: int = 512, use_graph: bool = True, poll_every: int = 8):
+                 max_new_tokens: int = 512, use_graph: bool = True, poll_every: int = 8, prompt_path: str = "mfma"):
         _lib.load()
+        if prompt_path not in ("mfma", "chunks"):
+            raise ValueError("prompt_path: 'mfma' (GEMM projections) or 'chunks' (16-row passes of the token kernels)")
         self.cfg, self.dev = cfg, torch.device(device)
         self.T_max, self.cap = int(max_positions), int(max_new_tokens)
         self.use_graph, self.poll_every = use_graph, max(1, int(poll_every))
@@ -136,6 +138,9 @@ class LlamaDecodeEngine:
         fr = torch.outer(torch.arange(self.T_max, dtype=torch.float32), inv_freq)      # rotary table (weights-like)
         self.rope_cos, self.rope_sin = fr.cos().to(dev).contiguous(), fr.sin().to(dev).contiguous()
         self.state = E(8, dtype=torch.int32)
+        self.state_pf = E(8, dtype=torch.int32)             # prompt pass: per-layer chunk cursor (see _prompt_mfma)
+        self.ones_h = torch.ones(H, dtype=torch.float16, device=dev)
+        self.prompt_path = prompt_path
         self.out_ids = E(self.cap, dtype=torch.int32)
         self.feat = E(self.cap, H)
         self.chain = E(1, dtype=torch.int32)
@@ -234,10 +239,13 @@ class LlamaDecodeEngine:
         with torch.cuda.stream(st):
             self.state.copy_(torch.tensor([0, 0, 0, int(last_prompt_id), max_new, int(eos_token_id), 0, 0],
                                           dtype=torch.int32), non_blocking=False)
-            for r0 in range(0, T0, CHUNK):
-                m = min(CHUNK, T0 - r0)
-                self.h[:m].copy_(inputs_embeds[r0:r0 + m])
-                self._plan(m, "last" if r0 + m == T0 else "chunk").run(st.cuda_stream)
+            if T0 > CHUNK and self.prompt_path == "mfma":
+                self._prompt_mfma(inputs_embeds)
+            else:
+                for r0 in range(0, T0, CHUNK):
+                    m = min(CHUNK, T0 - r0)
+                    self.h[:m].copy_(inputs_embeds[r0:r0 + m])
+                    self._plan(m, "last" if r0 + m == T0 else "chunk").run(st.cuda_stream)
             tok = self._plan(1, "token")
             done = False
             while not done and steps < max_new - 1:
@@ -260,6 +268,34 @@ class LlamaDecodeEngine:
         self.last_run_info = {"graph": graph, "prompt_tokens": T0, "new_tokens": n, "token_steps_launched": steps,
                               "ops_per_token": tok.n}
         return {"ids": ids, "hidden": hidden}
+
+    def _prompt_mfma(self, inputs_embeds: Tensor) -> None:
+        """Whole prompt in one pass per layer: the projections are [T0,K] x [N,K]^T MFMA GEMMs (weights streamed once
+        per layer instead of once per 16-row chunk); only the attention walks the rows in chunks of 16 (causal inside
+        a chunk, cache rows before it).  Ends like the chunked path: final norm of the last row, lm_head, first pick."""
+        c = self.cfg
+        T0 = int(inputs_embeds.shape[0])
+        Hq, Hkv, eps = c.num_attention_heads, c.kv_heads, c.rms_norm_eps
+        scale = 1.0 / math.sqrt(c.head_dim)
+        pf = self.state_pf
+        h = inputs_embeds.contiguous().clone()
+        att = torch.empty((T0, Hq * c.head_dim), dtype=torch.float16, device=self.dev)
+        for l in range(c.num_hidden_layers):
+            xn = ops.llm_rmsnorm(h, self.ones_h, eps)                        # gains are folded into wqkv / wgu
+            qkv = ops.gemm(xn, self.wqkv[l])
+            pf.zero_()                                                       # chunk cursor of this layer's cache
+            for r0 in range(0, T0, CHUNK):
+                m = min(CHUNK, T0 - r0)
+                ops.llm_attention(qkv[r0:r0 + m], self.kc[l], self.vc[l], self.rope_cos, self.rope_sin, pf, Hq, Hkv,
+                                  scale, out=att[r0:r0 + m])
+                ops.llm_advance(pf, m)
+            h = ops.gemm(att, self.wo[l], residual=h)
+            xn = ops.llm_rmsnorm(h, self.ones_h, eps)
+            act = ops.llm_swiglu(ops.gemm(xn, self.wgu[l]))
+            h = ops.gemm(act, self.wdown[l], residual=h)
+        ops.llm_rmsnorm(h[T0 - 1:T0], self.norm_g, eps, out=self.hn)
+        ops.llm_gemv(self.hn, self.lm_head, out=self.logits.view(1, -1))
+        ops.llm_select(self.logits, self.chain if self.n_chain else None, T0, self.state, self.out_ids)
 
     def embed_tokens(self, input_ids: Tensor) -> Tensor:
         """Row gather from the embedding table (data movement only)."""

@@ -442,3 +442,13 @@ def blend(a: Tensor, b: Tensor, scale: float) -> Tensor:
     out = torch.empty_like(a)
     check(_lib.load().ds_blend_f16(_p(a), _p(b), _p(out), a.numel(), scale, _stream()), "ds_blend_f16")
     return out
+
+
+def llm_swiglu(gate_up: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    """[M, 2I] (gate | up) -> silu(gate) * up  [M, I]."""
+    _chk(gate_up, out)
+    M, I2 = gate_up.shape
+    if out is None:
+        out = torch.empty((M, I2 // 2), dtype=torch.float16, device=gate_up.device)
+    check(_lib.load().ds_llm_swiglu_f16(_p(gate_up), _p(out), M, I2 // 2, _stream()), "ds_llm_swiglu_f16")
+    return out

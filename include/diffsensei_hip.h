@@ -202,6 +202,9 @@ int ds_llm_advance(int32_t* state, int rows, void* stream); /* state[0] += rows 
 /* out = a*scale + b*(1-scale), n elements (multiple of 8): `img_gen_feat * mllm_scale + image_embeds * (1 - mllm_scale)`
  * (reference scripts/demo/gradio.py:108-109) */
 int ds_blend_f16(const void* a, const void* b, void* out, int64_t n, float scale, void* stream);
+/* act[M,I] = silu(gate_up[:, :I]) * gate_up[:, I:] - the prompt pass, where gate|up comes out of ds_gemm_f16 as [M,2I]
+ * (LlamaMLP.forward, modeling_llama_xformer.py:166-167) */
+int ds_llm_swiglu_f16(const void* gate_up, void* act, int M, int I, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Plans: a static launch list (one UNet forward, or forward + CFG + scheduler step) built once by the host

@@ -154,6 +154,13 @@ def test_llm_select_processor_semantics(hip_lib):
     assert st.tolist() == [10, 4, 1, 5, 8, 2, 0, 0] and torch.equal(before, out_ids), "finished -> no-op"
 
 
+def test_llm_swiglu(hip_lib):
+    from diffsensei_amd import ops
+    g = torch.Generator().manual_seed(5)
+    gu = _h((7, 2 * 704), g, 2.0)
+    _close(ops.llm_swiglu(gu.to(DEV)), F.silu(gu[:, :704].float()) * gu[:, 704:].float(), tol=2e-3, what="swiglu")
+
+
 def test_blend(hip_lib):
     from diffsensei_amd import ops
     g = torch.Generator().manual_seed(1)
@@ -171,7 +178,8 @@ def tiny(hip_lib):
                       num_attention_heads=G.TINY["num_attention_heads"], rms_norm_eps=G.TINY["rms_norm_eps"])
     sd = G.tiny_weights()
     sd_in, sd_out = G.tiny_resampler(G.RES_IN, 11), G.tiny_resampler(G.RES_OUT, 12)
-    mk = lambda graph: LlamaDecodeEngine(cfg, sd, DEV, max_positions=96, max_new_tokens=40, use_graph=graph, poll_every=4)
+    mk = lambda graph, path="mfma": LlamaDecodeEngine(cfg, sd, DEV, max_positions=96, max_new_tokens=40, use_graph=graph,
+                                                      poll_every=4, prompt_path=path)
     res_in, res_out = QwenResampler(sd_in, G.RES_IN["num_heads"], DEV), QwenResampler(sd_out, G.RES_OUT["num_heads"], DEV)
     return {"G": G, "sd": sd, "sd_in": sd_in, "sd_out": sd_out, "mk": mk, "res_in": res_in, "res_out": res_out,
             "LVLM": ContinuousLVLM, "gold": dict(np.load(GOLD))}
@@ -202,9 +210,10 @@ def _check_ids(got, want, margins, what):
     return len(want)
 
 
+@pytest.mark.parametrize("path", ["mfma", "chunks"])      # prompt pass: GEMM projections / 16-row passes of the token kernels
 @pytest.mark.parametrize("graph", [True, False])
 @pytest.mark.parametrize("tag", ["a", "b"])
-def test_generate_matches_golden_and_oracle(tiny, graph, tag):
+def test_generate_matches_golden_and_oracle(tiny, graph, tag, path):
     from oracle import llama_ref as R
     G, gold = tiny["G"], tiny["gold"]
     input_ids, mask, image_embeds = G.tiny_prompt()
@@ -213,7 +222,7 @@ def test_generate_matches_golden_and_oracle(tiny, graph, tag):
                           (G.RES_IN["num_heads"], G.RES_OUT["num_heads"]), input_ids, image_embeds, mask, G.IMG_IDS, eos,
                           G.MAX_NEW, G.N_IMG)
     assert ref["output_ids"].tolist() == gold[f"{tag}_ids"].tolist()                      # oracle == transformers
-    agent = tiny["LVLM"](tiny["mk"](graph), tiny["res_in"], tiny["res_out"])
+    agent = tiny["LVLM"](tiny["mk"](graph, path), tiny["res_in"], tiny["res_out"])
     for rep in range(2):                                                                  # 2nd call reuses the plan/graph
         out = agent.generate(input_ids=input_ids[None], image_embeds=image_embeds.to(DEV), ids_cmp_mask=mask[None],
                              num_img_gen_tokens=G.N_IMG, max_new_tokens=G.MAX_NEW, img_ids_list=G.IMG_IDS,
