@@ -134,6 +134,27 @@ def synthetic_request(device, size, seed, output_type="pt"):
         generator=torch.Generator().manual_seed(seed), output_type=output_type)
 
 
+def build_mllm_agent(device, seed=7):
+    """The agent of scripts/demo/gradio.py:255-270 at LLaMA-2-13B dimensions with seeded random weights, and a synthetic
+    tokenised instruction: [bos, 40 text ids, <img>, 64 placeholders, </img>, 3 text ids, <img>] - the trailing <img>
+    starts the forced 64-token image block (random weights never emit it on their own), 66 new tokens in total."""
+    from diffsensei_amd.mllm import (ContinuousLVLM, LlamaConfig, LlamaDecodeEngine, QwenResampler,
+                                     random_llama_state_dict, random_qwen_resampler_state_dict)
+    cfg = LlamaConfig()
+    llm = LlamaDecodeEngine(cfg, random_llama_state_dict(cfg, device, seed), device, max_positions=256, max_new_tokens=128)
+    res_in = QwenResampler(random_qwen_resampler_state_dict(8, cfg.hidden_size, 2048, device, seed + 1), 32, device)
+    res_out = QwenResampler(random_qwen_resampler_state_dict(8, 2048, cfg.hidden_size, device, seed + 2), 32, device)
+    boi = 32100
+    chain = [boi] + [boi + 1 + i for i in range(64)] + [boi + 65]
+    g = torch.Generator().manual_seed(seed)
+    text = lambda n: torch.randint(3, 32000, (n,), generator=g).tolist()
+    ids = [1] + text(40) + chain + text(3) + [boi]
+    mask = torch.zeros(len(ids), dtype=torch.bool)
+    mask[42:42 + 64] = True
+    return ContinuousLVLM(llm, res_in, res_out), {"input_ids": torch.tensor(ids), "ids_cmp_mask": mask, "chain": chain,
+                                                  "max_new": 66}
+
+
 def profile_forward_ops(pipe, reps=3):
     """HIP-event time of every op of the UNet forward plan, on the stream the kernels are launched on; grouped by
     the gfx950 kernel they dispatch to.  Returns (per-kernel table, forward_ms)."""
@@ -179,6 +200,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-vae", action="store_true", help="stop at the latents (the round-1 timed region)")
+    ap.add_argument("--mllm", action="store_true",
+                    help="BASELINE config 3: run the MLLM pre-pass (LLaMA-2-13B dims, 66 new tokens) inside the timed "
+                         "region and feed its ip_image_embeds to the sampler (scripts/demo/gradio.py:85-129); "
+                         "not part of the default metric line (round 1: every stage GPU-tested and the pre-pass "
+                         "measured on its own by tools/mllm_bench.py; the combined full-size run is still to be taken)")
     args = ap.parse_args()
 
     from diffsensei_amd.distributed import init_from_env
@@ -196,8 +222,18 @@ def main():
     ns = args.num_samples
     req = synthetic_request(device, args.size, seed=1234 + rank, output_type="latent" if args.no_vae else "pt")
 
+    agent = mllm_in = None
+    if args.mllm:
+        agent, mllm_in = build_mllm_agent(device)
+
     def one_step():
-        out = pipe(num_samples=ns, **req)
+        r = req
+        if agent is not None:                      # gradio.py:85-129: references -> MLLM -> blended character tokens
+            from diffsensei_amd.mllm import mllm_prepass
+            emb = mllm_prepass(pipe, agent, mllm_in["input_ids"], mllm_in["ids_cmp_mask"], r["ip_images"], 0.4,
+                               img_ids_list=mllm_in["chain"], eos_token_id=2, max_new_tokens=mllm_in["max_new"])
+            r = dict(r, ip_images=[], ip_image_embeds=emb, ip_bbox=list(r["ip_bbox"]) + [[0.0] * 4] * (4 - len(r["ip_bbox"])))
+        out = pipe(num_samples=ns, **r)
         return out.images
 
     for _ in range(args.warmup):
@@ -273,6 +309,8 @@ def main():
                                        "character encoding, 50 x (UNet + CFG + scheduler step)" +
                                        ("; VAE decode excluded (output: latents)" if args.no_vae else
                                         ", SDXL VAE decode + denormalize (bf16 HIP engine; output: [0,1] fp32 images on the device)"),
+                       "mllm_prepass": ("LLaMA-2-13B dims, 111-token prompt + 66 new tokens (64-token image block), both "
+                                        "QwenResamplers, blend; timed") if args.mllm else None,
                        "num_samples": ns, "unet_batch": 2 * ns, "hipgraph": pipe.last_run_info.get("graph"),
                        "kernel_launches_per_denoise_step": pipe.last_run_info.get("ops_per_step"),
                        "weights": "seeded random at SDXL UNet / CLIP-L + bigG text / CLIP-H / ViT-MAE / Resampler / VAE decoder shapes", **setup},

@@ -267,15 +267,17 @@ int ds_launch_groupnorm(const GroupNormParams& p, hipStream_t stream) {
 int ds_launch_layernorm(const half_t* x, half_t* y, const half_t* gamma, const half_t* beta, int rows, int C,
                         float eps, hipStream_t stream) {
     DS_REQUIRE(rows > 0 && C > 0 && C % 8 == 0, "layernorm: bad shape rows=%d C=%d", rows, C);
-    DS_REQUIRE(C <= 8 * 64 * 8, "layernorm: C (%d) > 4096 unsupported", C);
+    DS_REQUIRE(C <= 16 * 64 * 8, "layernorm: C (%d) > 8192 unsupported", C);
     dim3 grid((rows + 3) / 4);
     const int ncc = C >> 3;
     if (ncc <= 64 * 2)
         hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, stream, x, y, gamma, beta, rows, C, eps);
     else if (ncc <= 64 * 4)
         hipLaunchKernelGGL(layernorm_kernel<4>, grid, dim3(256), 0, stream, x, y, gamma, beta, rows, C, eps);
-    else
+    else if (ncc <= 64 * 8)
         hipLaunchKernelGGL(layernorm_kernel<8>, grid, dim3(256), 0, stream, x, y, gamma, beta, rows, C, eps);
+    else  // the MLLM's input QwenResampler normalises LLaMA-width rows (5120)
+        hipLaunchKernelGGL(layernorm_kernel<16>, grid, dim3(256), 0, stream, x, y, gamma, beta, rows, C, eps);
     DS_LAUNCH_CHECK();
     return 0;
 }

@@ -302,6 +302,30 @@ class LlamaDecodeEngine:
         return self.embed.index_select(0, input_ids.to(self.dev).view(-1).long())
 
 
+def sincos_pos_embed_2d(embed_dim: int, grid_size: int) -> Tensor:
+    """The fixed 2-D sin/cos table `QwenResampler.pos_embed` is initialised with (qwen_resampler.py:37-86): first half
+    of the channels encodes the column index, second half the row index, each as [sin | cos] over 10000^(-2i/d)."""
+    def one(dim, pos):
+        omega = 1.0 / 10000 ** (torch.arange(dim // 2, dtype=torch.float32) / (dim / 2.0))
+        out = pos.reshape(-1)[:, None] * omega[None]
+        return torch.cat([out.sin(), out.cos()], 1)
+    r = torch.arange(grid_size, dtype=torch.float32)
+    gh, gw = torch.meshgrid(r, r, indexing="ij")
+    return torch.cat([one(embed_dim // 2, gw), one(embed_dim // 2, gh)], 1)
+
+
+def random_qwen_resampler_state_dict(grid_size: int, embed_dim: int, kv_dim: int, device, seed: int = 0) -> Dict[str, Tensor]:
+    """Seeded weights with the reference module's key names (benchmarks / tests; no checkpoints exist offline)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    E, Q = embed_dim, grid_size ** 2
+    R = lambda *s, std=0.02: torch.randn(*s, generator=g, device=device) * std
+    return {"pos_embed": sincos_pos_embed_2d(E, grid_size).to(device), "query": R(Q, E),
+            "kv_proj.weight": R(E, kv_dim, std=1.0 / math.sqrt(kv_dim)),
+            "attn.in_proj_weight": R(3 * E, E, std=1.0 / math.sqrt(E)), "attn.in_proj_bias": R(3 * E),
+            "attn.out_proj.weight": R(E, E, std=1.0 / math.sqrt(E)), "attn.out_proj.bias": R(E),
+            "ln_q.weight": 1.0 + R(E), "ln_q.bias": R(E), "ln_kv.weight": 1.0 + R(E), "ln_kv.bias": R(E)}
+
+
 class QwenResampler:
     """Single cross-attention resampler (reference src/models/qwen_resampler.py:87-145) on the HIP ops.
     Weight-only terms are folded at construction: q = (ln_q(query)+pos) Wq^T + bq is a constant, and the position

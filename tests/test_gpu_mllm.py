@@ -198,6 +198,17 @@ def test_qwen_resampler_vs_reference_vectors(tiny):
     _close(y2[0], torch.from_numpy(gold["input_resampler_out"]), tol=6e-3, what="batched row 0")
 
 
+@pytest.mark.parametrize("E,KV", [(5120, 2048), (2048, 5120)])
+def test_qwen_resampler_at_the_agent_dimensions(hip_lib, E, KV):
+    """configs/model/diffsensei.yaml agent.{input,output}_resampler: 64 queries, 32 heads (head_dim 160 / 64)."""
+    from diffsensei_amd.mllm import QwenResampler, random_qwen_resampler_state_dict
+    from oracle import llama_ref as R
+    sd = random_qwen_resampler_state_dict(8, E, KV, DEV, seed=E)
+    x = _h((1, 64, KV), torch.Generator().manual_seed(KV))
+    ref = R.qwen_resampler({k: v.float().cpu() for k, v in sd.items()}, x.float(), 32)
+    _close(QwenResampler(sd, 32, DEV)(x.to(DEV)), ref, tol=1e-2, what=f"resampler {KV}->{E}")
+
+
 def _check_ids(got, want, margins, what):
     """identical, except that a choice whose fp32 top-2 margin is inside the fp16 logit noise may legitimately flip
     (everything after such a flip is a different continuation)."""

@@ -234,7 +234,7 @@ def test_groupnorm(hip_lib, B, HW, C1, C2, silu, eps):
     _close(y, ref, tol=3e-3, what="groupnorm")
 
 
-@pytest.mark.parametrize("rows,C", [(1000, 640), (2048, 1280), (37, 128), (64, 2048), (5, 768)])
+@pytest.mark.parametrize("rows,C", [(1000, 640), (2048, 1280), (37, 128), (64, 2048), (5, 768), (64, 5120), (9, 8192)])
 def test_layernorm(hip_lib, rows, C):
     ops = _ops(hip_lib)
     g = torch.Generator().manual_seed(rows + C)
