@@ -577,7 +577,8 @@ int launch_gemv_stream(const LlmGemvParams& p, hipStream_t stream) {
     if (!cus) {
         int dev = 0;
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -2;
+        DS_HIP(hipGetDevice(&dev));
+        DS_HIP(hipGetDeviceProperties(&prop, dev));
         cus = prop.multiProcessorCount;
     }
     const size_t lds = (size_t)MC * p.K * 2 + (size_t)MC * 5 * sizeof(float);
