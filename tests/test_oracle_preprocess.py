@@ -1,0 +1,47 @@
+"""Pins oracle/image_preprocess_ref.py: the numpy restatement of Pillow's 8-bit separable resize must be BIT-EXACT against
+Pillow itself (installed third-party code, the arithmetic behind reference src/pipelines/pipeline_diffsensei.py:125-126),
+and the two processor pipelines must match transformers' CLIPImageProcessor / ViTImageProcessor (fp32, <= 1e-6: the
+library fuses rescale and normalisation in a different order).  CPU only."""
+import numpy as np
+import pytest
+from PIL import Image
+
+from oracle import image_preprocess_ref as P
+
+SHAPES = [((300, 200), (336, 224)), ((224, 224), (224, 224)), ((512, 640), (224, 280)), ((100, 100), (224, 224)),
+          ((386, 224), (224, 224)), ((37, 911), (224, 551)), ((640, 640), (224, 224)), ((224, 312), (224, 224)),
+          ((5, 7), (224, 224)), ((225, 223), (224, 224))]
+
+
+@pytest.mark.parametrize("src,dst", SHAPES)
+@pytest.mark.parametrize("name,flag", [("bicubic", Image.BICUBIC), ("bilinear", Image.BILINEAR)])
+def test_resize_is_bit_exact_against_pillow(src, dst, name, flag):
+    rng = np.random.RandomState(src[0] * 1000 + src[1])
+    for kind in ("noise", "flat", "edges"):
+        if kind == "noise":
+            img = rng.randint(0, 256, src + (3,), dtype=np.uint8)
+        elif kind == "flat":
+            img = np.full(src + (3,), 255, np.uint8)                     # overshoot of the negative bicubic lobes clamps
+        else:
+            img = (rng.randint(0, 2, src + (3,)) * 255).astype(np.uint8)
+        ref = np.asarray(Image.fromarray(img).resize((dst[1], dst[0]), flag))
+        assert np.array_equal(P.pil_resize_u8(img, dst[0], dst[1], name), ref), (kind, src, dst, name)
+
+
+def test_shortest_edge_rule():
+    assert P.shortest_edge_size(300, 200) == (336, 224)
+    assert P.shortest_edge_size(224, 386) == (224, 386)
+    assert P.shortest_edge_size(97, 333) == (224, int(224 * 333 / 97))
+    assert P.shortest_edge_size(500, 500) == (224, 224)
+
+
+@pytest.mark.parametrize("hw", [(300, 200), (224, 386), (224, 312), (640, 512), (224, 224), (97, 333)])
+def test_processors_match_transformers(hw):
+    from transformers import CLIPImageProcessor, ViTImageProcessor
+    img = np.random.RandomState(hw[0] + hw[1]).randint(0, 256, hw + (3,), dtype=np.uint8)
+    pil = Image.fromarray(img)
+    ref_c = CLIPImageProcessor()(images=[pil], return_tensors="np").pixel_values[0]
+    ref_v = ViTImageProcessor()(images=[pil], return_tensors="np").pixel_values[0]
+    got_c, got_v = P.clip_preprocess(img), P.vit_preprocess(img)
+    assert got_c.shape == ref_c.shape == (3, 224, 224) and got_c.dtype == np.float32
+    assert np.abs(got_c - ref_c).max() <= 1e-6 and np.abs(got_v - ref_v).max() <= 1e-6
