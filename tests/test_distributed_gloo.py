@@ -123,3 +123,44 @@ def test_sharded_bucketed_serving_world2():
     assert calls0 and calls1                                                 # both ranks got work
     for i in range(10):
         assert out0[i].startswith(f"p{i}@")
+
+
+def _mllm_worker(rank, world, port, q):
+    """The MLLM engine's packed weights (folded q|k|v / gate|up, o, down, embeddings, lm_head, final gain) are what the
+    N > 1 start-up broadcast must cover: rank 1 starts from different seeds and must end bit-identical to rank 0."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from diffsensei_amd.distributed import broadcast_tensors, init_from_env
+    from diffsensei_amd.mllm import LlamaConfig, LlamaDecodeEngine, llama_param_shapes
+    init_from_env("gloo")
+    cfg = LlamaConfig(vocab_size=96, hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=1)
+    g = torch.Generator().manual_seed(100 + rank)
+    sd = {k: torch.randn(s, generator=g) * 0.05 for k, s in llama_param_shapes(cfg).items()}
+    eng = LlamaDecodeEngine(cfg, sd, "cpu", max_positions=16, max_new_tokens=4)
+    ts = eng.tensors()
+    n_param = sum(t.numel() for t in ts)
+    before = torch.cat([t.flatten().float() for t in ts]).sum().item()
+    broadcast_tensors(ts, src=0, bucket_bytes=1 << 16)
+    after = torch.cat([t.flatten().float() for t in eng.tensors()])
+    dist.barrier()
+    q.put((rank, n_param, before, after.sum().item(), after[::97].tolist()))
+    dist.destroy_process_group()
+
+
+def test_mllm_weight_broadcast_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mllm_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, n0, before0, after0, sample0), (_, n1, before1, after1, sample1) = res
+    # every matrix of the model is in the list: 2 layers x (3+1+2+1) H-by-* blocks + embeddings + lm_head + final gain
+    assert n0 == n1 == 2 * (3 * 128 * 128 + 128 * 128 + 2 * 256 * 128 + 128 * 256) + 2 * 96 * 128 + 128
+    assert before0 != before1 and after0 == before0 and after1 == after0 and sample0 == sample1
