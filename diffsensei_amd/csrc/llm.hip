@@ -3,9 +3,11 @@
 // embedding, attention with past_key_value, MLP, decoder layer), src/models/mllm/generation.py:19-30 (logits processor).
 //
 // Batch-1 greedy decoding streams every weight once per token: the path is HBM-bound (13 B parameters = 26 GB per
-// token), so the kernels below are wide vector loads + fp32 dot products on the VALU, not MFMA tiles.  One code path
-// serves the prompt (chunks of up to 16 rows, causal inside the chunk) and the token loop (1 row); the token loop is a
-// static launch list whose only varying inputs live in a small device-side state block, so it replays as a hipGraph:
+// token), so the kernels below are wide vector loads + fp32 dot products on the VALU, not MFMA tiles.  The same kernels
+// take up to 16 rows (causal inside the chunk), which is how the attention of the prompt runs; the prompt's projections
+// go through the MFMA GEMMs (mllm.py: _prompt_mfma; 16-row passes of these kernels remain as an A/B path).  The token
+// loop is a static launch list whose only varying inputs live in a small device-side state block, so it replays as a
+// hipGraph:
 //     state[0] = tokens in the KV cache   state[1] = tokens generated   state[2] = finished   state[3] = current token
 //     state[4] = max_new_tokens of this call   state[5] = eos token id                      (int32[8], two spare)
 //

@@ -10,7 +10,9 @@ Mirrors, for batch 1 and greedy decoding (the only mode the reference uses: `do_
 Execution model: every weight is read once per generated token, so decoding is HBM-bound; one token step is a static
 list of `DS_OP_LLM_*` launches (csrc/llm.hip) whose step-varying scalars live in a device-side state block, captured
 once into a hipGraph and replayed per token.  The host looks at the device only every `poll_every` tokens (one 32-byte
-copy) to see whether EOS was produced.  The prompt runs through the same kernels in chunks of up to 16 rows.
+copy) to see whether EOS was produced.  The prompt is one pass per layer: projections through the MFMA GEMMs
+(`ops.gemm`), attention through the decode kernel in 16-row chunks (`prompt_path="mfma"`, 22 ms for 96 tokens at 13B
+dims); `prompt_path="chunks"` runs it through the token kernels 16 rows at a time instead (166 ms; kept for A/B).
 
 Host-side packing (once): q|k|v and gate|up projections stacked, the two RMSNorm gains of each layer folded into them
 (W' = W diag(g)); QwenResampler: the constant query projection and the position-embedding contribution to the keys are
