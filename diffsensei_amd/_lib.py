@@ -71,6 +71,9 @@ SIGNATURES = {
     "ds_llm_advance": (i32, [vp, i32, vp]),
     "ds_blend_f16": (i32, [vp, vp, vp, i64, f32, vp]),
     "ds_llm_swiglu_f16": (i32, [vp, vp, i32, i32, vp]),
+    "ds_resize_h_u8": (i32, [vp, i32, i32, vp, vp, vp, i32, i32, vp, vp]),
+    "ds_resize_v_norm_u8": (i32, [vp, i32, i32, vp, vp, vp, i32, i32, i32, i32, i32, f32, C.POINTER(f32), C.POINTER(f32),
+                                  vp, vp, vp]),
     "ds_op_run": (i32, [C.POINTER(DsOp), vp]),
     "ds_op_describe": (i32, [C.POINTER(DsOp), C.c_char_p, i32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "ds_plan_create": (i32, [C.POINTER(DsOp), i32, C.POINTER(vp)]),

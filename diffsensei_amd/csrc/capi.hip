@@ -292,6 +292,18 @@ int ds_llm_swiglu_f16(const void* gate_up, void* act, int M, int I, void* stream
     return ds_launch_llm_swiglu(H(gate_up), HM(act), M, I, S(stream));
 }
 
+int ds_resize_h_u8(const uint8_t* src, int H_, int W_, const int32_t* first, const int32_t* count, const int32_t* taps,
+                   int ksize, int out_w, uint8_t* dst, void* stream) {
+    return ds_launch_resize_h(src, H_, W_, first, count, taps, ksize, out_w, dst, S(stream));
+}
+
+int ds_resize_v_norm_u8(const uint8_t* tmp, int Ht, int Wt, const int32_t* first, const int32_t* count,
+                        const int32_t* taps, int ksize, int top, int left, int out_h, int out_w, float scale,
+                        const float* mean3, const float* std3, float* out_f32, uint8_t* out_u8, void* stream) {
+    return ds_launch_resize_v_norm(tmp, Ht, Wt, first, count, taps, ksize, top, left, out_h, out_w, scale, mean3, std3,
+                                   out_f32, out_u8, S(stream));
+}
+
 int ds_blend_f16(const void* a, const void* b, void* out, int64_t n, float scale, void* stream) {
     return ds_launch_blend(H(a), H(b), HM(out), (long)n, scale, S(stream));
 }

@@ -172,3 +172,10 @@ int ds_launch_llm_select(const half_t* logits, int V, const int* chain, int n_ch
 int ds_launch_llm_advance(int* state, int rows, hipStream_t stream);
 int ds_launch_blend(const half_t* a, const half_t* b, half_t* out, long n, float s, hipStream_t stream);
 int ds_launch_llm_swiglu(const half_t* gu, half_t* act, int M, int I, hipStream_t stream);
+
+// ---- character-reference pre-processing (preprocess.hip): Pillow's 8-bit separable resize + crop + normalise ----
+int ds_launch_resize_h(const uint8_t* src, int H, int W, const int* first, const int* count, const int* taps, int ksize,
+                       int out_w, uint8_t* dst, hipStream_t stream);
+int ds_launch_resize_v_norm(const uint8_t* tmp, int Ht, int Wt, const int* first, const int* count, const int* taps,
+                            int ksize, int top, int left, int out_h, int out_w, float scale, const float* mean3,
+                            const float* std3, float* out_f32, uint8_t* out_u8, hipStream_t stream);

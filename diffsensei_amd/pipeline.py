@@ -57,6 +57,8 @@ class DiffSenseiPipeline:
         self.magi_image_encoder = None
         self.image_proj_model = None
         self._clip_proc = None
+        self.device_preprocess = False   # True: character references are resized / normalised by csrc/preprocess.hip
+        self._device_pre = None
         self._magi_proc = None
         self._guidance_scale = 1.0
         self._stream = None
@@ -142,9 +144,15 @@ class DiffSenseiPipeline:
         num_ips = len(ip_images)
         while len(ip_images) < max_num_ips:
             ip_images.append(_black_image())
-        clip_proc, magi_proc = self._processors()
-        clip_px = clip_proc(images=ip_images, return_tensors="pt").pixel_values
-        magi_px = magi_proc(images=ip_images, return_tensors="pt").pixel_values
+        if self.device_preprocess:      # opt-in: Pillow's resize + crop + normalise on the device (preprocess.py), bytes only go up
+            if self._device_pre is None:
+                from .preprocess import DevicePreprocessor
+                self._device_pre = DevicePreprocessor(self._execution_device)
+            clip_px, magi_px = self._device_pre.clip(ip_images), self._device_pre.vit(ip_images)
+        else:
+            clip_proc, magi_proc = self._processors()
+            clip_px = clip_proc(images=ip_images, return_tensors="pt").pixel_values
+            magi_px = magi_proc(images=ip_images, return_tensors="pt").pixel_values
         clip_embeds = self.image_encoder.penultimate_hidden(clip_px).unsqueeze(0)
         magi_embeds = self.magi_image_encoder.cls_embedding(magi_px).unsqueeze(0)
         if zero_padded:

@@ -207,6 +207,24 @@ int ds_blend_f16(const void* a, const void* b, void* out, int64_t n, float scale
 int ds_llm_swiglu_f16(const void* gate_up, void* act, int M, int I, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Character-reference pre-processing on the device.  Replaces the Pillow resize that
+ * `CLIPImageProcessor()` / `ViTImageProcessor()` run on the host (reference src/pipelines/pipeline_diffsensei.py:125-126)
+ * bit for bit: 8-bit separable resample with 22-bit fixed-point taps (libImaging Resample.c), horizontal pass, 8-bit
+ * intermediate, vertical pass; then centre crop, * rescale, (x - mean) / std, CHW fp32.
+ * Tables (device int32, built once per (in, out, filter) by the host with Pillow's double arithmetic):
+ *   first[o] = first source index of output o, count[o] = taps used, taps[o*ksize + k] = round(w * 2^22).
+ * Images: RGB uint8, HWC, device.  mean3 / std3: HOST arrays of 3 floats.
+ * ---------------------------------------------------------------------------------------------- */
+/* dst[H,out_w,3] = horizontal pass of src[H,W,3] */
+int ds_resize_h_u8(const uint8_t* src, int H, int W, const int32_t* first, const int32_t* count, const int32_t* taps,
+                   int ksize, int out_w, uint8_t* dst, void* stream);
+/* vertical pass of tmp[Ht,Wt,3] restricted to the crop window rows [top, top+out_h) x columns [left, left+out_w),
+ * then out_f32[3,out_h,out_w] = (u8 * scale - mean) / std; out_u8 (may be NULL) receives the cropped bytes [out_h,out_w,3] */
+int ds_resize_v_norm_u8(const uint8_t* tmp, int Ht, int Wt, const int32_t* first, const int32_t* count,
+                        const int32_t* taps, int ksize, int top, int left, int out_h, int out_w, float scale,
+                        const float* mean3, const float* std3, float* out_f32, uint8_t* out_u8, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Plans: a static launch list (one UNet forward, or forward + CFG + scheduler step) built once by the host
  * and replayed with zero host arithmetic — optionally as a captured hipGraph.
  * ---------------------------------------------------------------------------------------------- */

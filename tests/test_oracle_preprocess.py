@@ -45,3 +45,16 @@ def test_processors_match_transformers(hw):
     got_c, got_v = P.clip_preprocess(img), P.vit_preprocess(img)
     assert got_c.shape == ref_c.shape == (3, 224, 224) and got_c.dtype == np.float32
     assert np.abs(got_c - ref_c).max() <= 1e-6 and np.abs(got_v - ref_v).max() <= 1e-6
+
+
+@pytest.mark.parametrize("filt", ["bicubic", "bilinear"])
+def test_product_tables_equal_the_oracle_tables(filt):
+    """diffsensei_amd/preprocess.py builds the coefficient tables the device kernels consume; they must be the tables the
+    Pillow-pinned oracle derives (the kernels then only do the integer multiply-accumulate)."""
+    from diffsensei_amd.preprocess import resample_tables, shortest_edge_size
+    for n_in, n_out in [(200, 224), (300, 336), (224, 224), (640, 224), (911, 551), (5, 224), (1000, 224), (333, 517)]:
+        first, count, taps = resample_tables(n_in, n_out, filt)
+        o_first, o_count, o_taps = P.precompute_coeffs(n_in, n_out, filt)
+        assert np.array_equal(first, o_first) and np.array_equal(count, o_count) and np.array_equal(taps, o_taps)
+        assert taps.dtype == np.int32 and int(np.abs(taps.astype(np.int64)).sum(1).max()) * 255 < 2 ** 31   # int32 accumulate is safe
+    assert shortest_edge_size(97, 333, 224) == P.shortest_edge_size(97, 333, 224)
