@@ -1,6 +1,6 @@
 """Build the gfx950 kernel library in-tree: diffsensei_amd/lib/libdiffsensei_hip.so.
 
-    python -m diffsensei_amd.build [--force]
+    python -m diffsensei_amd.build [--force] [--ablation]
 
 hipcc cross-compiles for gfx950 without a GPU, so this runs in the build container; the resulting .so travels
 with the tree to the GPU box.  One hipcc invocation per source (parallel), then one link.
@@ -40,10 +40,11 @@ def _digest() -> str:
     return h.hexdigest()
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, ablation: bool = False) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     stamp = os.path.join(LIBDIR, "build.stamp")
-    dig = _digest()
+    flags = FLAGS + (["-DDS_ABLATION"] if ablation else [])
+    dig = _digest() + ("+ablation" if ablation else "")
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
         return LIB
     hipcc = _hipcc()
@@ -51,7 +52,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     def compile_one(src):
         obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
-        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *flags, "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
@@ -73,4 +74,4 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, ablation="--ablation" in sys.argv)

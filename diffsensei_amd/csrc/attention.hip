@@ -18,7 +18,7 @@
 #include "ds_common.h"
 #include "ds_kernels.h"
 
-static int g_attn_variant = 0;  // 0 auto, 1 force 32 query rows per wave
+static int g_attn_variant = 0;  // 0 auto, 1 force 32 query rows per wave (QB = 1), 2 force 64 rows per wave (QB = 2)
 void ds_attn_set_variant(int v) { g_attn_variant = v; }
 static long g_ip_min_blocks = 1024;  // ip_attn: double the query tiles per block while the grid keeps this many blocks
 void ds_ip_attn_set_min_blocks(int v) { g_ip_min_blocks = v; }
@@ -533,7 +533,7 @@ int ds_launch_self_attn(const SelfAttnParams& p, hipStream_t stream) {
     // 64 query rows per wave when that still leaves >= 2 blocks per CU; 32 rows per wave otherwise
     const long blocks2 = (long)((p.Nq + 255) / 256) * p.B * p.heads;
     // (measured on MI355X: 64-row waves win from N = 4096 up, lose at N = 1024 — profiles/r01_attn_variants.txt)
-    if (blocks2 >= 512 && p.Nk >= 2048 && g_attn_variant != 1) {
+    if (g_attn_variant == 2 || (blocks2 >= 512 && p.Nk >= 2048 && g_attn_variant != 1)) {
         hipLaunchKernelGGL(self_attn_kernel<2>, dim3((p.Nq + 255) / 256, p.B * p.heads), dim3(256), 0, stream, p);
     } else {
         hipLaunchKernelGGL(self_attn_kernel<1>, dim3((p.Nq + 127) / 128, p.B * p.heads), dim3(256), 0, stream, p);

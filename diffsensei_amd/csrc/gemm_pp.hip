@@ -543,11 +543,16 @@ int ds_launch_gemm_pp(const GemmParams& p0, int batch, hipStream_t stream) {
     p.tiles_n = (p.N + 255) / 256;
     const size_t lds = 8 * HT + 8 * 4096;
     typedef void (*kern_t)(const GemmParams);
+    // production build: the plain kernel per element type.  The ablation builds (gemm_debug switches, tools/ablate_pp.py)
+    // are only instantiated with -DDS_ABLATION (python -m diffsensei_amd.build --ablation).
     static const struct { int dbg; kern_t k; } table[] = {
-        {0, gemm_pp_kernel<half_t, 0>},   {1, gemm_pp_kernel<half_t, 1>},   {2, gemm_pp_kernel<half_t, 2>},   {3, gemm_pp_kernel<half_t, 3>},
+        {0, gemm_pp_kernel<half_t, 0>},
+#ifdef DS_ABLATION
+        {1, gemm_pp_kernel<half_t, 1>},   {2, gemm_pp_kernel<half_t, 2>},   {3, gemm_pp_kernel<half_t, 3>},
         {4, gemm_pp_kernel<half_t, 4>},   {6, gemm_pp_kernel<half_t, 6>},   {8, gemm_pp_kernel<half_t, 8>},   {16, gemm_pp_kernel<half_t, 16>},
         {17, gemm_pp_kernel<half_t, 17>}, {18, gemm_pp_kernel<half_t, 18>}, {20, gemm_pp_kernel<half_t, 20>}, {22, gemm_pp_kernel<half_t, 22>},
         {24, gemm_pp_kernel<half_t, 24>}, {48, gemm_pp_kernel<half_t, 48>}, {49, gemm_pp_kernel<half_t, 49>}, {64, gemm_pp_kernel<half_t, 64>}, {128, gemm_pp_kernel<half_t, 128>},
+#endif
         {-1, gemm_pp_kernel<bf16_t, 0>}};  // -1: the bf16 build (VAE decoder), no ablation variants
     if (g_pp_blocks == 0) {
         for (const auto& e : table)

@@ -32,21 +32,23 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     backend = os.environ.get("DS_DIST_BACKEND", backend)
     if "DS_FORCE_DEVICE" in os.environ:
         local = int(os.environ["DS_FORCE_DEVICE"])
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local)   # every launch resolves "the current stream" on this rank's own GPU
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
-            torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
 
-def broadcast_tensors(tensors: Sequence[Tensor], src: int = 0, bucket_bytes: int = 512 << 20) -> Dict[str, float]:
-    """In-place broadcast of same-device tensors from `src`, coalesced into large flat buckets per dtype."""
+def broadcast_tensors(tensors: Sequence[Tensor], src: int = 0, bucket_bytes: int = 512 << 20,
+                      force: bool = False) -> Dict[str, float]:
+    """In-place broadcast of same-device tensors from `src`, coalesced into large flat buckets per dtype.
+    `force`: issue the collectives even in a 1-rank group (the RCCL bring-up test on a single GPU)."""
     stats = {"bytes": 0, "buckets": 0, "seconds": 0.0}
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return stats
     t0 = time.perf_counter()
     by_dtype: Dict[torch.dtype, List[Tensor]] = {}
@@ -82,6 +84,65 @@ def broadcast_tensors(tensors: Sequence[Tensor], src: int = 0, bucket_bytes: int
     if tensors and tensors[0].is_cuda:
         torch.cuda.synchronize()
     stats["seconds"] = time.perf_counter() - t0
+    return stats
+
+
+def tensors_checksum(tensors: Sequence[Tensor]) -> Tensor:
+    """int64 [2] = (wrapping sum of every tensor's bit pattern weighted by its position, total element count), computed
+    on the tensors' device.  Exact (integer arithmetic), so equal weights <=> equal checksums across ranks up to
+    collisions; used to verify the weight broadcast."""
+    dev = tensors[0].device if tensors else torch.device("cpu")
+    acc = torch.zeros(2, dtype=torch.int64, device=dev)
+    for k, t in enumerate(tensors):
+        flat = t.detach().reshape(-1)
+        if flat.element_size() == 2:
+            bits = flat.view(torch.int16).to(torch.int64)
+        elif flat.element_size() == 4:
+            bits = flat.view(torch.int32).to(torch.int64)
+        elif flat.element_size() == 1:
+            bits = flat.view(torch.uint8).to(torch.int64)
+        else:
+            bits = flat.view(torch.int64)
+        # position weights keep permutations of equal tensors from cancelling; the sum wraps mod 2^64 by construction
+        w = torch.arange(1, bits.numel() + 1, dtype=torch.int64, device=dev) % 8191 + 1
+        acc[0] += (bits * w).sum() * (2 * k + 1)
+        acc[1] += bits.numel()
+    return acc
+
+
+def verify_replicas(tensors: Sequence[Tensor]) -> Dict[str, int]:
+    """All ranks must hold bit-identical `tensors`: all-reduce MIN and MAX of the checksum and compare.  Raises on any
+    rank if they differ.  Returns {"checksum", "elements"}; a no-op outside a process group."""
+    cs = tensors_checksum(tensors)
+    if dist.is_initialized():
+        lo, hi = cs.clone(), cs.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if not torch.equal(lo, hi):
+            raise RuntimeError(f"weight replicas differ across ranks after the broadcast: checksum min {lo.tolist()} "
+                               f"max {hi.tolist()} (this rank {cs.tolist()})")
+    return {"checksum": int(cs[0].item()), "elements": int(cs[1].item())}
+
+
+def broadcast_pipeline(pipe, extra: Sequence = (), src: int = 0, bucket_bytes: int = 512 << 20,
+                       force: bool = False) -> Dict[str, float]:
+    """Start-up weight distribution of one serving process group: broadcast `pipe.tensors()` (+ the `tensors()` of every
+    object in `extra`, e.g. the MLLM agent) from rank `src`, drop the UNet's derived packed weights, and verify that all
+    ranks ended up bit-identical.  Returns the broadcast stats + {"verify_ms", "checksum", "elements"}."""
+    tensors = list(pipe.tensors())
+    for m in extra:
+        if m is not None:
+            tensors += list(m.tensors())
+    stats = broadcast_tensors(tensors, src=src, bucket_bytes=bucket_bytes, force=force)
+    pipe.unet.weights_changed()
+    t0 = time.perf_counter()
+    ver = verify_replicas(tensors) if (dist.is_initialized() and (dist.get_world_size() > 1 or force)) else \
+        {"checksum": None, "elements": sum(t.numel() for t in tensors)}
+    if tensors and tensors[0].is_cuda:
+        torch.cuda.synchronize()
+    stats.update(ver)
+    stats["verify_ms"] = (time.perf_counter() - t0) * 1e3
+    stats["tensors"] = len(tensors)
     return stats
 
 

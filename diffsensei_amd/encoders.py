@@ -55,6 +55,15 @@ class ViTEncoderEngine:
     def n_patches(self) -> int:
         return (self.image_size // self.patch) ** 2
 
+    def tensors(self) -> List[Tensor]:
+        """Frozen weights in kernel layout (the multi-GPU weight broadcast list)."""
+        out = [getattr(L, s) for L in self.layers for s in L.__slots__]
+        out += [t for t in (self.patch_w, self.patch_b, self.cls_row, self.pos_patches) if t is not None]
+        for pair in (self.pre_ln, self.post_ln):
+            if pair is not None:
+                out += list(pair)
+        return out
+
     def embed(self, pixel_values: Tensor) -> Tensor:
         """[B,3,S,S] -> tokens [B, 1+n_patches, hidden] (non-overlapping patch conv as one GEMM)."""
         B = pixel_values.shape[0]
@@ -238,6 +247,14 @@ class ClipTextEngine:
 
     def parameters(self):
         yield self.tok_emb
+
+    def tensors(self) -> List[Tensor]:
+        """Frozen weights in kernel layout (the multi-GPU weight broadcast list)."""
+        out = [getattr(L, s) for L in self.layers for s in L.__slots__]
+        out += [self.tok_emb, self.pos_emb, *self.final_ln]
+        if self.text_projection is not None:
+            out.append(self.text_projection)
+        return out
 
     def _block(self, h: Tensor, L: _ViTLayer, B: int, N: int) -> Tensor:
         D = self.hidden

@@ -178,6 +178,7 @@ class Plan:
 
     def __init__(self, ops: List[DsOp], keep: list):
         self.lib = _lib.load()
+        self.dev = next((t.device for t in keep if isinstance(t, torch.Tensor) and t.is_cuda), None)
         self.n = len(ops)
         arr = (DsOp * self.n)(*ops)
         h = C.c_void_p()
@@ -186,7 +187,12 @@ class Plan:
         self.keep = keep
         self.captured = False
 
+    def _bind(self):
+        if self.dev is not None and self.dev.index is not None and self.dev.index != torch.cuda.current_device():
+            torch.cuda.set_device(self.dev)   # launches resolve "the current stream" on the plan's own GPU
+
     def run(self, stream: Optional[int] = None):
+        self._bind()
         s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
         check(self.lib.ds_plan_run(self.handle, s), "ds_plan_run")
 
@@ -195,6 +201,7 @@ class Plan:
         self.captured = True
 
     def replay(self, stream: Optional[int] = None):
+        self._bind()
         s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
         check(self.lib.ds_plan_replay(self.handle, s), "ds_plan_replay")
 
@@ -213,18 +220,11 @@ class UNetEngine:
 
     def __init__(self, packed: PackedUNet, batch: int, height: int, width: int, aspect_ratio: Optional[float] = None):
         cfg = packed.cfg
-        if height % 4 or width % 4:
-            raise ValueError(f"latent size {height}x{width}: both sides must be multiples of 4 (image multiples of 32)")
         self.pk, self.cfg = packed, cfg
         self.B, self.H, self.W = batch, height, width
         self.dev = packed.device
         self.aspect_ratio = aspect_ratio if aspect_ratio is not None else height / width
-        nlev = len(cfg.block_out_channels)
-        self.hw = [(height >> l, width >> l) for l in range(nlev)]
-        for l in range(1, nlev):
-            if (self.hw[l][0] * self.hw[l][1]) % 8:
-                raise ValueError(f"latent {height}x{width}: level {l} has {self.hw[l][0] * self.hw[l][1]} tokens; the "
-                                 f"attention kernels need a multiple of 8 (use image sides that are multiples of 64)")
+        self.hw = self.level_sizes(cfg, height, width)
         self.keep: list = []
         B = batch
         E = lambda *shape, dtype=torch.float16: self._alloc(shape, dtype)
@@ -270,6 +270,25 @@ class UNetEngine:
         self.prepare_plan = self._build_prepare()
         self.forward_ops = self._build_forward()
         self.forward_plan = Plan(self.forward_ops, self.keep)
+
+    @staticmethod
+    def level_sizes(cfg: UNetMangaConfig, height: int, width: int) -> List[Tuple[int, int]]:
+        """(h, w) of every resolution level for a latent of height x width, or ValueError with the rule that failed.
+        The reference accepts any image side that is a multiple of 8; this engine needs every level to halve exactly
+        (latent sides multiples of 2^(levels-1)) and every attention level's token count to be a multiple of 8 (16-byte
+        rows of the key-contiguous V^T operand) - all image sides that are multiples of 64 qualify."""
+        nlev = len(cfg.block_out_channels)
+        q = 1 << (nlev - 1)
+        if height <= 0 or width <= 0 or height % q or width % q:
+            raise ValueError(f"latent size {height}x{width} (image {8 * height}x{8 * width}): both latent sides must be "
+                             f"multiples of {q} (image sides multiples of {8 * q}); multiples of 64 always work")
+        hw = [(height >> l, width >> l) for l in range(nlev)]
+        for l in range(1, nlev):
+            if (hw[l][0] * hw[l][1]) % 8:
+                raise ValueError(f"latent {height}x{width} (image {8 * height}x{8 * width}): attention level {l} would have "
+                                 f"{hw[l][0] * hw[l][1]} tokens; the attention kernels need a multiple of 8 - use image "
+                                 f"sides that are multiples of 64")
+        return hw
 
     # -- memory
     def _alloc(self, shape, dtype) -> Tensor:

@@ -353,6 +353,12 @@ class QwenResampler:
         self._add: Dict[int, Tensor] = {}
         self.w_out, self.b_out = half(f32("attn.out_proj.weight")), half(f32("attn.out_proj.bias"))
 
+    def tensors(self) -> List[Tensor]:
+        """Frozen (folded) weights (the multi-GPU weight broadcast list); the per-length key addends are derived."""
+        self._add.clear()
+        return [t for t in (self.q, self.kv_proj, self.ln_g, self.ln_b, self.w_kv, self.pos, self._wk, self._bk, self._bv,
+                            self.w_out, self.b_out) if t is not None]
+
     def _kv_addend(self, L: int) -> Tensor:
         """[L,2E] = [pos Wk^T + bk | bv] (pos interpolated like get_abs_pos when L differs from the query grid)."""
         a = self._add.get(L)
@@ -387,6 +393,25 @@ class QwenResampler:
 BOI_TOKEN, EOI_TOKEN, IMG_TOKEN = "<img>", "</img>", "<img_{:05d}>"
 
 
+def image_token_ids(tokenizer, num_img_gen_tokens: int, img_ids_list: Optional[Sequence[int]] = None):
+    """(processor chain, </img> id, the `num_img_gen_tokens` <img_xxxxx> ids) the way the reference derives them.
+
+    The LLaMA sentencepiece tokenizer prepends a '▁' id to whatever it encodes; the reference therefore takes
+    `encode(EOI_TOKEN)[1]` and `encode(img tokens)[1:]` (seed_x.py:139-141, gradio.py:44-45) but keeps the FULL encoded
+    list, prefix included, as the logits processor's chain (generation.py:15-17).  Same here: the chain is the list as
+    encoded; </img> is its last id and the image ids are the `num_img_gen_tokens` ids before it, so a list with or
+    without the prefix gives the same answer."""
+    if img_ids_list is None:
+        if tokenizer is None:
+            raise ValueError("pass a tokenizer or `img_ids_list`")
+        s = BOI_TOKEN + "".join(IMG_TOKEN.format(i) for i in range(num_img_gen_tokens)) + EOI_TOKEN
+        img_ids_list = tokenizer.encode(s, add_special_tokens=False)
+    chain = [int(v) for v in img_ids_list]
+    if len(chain) < num_img_gen_tokens + 2:
+        raise ValueError(f"image-token chain has {len(chain)} ids; needs <img> + {num_img_gen_tokens} image ids + </img>")
+    return chain, chain[-1], chain[-(num_img_gen_tokens + 1):-1]
+
+
 class ContinuousLVLM:
     """`ContinuousLVLM.generate` of the reference (seed_x.py:90-171) over the decode engine.
 
@@ -399,6 +424,10 @@ class ContinuousLVLM:
     def dtype(self):
         return torch.float16
 
+    def tensors(self) -> List[Tensor]:
+        """Frozen weights of the whole agent: LLaMA decode engine + both QwenResamplers (multi-GPU broadcast list)."""
+        return self.llm.tensors() + self.input_resampler.tensors() + self.output_resampler.tensors()
+
     @torch.no_grad()
     def generate(self, tokenizer=None, prompt=None, input_ids=None, image_embeds=None, ids_cmp_mask=None,
                  logits_processor=None, num_img_gen_tokens=64, temperature=0.7, num_beams=1, max_new_tokens=120,
@@ -408,12 +437,7 @@ class ContinuousLVLM:
                                       "have no device implementation")
         if num_beams != 1:
             raise NotImplementedError("the reference decodes greedily (num_beams=1, do_sample=False)")
-        if img_ids_list is None:
-            if tokenizer is None:
-                raise ValueError("pass a tokenizer or `img_ids_list`")
-            s = BOI_TOKEN + "".join(IMG_TOKEN.format(i) for i in range(num_img_gen_tokens)) + EOI_TOKEN
-            img_ids_list = tokenizer.encode(s, add_special_tokens=False)
-        img_ids_list = [int(v) for v in img_ids_list]
+        img_ids_list, eoi_token_id, image_gen_id_list = image_token_ids(tokenizer, num_img_gen_tokens, img_ids_list)
         if eos_token_id is None:
             eos_token_id = getattr(tokenizer, "eos_token_id", None)
             if eos_token_id is None:
@@ -432,8 +456,7 @@ class ContinuousLVLM:
         llm.set_image_token_chain(img_ids_list)
         g = llm.generate(emb, int(ids[-1]), int(eos_token_id), int(max_new_tokens))
         generate_ids, last_hidden_states = g["ids"].clone(), g["hidden"]
-        eoi_token_id = img_ids_list[-1]
-        image_gen_ids = torch.tensor(img_ids_list[1:-1], dtype=generate_ids.dtype, device=generate_ids.device)
+        image_gen_ids = torch.tensor(image_gen_id_list, dtype=generate_ids.dtype, device=generate_ids.device)
         eoi_indices = torch.where(generate_ids == eoi_token_id)[0].tolist()
         num_gen_imgs = len(eoi_indices)
         ids_gen_mask = torch.zeros_like(generate_ids, dtype=torch.bool)

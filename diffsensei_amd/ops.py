@@ -16,6 +16,14 @@ from ._lib import check
 Tensor = torch.Tensor
 
 
+def bind_device(dev: torch.device) -> None:
+    """One process drives one GPU.  The library launches on "the current stream", which HIP resolves per
+    CURRENT device, so before a launch the tensors' device is made the current one (a no-op in the normal case where
+    `init_from_env` / the caller already selected it)."""
+    if dev.type == "cuda" and dev.index is not None and dev.index != torch.cuda.current_device():
+        torch.cuda.set_device(dev)
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -30,6 +38,7 @@ def _chk(*ts: Optional[Tensor], dtype=torch.float16) -> None:
             continue
         if not t.is_cuda:
             raise _lib.DiffSenseiHipError("diffsensei_amd ops need CUDA(HIP) tensors — there is no CPU path")
+        bind_device(t.device)
         if dtype is not None and t.dtype != dtype:
             raise _lib.DiffSenseiHipError(f"expected {dtype}, got {t.dtype}")
         if not t.is_contiguous():

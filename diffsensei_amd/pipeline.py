@@ -57,7 +57,10 @@ class DiffSenseiPipeline:
         self.magi_image_encoder = None
         self.image_proj_model = None
         self._clip_proc = None
-        self.device_preprocess = False   # True: character references are resized / normalised by csrc/preprocess.hip
+        # character references are resized / cropped / normalised by csrc/preprocess.hip (bytes identical to Pillow; e2e
+        # character tokens vs the host processors rel-L2 6.9e-4, profiles/r02_device_preprocess_e2e.log).  False, or a
+        # reference that is not a PIL image, goes through the transformers processors on the host like the reference.
+        self.device_preprocess = True
         self._device_pre = None
         self._magi_proc = None
         self._guidance_scale = 1.0
@@ -111,6 +114,17 @@ class DiffSenseiPipeline:
             return m
         return ViTMAEEngine.from_transformers(m, self.unet.device)
 
+    def tensors(self) -> List[Tensor]:
+        """Every frozen weight tensor of the pipeline's engines (UNet state dict, text encoders, CLIP-H, Magi, Resampler,
+        VAE decoder): the list `distributed.broadcast_pipeline` sends from rank 0 over RCCL.  Components that are not HIP
+        engines (a user-supplied VAE object with its own `.decode`) are skipped."""
+        out: List[Tensor] = []
+        for m in (self.unet, self.text_encoder, self.text_encoder_2, self.image_encoder, self.magi_image_encoder,
+                  self.image_proj_model, self.vae):
+            if m is not None and hasattr(m, "tensors"):
+                out += list(m.tensors())
+        return out
+
     def register_manga_modules(self, magi_image_encoder, image_proj_model):
         """reference :73-79"""
         self.magi_image_encoder = self._as_magi_engine(magi_image_encoder)
@@ -144,7 +158,8 @@ class DiffSenseiPipeline:
         num_ips = len(ip_images)
         while len(ip_images) < max_num_ips:
             ip_images.append(_black_image())
-        if self.device_preprocess:      # opt-in: Pillow's resize + crop + normalise on the device (preprocess.py), bytes only go up
+        if self.device_preprocess and all(hasattr(im, "convert") and hasattr(im, "size") for im in ip_images):
+            # Pillow's resize + crop + normalise on the device (preprocess.py): only the RGB bytes go up
             if self._device_pre is None:
                 from .preprocess import DevicePreprocessor
                 self._device_pre = DevicePreprocessor(self._execution_device)
@@ -278,6 +293,10 @@ class DiffSenseiPipeline:
         original_size = original_size or (height, width)
         target_size = target_size or (height, width)
         self.check_inputs(prompt, prompt_2, ip_images, ip_image_embeds, ip_bbox)
+        if height % self.vae_scale_factor or width % self.vae_scale_factor:
+            raise ValueError(f"`height` and `width` have to be divisible by {self.vae_scale_factor} but are {height} and {width}.")
+        from .engine import UNetEngine                  # fail before any encoder runs, with the engine's own shape rule
+        UNetEngine.level_sizes(self.unet.config, height // self.vae_scale_factor, width // self.vae_scale_factor)
         self._guidance_scale = guidance_scale
         device = self._execution_device
         self.set_ip_scale(ip_scale)
@@ -332,6 +351,12 @@ class DiffSenseiPipeline:
             img = torch.cat([cat("neg", 2), img], dim=0)
             bbox = torch.cat([cat("neg", 3), bbox], dim=0)
             dialog = torch.cat([cat("neg", 4), dialog], dim=0)
+        else:
+            # Without CFG the reference still passes bbox = cat([negative_ip_bbox, ip_bbox]) (reference :270-273) while the
+            # UNet batch is only the `num_samples` conditional rows, so its mask builder indexes the FIRST num_samples rows:
+            # the all-zero negative boxes (attention_processor.py:141-163 loops `for i in range(batch)`).  Mirrored here so
+            # guidance_scale <= 1 gives the reference's images; `dialog_bbox` is not concatenated there and stays positive.
+            bbox = cat("neg", 3)
         enc = torch.cat([prompt_embeds, img], dim=1)
 
         # one plan replay per step

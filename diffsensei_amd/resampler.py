@@ -56,6 +56,10 @@ class Resampler:
     def state_dict(self):
         return dict(self._sd)
 
+    def tensors(self):
+        """Frozen weights (the multi-GPU weight broadcast list)."""
+        return list(self._sd.values())
+
     def init_random(self, seed: int = 0) -> "Resampler":
         g = torch.Generator(device="cpu")
         g.manual_seed(seed)

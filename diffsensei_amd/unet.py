@@ -122,6 +122,15 @@ class UNetMangaModel:
     def state_dict(self) -> Dict[str, Tensor]:
         return dict(self._sd)
 
+    def tensors(self):
+        """Frozen weights in state-dict layout (the multi-GPU weight broadcast list).  They are re-packed for the kernels
+        lazily, so a broadcast into these tensors must be followed by `weights_changed()`."""
+        return list(self._sd.values())
+
+    def weights_changed(self):
+        """Drop the packed copies / launch plans derived from the state dict (after an in-place update of `tensors()`)."""
+        self._invalidate()
+
     def load_state_dict(self, sd: Dict[str, Tensor], strict: bool = True):
         shapes = param_shapes(self.config)
         missing = [k for k in shapes if k not in sd]
@@ -161,6 +170,26 @@ class UNetMangaModel:
         return self._attn_processors
 
     def set_attn_processor(self, procs: Dict[str, Any]):
+        """diffusers protocol `unet.set_attn_processor({name: processor})` (reference src/models/unet.py:84).  The launch
+        plan implements exactly the reference's two processors, so anything else is refused instead of being silently
+        ignored: every key must be a known processor slot, attn1 slots take `AttnProcessor2_0`, attn2 slots take
+        `MaskedIPAttnProcessor2_0` (whose `.scale` the plan reads) or, before `set_manga_modules`, `AttnProcessor2_0`."""
+        known = attn_processor_names(self.config)
+        if not isinstance(procs, dict):
+            procs = {n: procs for n in known}
+        unknown = [n for n in procs if n not in known]
+        if unknown:
+            raise ValueError(f"set_attn_processor: unknown processor slots {unknown[:3]} (+{max(0, len(unknown) - 3)})")
+        missing = [n for n in known if n not in procs]
+        if missing:
+            raise ValueError(f"set_attn_processor: a processor is needed for every attention layer; missing {missing[:3]} "
+                             f"(+{max(0, len(missing) - 3)})")
+        for n, pr in procs.items():
+            ok = isinstance(pr, (AttnProcessor2_0, MaskedIPAttnProcessor2_0)) if n.endswith("attn2.processor") \
+                else isinstance(pr, AttnProcessor2_0)
+            if not ok:
+                raise ValueError(f"set_attn_processor: {type(pr).__name__} at {n} is not executed by the MI355X launch plan "
+                                 f"(attn1: AttnProcessor2_0, attn2: MaskedIPAttnProcessor2_0)")
         self._attn_processors = dict(procs)
 
     # ---- execution
@@ -176,12 +205,23 @@ class UNetMangaModel:
             self._packed = PackedUNet(self.config, self._sd, self.device)
         return self._packed
 
+    # Launch plans are cached per (batch, latent size): each owns its activation buffers, K/V panels and a captured
+    # hipGraph (GBs at batch 32).  A serving queue with many bucket fill levels must not accumulate them without bound,
+    # so the cache is LRU with a byte budget (DIFFSENSEI_ENGINE_CACHE_GB, default 64 of the 288 GB); the engine in use
+    # is never evicted.
+    engine_cache_bytes = int(float(os.environ.get("DIFFSENSEI_ENGINE_CACHE_GB", "64")) * (1 << 30))
+
     def engine(self, batch: int, height: int, width: int, aspect_ratio: Optional[float] = None) -> UNetEngine:
         key = (batch, height, width, None if aspect_ratio is None else round(float(aspect_ratio), 6))
-        eng = self._engines.get(key)
+        eng = self._engines.pop(key, None)
         if eng is None:
             eng = UNetEngine(self.packed(), batch, height, width, aspect_ratio)
-            self._engines[key] = eng
+        self._engines[key] = eng                      # dict order = recency (most recent last)
+        total = sum(e.nbytes() for e in self._engines.values())
+        for k in list(self._engines):
+            if total <= self.engine_cache_bytes or k == key:
+                break
+            total -= self._engines.pop(k).nbytes()
         return eng
 
     def ip_scale(self) -> float:

@@ -28,8 +28,19 @@ const char* ds_last_error(void);
 int ds_version(void);
 /* number of HIP devices visible / properties of the current one (sanity for loaders) */
 int ds_device_info(int* cu_count, int* lds_bytes, char* arch_name, int arch_name_len);
-/* tuning knobs (process-wide): "gemm_variant" = 0 auto | 1 register-staged only | 2, 7 two-buffer LDS-DMA | 8, 9 one-buffer
- * LDS-DMA | 3 256x256 ping-pong | 10 halo-patch conv (A/B runs; 0 in production) */
+/* Tuning / test knobs (process-wide; every one defaults to 0 = automatic dispatch, which is what production runs).
+ * They exist so that A/B runs and the parity tests can force a kernel variant the automatic rule would only pick at
+ * large problem sizes; every variant of an operator computes the same result (the tests assert torch.equal between them).
+ *   "gemm_variant"       0 auto | 1 register-staged only | 2, 7 two-buffer LDS-DMA | 8, 9 one-buffer LDS-DMA |
+ *                        3 256x256 ping-pong (gemm_pp_kernel) | 10 halo-patch conv
+ *   "conv_halo_variant"  0 auto (16x16-pixel blocks from 1024 blocks on) | 1 force conv_halo_kernel (8x16 pixels) |
+ *                        2 force conv_halo256_kernel (16x16 pixels)
+ *   "attn_variant"       0 auto (64 query rows per wave from Nk >= 2048 and >= 512 blocks on) | 1 force
+ *                        self_attn_kernel<1> (32 rows per wave) | 2 force self_attn_kernel<2> (64 rows per wave)
+ *   "ip_attn_min_blocks" grid size below which ip_attn_kernel stops doubling its query tiles per block (default 1024)
+ *   "llm_gemv_variant"   0 auto (software-pipelined persistent GEMV) | 1 one column per wavefront | 2 un-pipelined streaming GEMV
+ *   "gemm_debug"         ablation builds of gemm_pp_kernel (only in a library built with -DDS_ABLATION; 0 otherwise)
+ * returns 0, or -1 (ds_last_error()) for an unknown key / out-of-range value */
 int ds_set_option(const char* key, int value);
 
 /* ------------------------------------------------------------------------------------------------

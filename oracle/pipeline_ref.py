@@ -22,7 +22,9 @@ def sample_loop(unet: UNetOracle, scheduler, latents: torch.Tensor, enc: torch.T
                 time_ids: torch.Tensor, bbox: torch.Tensor, dialog_bbox: Optional[torch.Tensor], guidance_scale: float,
                 num_steps: int, ip_scale: float, q: Callable = _id, max_steps: Optional[int] = None) -> torch.Tensor:
     """latents: [ns,4,H,W] already multiplied by init_noise_sigma; enc/text_embeds/time_ids/bbox/dialog_bbox are the
-    CFG-concatenated ([neg..., pos...]) tensors of reference :294-303."""
+    CFG-concatenated ([neg..., pos...]) tensors of reference :294-303.  guidance_scale <= 1 (`do_classifier_free_guidance`
+    False, reference :315, :333): the conditional rows only - the caller passes `num_samples` rows, and for `bbox` the
+    FIRST `num_samples` rows of cat([negative_ip_bbox, ip_bbox]) like the reference's mask builder ends up using."""
     scheduler.set_timesteps(num_steps)
     unet.ip_scale = ip_scale
     x = q(latents.float())
@@ -30,11 +32,15 @@ def sample_loop(unet: UNetOracle, scheduler, latents: torch.Tensor, enc: torch.T
     n = num_steps if max_steps is None else min(num_steps, max_steps)
     for i in range(n):
         t = float(scheduler.timesteps[i])
-        xin = torch.cat([x] * 2)                                   # :315
+        do_cfg = guidance_scale > 1
+        xin = torch.cat([x] * 2) if do_cfg else x                  # :315
         xin = q(scheduler.scale_model_input(xin, i))               # :317
         eps = unet.forward(xin, t, enc, text_embeds, time_ids, bbox, ar, dialog_bbox)   # :322-329
-        u, c = eps.chunk(2)
-        e = q(u + q(guidance_scale * q(c - u)))                    # :333-334 (fp16 tensor ops in the reference)
+        if do_cfg:
+            u, c = eps.chunk(2)
+            e = q(u + q(guidance_scale * q(c - u)))                # :333-334 (fp16 tensor ops in the reference)
+        else:
+            e = eps
         x = q(scheduler.step(e, i, x))                             # :337
     return x
 

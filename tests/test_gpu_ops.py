@@ -194,6 +194,85 @@ def test_conv3x3(hip_lib, B, H, W, Cin, Cout, stride, up):
     _close(y2.permute(0, 3, 1, 2), ref2, what="conv+rowbias+res")
 
 
+def _conv_case(g, B, H, W, Cin, Cout, up, dtype=torch.float16):
+    x = (torch.randn((B, Cin, H, W), generator=g)).to(dtype)
+    w = (torch.randn((Cout, Cin, 3, 3), generator=g) / math.sqrt(9 * Cin)).to(dtype)
+    b = torch.randn((Cout,), generator=g).to(dtype)
+    xi = F.interpolate(x.float(), scale_factor=2.0, mode="nearest") if up else x.float()
+    ref = F.conv2d(xi, w.float(), b.float(), padding=1)
+    return x.permute(0, 2, 3, 1).contiguous().to(DEV), w.permute(0, 2, 3, 1).contiguous().to(DEV), b.to(DEV), ref
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,up", [(2, 32, 32, 64, 128, False), (1, 20, 24, 128, 192, False),
+                                                (2, 9, 13, 64, 64, True), (1, 64, 64, 320, 320, False),
+                                                (3, 16, 48, 640, 320, False), (1, 24, 40, 1280, 640, True)])
+def test_conv_halo256_forced_variant(hip_lib, B, H, W, Cin, Cout, up):
+    """`conv_halo256_kernel<half>` (16x16-pixel blocks; the variant the benchmark's batch-32 forward dispatches to) forced
+    with conv_halo_variant 2 on shapes whose grids are far below its automatic threshold, incl. ragged edge patches and the
+    fused x2 upsample: vs F.conv2d in fp32, and bit-identical to `conv_halo_kernel` (8x16 pixels, variant 1)."""
+    from diffsensei_amd import _lib
+    ops = _ops(hip_lib)
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(B * H + Cin + Cout + int(up))
+    x, w, b, ref = _conv_case(g, B, H, W, Cin, Cout, up)
+    rb = _r((B, Cout), g)
+    res = _r(tuple(ref.shape), g)
+    ref2 = (ref + rb.float()[:, :, None, None]).half().float() + res.float()
+    res_d = res.permute(0, 2, 3, 1).contiguous().to(DEV)
+    out = {}
+    try:
+        for v in (1, 2):
+            assert lib.ds_set_option(b"conv_halo_variant", v) == 0
+            out[v] = (ops.conv3x3(x, w, b, upsample=up),
+                      ops.conv3x3(x, w, b, upsample=up, rowbias=rb.to(DEV), residual=res_d))
+    finally:
+        lib.ds_set_option(b"conv_halo_variant", 0)
+    _close(out[2][0].permute(0, 3, 1, 2), ref, what="halo256")
+    _close(out[2][1].permute(0, 3, 1, 2), ref2, what="halo256+rowbias+res")
+    assert torch.equal(out[1][0], out[2][0]) and torch.equal(out[1][1], out[2][1]), "16x16 and 8x16 halo kernels differ"
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,up", [(8, 128, 128, 320, 320, False), (16, 32, 32, 640, 640, True)])
+def test_conv_halo256_natural_dispatch(hip_lib, B, H, W, Cin, Cout, up):
+    """Shapes of the benchmarked forward (batch 32: B x 128 x 128 x 320 -> 320; here B = 8 -> 1536 blocks >= 1024, and
+    the level-1 upsampler) that reach `conv_halo256_kernel` through the automatic dispatch of ds_conv3x3_f16."""
+    from diffsensei_amd import _lib
+    ops = _ops(hip_lib)
+    lib = _lib.load()
+    Ho, Wo = (2 * H, 2 * W) if up else (H, W)
+    assert B * ((Ho + 15) // 16) * ((Wo + 15) // 16) * ((Cout + 127) // 128) >= 1024
+    g = torch.Generator().manual_seed(B + H + Cin)
+    x, w, b, ref = _conv_case(g, B, H, W, Cin, Cout, up)
+    auto = ops.conv3x3(x, w, b, upsample=up)
+    try:
+        lib.ds_set_option(b"conv_halo_variant", 1)
+        small = ops.conv3x3(x, w, b, upsample=up)
+    finally:
+        lib.ds_set_option(b"conv_halo_variant", 0)
+    _close(auto.permute(0, 3, 1, 2), ref, what="halo256 auto")
+    assert torch.equal(auto, small)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,up", [(1, 32, 32, 128, 128, False), (1, 24, 40, 256, 128, True),
+                                                (2, 64, 64, 512, 256, False)])
+def test_conv_halo256_bf16(hip_lib, B, H, W, Cin, Cout, up):
+    """bf16 twin (VAE decoder) of the 16x16-pixel halo kernel: forced, vs fp32 conv and bit-identical to the 8x16 kernel."""
+    from diffsensei_amd import _lib
+    ops = _ops(hip_lib)
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(B * H + Cin + Cout + 5)
+    x, w, b, ref = _conv_case(g, B, H, W, Cin, Cout, up, dtype=torch.bfloat16)
+    out = {}
+    try:
+        for v in (1, 2):
+            assert lib.ds_set_option(b"conv_halo_variant", v) == 0
+            out[v] = ops.conv3x3_bf16(x, w, b, upsample=up)
+    finally:
+        lib.ds_set_option(b"conv_halo_variant", 0)
+    _close(out[2].permute(0, 3, 1, 2), ref, tol=1e-2, what="halo256 bf16")   # bf16 output: 8 mantissa bits
+    assert torch.equal(out[1], out[2])
+
+
 def test_conv_in_dialog_and_conv_out(hip_lib):
     ops = _ops(hip_lib)
     g = torch.Generator().manual_seed(11)
@@ -256,6 +335,55 @@ def test_self_attention(hip_lib, B, heads, N):
     vt = v.view(B, N, heads, 64).permute(0, 2, 3, 1).contiguous()
     y = ops.self_attention(q.to(DEV), k.to(DEV), vt.to(DEV), heads)
     _close(y, ref, tol=3e-3, what="self-attn")
+
+
+def _sdpa_case(g, B, heads, N):
+    C = heads * 64
+    q, k, v = _r((B, N, C), g), _r((B, N, C), g), _r((B, N, C), g)
+    hs = lambda t: t.float().view(B, N, heads, 64).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(hs(q), hs(k), hs(v)).transpose(1, 2).reshape(B, N, C)
+    vt = v.view(B, N, heads, 64).permute(0, 2, 3, 1).contiguous()
+    return q.to(DEV), k.to(DEV), vt.to(DEV), ref
+
+
+@pytest.mark.parametrize("B,heads,N", [(1, 2, 256), (2, 10, 1024), (1, 4, 960), (1, 2, 72), (1, 3, 4096), (2, 5, 2312)])
+def test_self_attention_64row_variant_forced(hip_lib, B, heads, N):
+    """`self_attn_kernel<2>` (64 query rows per wave: the variant the benchmark runs at N = 4096) forced with
+    attn_variant 2, incl. ragged query/key counts: vs fp32 SDPA, and bit-identical to `self_attn_kernel<1>`."""
+    from diffsensei_amd import _lib
+    ops = _ops(hip_lib)
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(B + heads + N)
+    q, k, vt, ref = _sdpa_case(g, B, heads, N)
+    out = {}
+    try:
+        for v in (1, 2):
+            assert lib.ds_set_option(b"attn_variant", v) == 0
+            out[v] = ops.self_attention(q, k, vt, heads)
+    finally:
+        lib.ds_set_option(b"attn_variant", 0)
+    _close(out[2], ref, tol=3e-3, what="self-attn<2>")
+    assert torch.equal(out[1], out[2]), "64-row and 32-row flash kernels differ"
+
+
+def test_self_attention_64row_natural_dispatch(hip_lib):
+    """The benchmark's level-1 shape class (N = 4096, heads 10) at a batch that crosses the automatic threshold
+    (16 * B * heads >= 512 blocks): ds_self_attn_f16 picks `self_attn_kernel<2>` by itself."""
+    from diffsensei_amd import _lib
+    ops = _ops(hip_lib)
+    lib = _lib.load()
+    B, heads, N = 4, 10, 4096
+    assert ((N + 255) // 256) * B * heads >= 512 and N >= 2048
+    g = torch.Generator().manual_seed(77)
+    q, k, vt, ref = _sdpa_case(g, B, heads, N)
+    auto = ops.self_attention(q, k, vt, heads)
+    try:
+        lib.ds_set_option(b"attn_variant", 1)
+        small = ops.self_attention(q, k, vt, heads)
+    finally:
+        lib.ds_set_option(b"attn_variant", 0)
+    _close(auto, ref, tol=3e-3, what="self-attn auto N=4096")
+    assert torch.equal(auto, small)
 
 
 def test_self_attention_forced_rescale(hip_lib):

@@ -91,6 +91,45 @@ def test_text_only_request_runs_the_ip_branch(pipe):
     assert _rel(out, ref) <= 5e-2, _rel(out, ref)
 
 
+def test_guidance_scale_one_uses_the_negative_boxes_like_the_reference(pipe):
+    """guidance_scale <= 1: the reference still hands cat([negative_ip_bbox, ip_bbox]) to a UNet batch of only the
+    conditional rows, so its mask builder reads the all-zero boxes (pipeline_diffsensei.py:270-273,
+    attention_processor.py:141-163); `dialog_bbox` stays the positive one.  Same here: vs the no-CFG oracle loop with
+    zero boxes, and independent of the `ip_bbox` values passed."""
+    from PIL import Image
+    from transformers import CLIPImageProcessor, ViTImageProcessor
+    from oracle.pipeline_ref import sample_loop
+    from oracle.resampler_ref import resampler_forward
+    from oracle.scheduler_ref import EulerDiscreteOracle
+    from oracle.unet_ref import UNetOracle
+    p, cfg, sd, rs, clip, mae, common = pipe
+    rng = np.random.RandomState(3)
+    imgs = [Image.fromarray(rng.randint(0, 256, (224, 224, 3), dtype=np.uint8)) for _ in range(2)]
+    boxes = [[0.05, 0.10, 0.50, 0.95], [0.50, 0.10, 0.95, 0.95]]
+    dialog = [[0.05, 0.02, 0.30, 0.15]]
+    lat0 = torch.randn(1, 4, 16, 16, generator=torch.Generator().manual_seed(6)).half()
+    kw = dict(common, guidance_scale=1.0)
+    out = p(ip_images=list(imgs), ip_bbox=boxes, dialog_bbox=dialog, ip_scale=0.6, latents=lat0.clone(), **kw).images
+    out0 = p(ip_images=list(imgs), ip_bbox=[[0.0] * 4] * 2, dialog_bbox=dialog, ip_scale=0.6, latents=lat0.clone(), **kw).images
+    assert torch.equal(out, out0), "without CFG the box values must not reach the mask (reference quirk)"
+    padded = list(imgs) + [Image.new("RGB", (224, 224))] * 2
+    with torch.no_grad():
+        ce = clip(CLIPImageProcessor()(images=padded, return_tensors="pt").pixel_values,
+                  output_hidden_states=True).hidden_states[-2].unsqueeze(0)
+        me = mae(ViTImageProcessor()(images=padded, return_tensors="pt").pixel_values).last_hidden_state[:, 0].unsqueeze(0)
+        ce[0, 2:], me[0, 2:] = 0, 0
+        img = hq(resampler_forward({k: v.float().cpu() for k, v in rs.state_dict().items()}, ce, me, 2, 64))
+        enc = torch.cat([common["prompt_embeds"].float(), img], dim=1)
+        te = common["pooled_prompt_embeds"].float()
+        tid = torch.tensor([[128, 128, 0, 0, 128, 128]], dtype=torch.float32)
+        db = torch.zeros(1, 8, 4, dtype=torch.float16)
+        db[0, 0] = torch.tensor(dialog[0]).half()
+        sch = EulerDiscreteOracle().set_timesteps(3)
+        ref = sample_loop(UNetOracle(cfg, sd, q=hq), EulerDiscreteOracle(), hq(lat0.float() * sch.init_noise_sigma), hq(enc),
+                          hq(te), tid, torch.zeros(1, 4, 4), db, 1.0, 3, 0.6, q=hq)
+    assert _rel(out, ref) <= 3e-2, _rel(out, ref)
+
+
 def test_call_returns_images_through_the_hip_vae(pipe):
     """Whole `__call__` to images (reference :339-367): VAE decode + denormalize on the bf16 HIP decoder; "pt"/"np"/"pil"."""
     from PIL import Image

@@ -91,3 +91,42 @@ def test_engine_has_no_cpu_path():
     assert eng.weight_bytes_per_token() == 2 * (3 * 128 * 128 + 128 * 128 + 512 * 128 + 128 * 256 + 64 * 128 + 128)
     with pytest.raises(ValueError):
         eng.generate(torch.zeros(4, 128, dtype=torch.float16), 1, 2, 4)                  # host tensor: refused
+
+
+class _SentencePieceLikeTokenizer:
+    """LLaMA-style: every encode() result starts with the '▁' id (29871), like the tokenizer the reference uses."""
+    eos_token_id = 2
+
+    def __init__(self, boi=32100, n=64):
+        self.vocab = {"<img>": boi, "</img>": boi + n + 1}
+        self.vocab.update({f"<img_{i:05d}>": boi + 1 + i for i in range(n)})
+
+    def encode(self, s, add_special_tokens=False):
+        ids, i = [29871], 0
+        while i < len(s):
+            j = s.index(">", i) + 1
+            ids.append(self.vocab[s[i:j]])
+            i = j
+        return ids
+
+
+def test_image_token_ids_follow_the_reference_tokenizer_convention():
+    """reference seed_x.py:139-141 / gradio.py:44-45 index past the sentencepiece prefix id ([1], [1:]) while the logits
+    processor keeps the whole encoded list (generation.py:15-17)."""
+    tok = _SentencePieceLikeTokenizer()
+    n = 64
+    # what the reference computes
+    ref_eoi = tok.encode(M.EOI_TOKEN, add_special_tokens=False)[1]
+    ref_img = tok.encode("".join(M.IMG_TOKEN.format(i) for i in range(n)), add_special_tokens=False)[1:]
+    ref_chain = tok.encode("".join([M.BOI_TOKEN] + [M.IMG_TOKEN.format(i) for i in range(n)] + [M.EOI_TOKEN]),
+                           add_special_tokens=False)
+    chain, eoi, img = M.image_token_ids(tok, n)
+    assert chain == ref_chain and chain[0] == 29871 and len(chain) == n + 3
+    assert eoi == ref_eoi and img == ref_img and len(img) == n
+    # an explicit list without the prefix (what the golden fixtures pass) gives the same ids
+    chain2, eoi2, img2 = M.image_token_ids(None, n, ref_chain[1:])
+    assert (eoi2, img2) == (eoi, img) and chain2 == ref_chain[1:]
+    with pytest.raises(ValueError):
+        M.image_token_ids(None, n, ref_chain[:10])
+    with pytest.raises(ValueError):
+        M.image_token_ids(None, n)
