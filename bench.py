@@ -11,16 +11,19 @@ plan.  Inputs are synthetic and already resident in HBM where tensors are involv
 images are 224x224 uint8 that go through the reference's CPU image processors).  Weights: seeded random at the true
 SDXL / CLIP-H / ViT-MAE / Resampler shapes (no checkpoint is reachable offline; throughput is value independent).
 The timed region also runs both SDXL text encoders (CLIP-L + OpenCLIP bigG shapes, HIP engine) on the prompt and the
-negative prompt (token ids from a synthetic tokenizer: no vocabulary files offline) and ends with the SDXL VAE decode +
-denormalisation on the bf16 HIP decoder (output: [0,1] fp32 images on the device; `--no-vae` stops at the latents).
+negative prompt (token ids from a synthetic tokenizer: no vocabulary files offline) and ends, like the reference's
+`__call__` (pipeline_diffsensei.py:339-367), with the SDXL VAE decode + denormalisation on the bf16 HIP decoder and the
+conversion to PIL images on the host (uint8 conversion on the device, 3 bytes per pixel over PCIe); `--output pt` stops
+at [0,1] fp32 images on the device (round-1 region), `--no-vae` at the latents.
 
 N > 1: one process per GPU, weights broadcast from rank 0 over RCCL once (time reported, outside the timed region),
 each rank serves its own requests with no data-path collective -> "scaling": "weak".  Timing: barrier +
 synchronize on both sides, MAX over ranks; value = N * K * num_samples / t.
 
 Extra objects on the JSON line: `roofline` (dominant kernel of the UNet forward, algorithmic flops / HIP-event time
-vs the 2.5 PFLOP/s dense fp16 MFMA peak) and `cpu_baseline` (the fp32 CPU oracle on a bounded sample of
-BASELINE.json configs[0], rank 0 at N=1 only).
+vs the 2.5 PFLOP/s dense fp16 MFMA peak), `cpu_baseline` (the fp32 CPU oracle on a bounded sample of BASELINE.json
+configs[0], rank 0 at N=1 only) and `parity` (the SAME configs[0] steps run on the GPU with the same weights, latents and
+conditioning as the oracle just timed: relative L2 of the latents; the bench FAILS above 3e-2).
 """
 from __future__ import annotations
 
@@ -45,10 +48,10 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def build_pipeline(device, num_gpus, rank, seed=0, with_vae=True):
+def build_pipeline(device, num_gpus, rank, seed=0, with_vae=True, agent=None):
     """Reference construction recipe (scripts/demo/gradio_wo_mllm.py:161-200) with synthetic weights."""
     from transformers import CLIPVisionConfig, CLIPVisionModel, ViTMAEConfig, ViTMAEModel
-    from diffsensei_amd.distributed import broadcast_tensors
+    from diffsensei_amd.distributed import broadcast_pipeline
     from diffsensei_amd.encoders import ClipVisionEngine, ViTMAEEngine
     from diffsensei_amd.pipeline import DiffSenseiPipeline
     from diffsensei_amd.resampler import Resampler
@@ -84,28 +87,19 @@ def build_pipeline(device, num_gpus, rank, seed=0, with_vae=True):
     from diffsensei_amd.vae import VaeConfig, VaeDecoderEngine
     vae = VaeDecoderEngine.init_random(VaeConfig(), seed + 2, device) if with_vae else None
     t_init = time.perf_counter() - t0
-    bstats = {"bytes": 0, "seconds": 0.0, "buckets": 0}
-    if num_gpus > 1:
-        tensors = list(unet._sd.values()) + list(resampler._sd.values()) + (vae.tensors() if vae is not None else [])
-        for eng in (te1, te2):
-            for L in eng.layers:
-                tensors += [getattr(L, s) for s in L.__slots__]
-            tensors += [eng.tok_emb, eng.pos_emb, *eng.final_ln] + ([eng.text_projection] if eng.text_projection is not None else [])
-        for eng in (clip, magi):
-            for L in eng.layers:
-                tensors += [getattr(L, s) for s in L.__slots__]
-            tensors += [eng.patch_w, eng.cls_row, eng.pos_patches] + [t for t in (eng.patch_b,) if t is not None]
-            for pair in (eng.pre_ln, eng.post_ln):
-                if pair is not None:
-                    tensors += list(pair)
-        dist.barrier()
-        bstats = broadcast_tensors(tensors, src=0)
     tok = SyntheticTokenizer()
     pipe = DiffSenseiPipeline(vae=vae, text_encoder=te1, text_encoder_2=te2, tokenizer=tok, tokenizer_2=tok,
                               scheduler=EulerDiscreteScheduler(), unet=unet, image_encoder=clip)
     pipe.register_manga_modules(magi_image_encoder=magi, image_proj_model=resampler)
+    # N > 1: every engine's frozen weights (pipe.tensors() [+ the MLLM agent]) go out from rank 0 in 512 MiB buckets,
+    # then an all-reduced checksum proves the replicas are bit-identical (ranks != 0 were seeded differently on purpose)
+    bstats = {"bytes": 0, "seconds": 0.0, "buckets": 0, "verify_ms": 0.0, "tensors": 0}
+    if num_gpus > 1:
+        dist.barrier()
+        bstats = broadcast_pipeline(pipe, extra=[agent] if agent is not None else [])
     return pipe, {"init_s": round(t_init, 2), "broadcast_bytes": bstats["bytes"],
-                  "broadcast_ms": round(bstats["seconds"] * 1e3, 2), "broadcast_buckets": bstats["buckets"]}
+                  "broadcast_ms": round(bstats["seconds"] * 1e3, 2), "broadcast_buckets": bstats["buckets"],
+                  "broadcast_verify_ms": round(bstats["verify_ms"], 2), "broadcast_tensors": bstats["tensors"]}
 
 
 class SyntheticTokenizer:
@@ -155,6 +149,34 @@ def build_mllm_agent(device, seed=7):
                                                   "max_new": 66}
 
 
+def gpu_parity_on_oracle_state(pipe, st):
+    """BASELINE configs[0] (512x512, 20-step Euler, text-only, batch 1) on the HIP engine with the weights, initial latents
+    and conditioning the CPU oracle has just been timed on (`north_star`: "outputs match the reference CPU path on identical
+    seeds/latents within stated fp16 tolerance").  Compares the latents after the oracle's measured steps; the tolerance,
+    3e-2 relative L2, is fp16 storage vs the oracle's pure fp32 through `steps_done` UNet forwards + CFG at 7.5."""
+    from diffsensei_amd.schedulers import EulerDiscreteScheduler
+    H, W = st["height"] // 8, st["width"] // 8
+    sch = EulerDiscreteScheduler()
+    sch.set_timesteps(st["steps"])
+    eng = pipe.unet.engine(2, H, W, H / W)
+    eng.build_sampler(1, sch.kind, True)
+    eng.set_request(st["enc"], st["text_embeds"], st["time_ids"], st["bbox"], None, st["ip_scale"])
+    eng.load_schedule(torch.from_numpy(sch.coef_table(st["guidance_scale"])))
+    eng.latents.copy_(st["latents0"].to(eng.latents.device, torch.float16))
+    eng.prep_plan.run()
+    for _ in range(st["steps_done"]):
+        eng.step_plan.run()
+    torch.cuda.synchronize()
+    got, ref = eng.latents.float().cpu(), st["latents"].float()
+    assert torch.isfinite(got).all()
+    rel = ((got - ref).norm() / ref.norm()).item()
+    moved = ((ref - st["latents0"].float()).norm() / ref.norm()).item()
+    return {"config": "C1: 512x512, 20-step Euler, text-only, batch 1 (BASELINE.json configs[0])", "steps": st["steps_done"],
+            "rel_l2": round(rel, 6), "max_abs": round((got - ref).abs().max().item(), 5), "tolerance": 3e-2,
+            "latents_moved_rel": round(moved, 4),
+            "vs": "oracle/pipeline_ref (fp32 torch, CPU) on the same weights / latents / conditioning"}
+
+
 def profile_forward_ops(pipe, reps=3):
     """HIP-event time of every op of the UNet forward plan, on the stream the kernels are launched on; grouped by
     the gfx950 kernel they dispatch to.  Returns (per-kernel table, forward_ms)."""
@@ -199,7 +221,13 @@ def main():
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-vae", action="store_true", help="stop at the latents (the round-1 timed region)")
+    ap.add_argument("--no-vae", action="store_true", help="stop at the latents (the first timed region of round 1)")
+    ap.add_argument("--output", choices=("pil", "pt"), default="pil",
+                    help="pil: PIL images on the host like the reference's __call__ (default, the metric's region); "
+                         "pt: [0,1] fp32 images left on the device (the round-1 region)")
+    ap.add_argument("--refs", type=int, default=2, help="character references in the request (BASELINE config 2: 1)")
+    ap.add_argument("--no-dialog", action="store_true", help="no dialog boxes (BASELINE config 2)")
+    ap.add_argument("--no-parity", action="store_true", help="skip the GPU-vs-oracle parity run on BASELINE configs[0]")
     ap.add_argument("--mllm", action="store_true",
                     help="BASELINE config 3: run the MLLM pre-pass (LLaMA-2-13B dims, 66 new tokens) inside the timed "
                          "region and feed its ip_image_embeds to the sampler (scripts/demo/gradio.py:85-129); "
@@ -218,13 +246,17 @@ def main():
     if world > 1:
         dist.barrier()
 
-    pipe, setup = build_pipeline(device, world, rank, with_vae=not args.no_vae)
-    ns = args.num_samples
-    req = synthetic_request(device, args.size, seed=1234 + rank, output_type="latent" if args.no_vae else "pt")
-
     agent = mllm_in = None
     if args.mllm:
-        agent, mllm_in = build_mllm_agent(device)
+        agent, mllm_in = build_mllm_agent(device, seed=7 if rank == 0 else 70 + rank)
+    pipe, setup = build_pipeline(device, world, rank, with_vae=not args.no_vae, agent=agent)
+    ns = args.num_samples
+    out_type = "latent" if args.no_vae else args.output
+    req = synthetic_request(device, args.size, seed=1234 + rank, output_type=out_type)
+    if args.refs != 2 or args.no_dialog:
+        req["ip_images"], req["ip_bbox"] = req["ip_images"][:args.refs], req["ip_bbox"][:args.refs]
+        if args.no_dialog:
+            req["dialog_bbox"] = []
 
     def one_step():
         r = req
@@ -252,9 +284,15 @@ def main():
         t = torch.tensor([dt], device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    assert torch.isfinite(lat.float()).all(), "non-finite output"
-    if not args.no_vae:
-        assert lat.shape == (ns, 3, args.size, args.size) and float(lat.min()) >= 0.0 and float(lat.max()) <= 1.0
+    if out_type == "pil":
+        assert len(lat) == ns and all(im.size == (args.size, args.size) and im.mode == "RGB" for im in lat)
+        import numpy as np
+        px = np.asarray(lat[0])
+        assert px.std() > 0, "constant image"
+    else:
+        assert torch.isfinite(lat.float()).all(), "non-finite output"
+        if not args.no_vae:
+            assert lat.shape == (ns, 3, args.size, args.size) and float(lat.min()) >= 0.0 and float(lat.max()) <= 1.0
     panels = world * args.steps * ns
     value = panels / dt
 
@@ -289,13 +327,20 @@ def main():
                                 sorted(table.items(), key=lambda kv: -kv[1]["ms"])}}
         log(json.dumps(extra, indent=1))
 
-    cpu_baseline = None
+    cpu_baseline = parity = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from diffsensei_amd.unet_config import sdxl_config
         from oracle.pipeline_ref import time_cpu_baseline
         sd_cpu = {k: v.float().cpu() for k, v in pipe.unet._sd.items()}
-        cpu_baseline = time_cpu_baseline(sdxl_config(), sd_cpu, 512, 512, 20, budget_s=25.0)
+        cpu_baseline = time_cpu_baseline(sdxl_config(), sd_cpu, 512, 512, 20, budget_s=25.0, keep_state=True, min_steps=2)
+        state = cpu_baseline.pop("_state")
         cpu_baseline["value"] = round(cpu_baseline["value"], 6)
+        del sd_cpu
+        if not args.no_parity:
+            parity = gpu_parity_on_oracle_state(pipe, state)
+            log("parity:", json.dumps(parity))
+            assert parity["rel_l2"] <= parity["tolerance"], \
+                f"GPU latents differ from the CPU oracle on BASELINE configs[0]: {parity}"
 
     if rank == 0:
         line = {
@@ -303,18 +348,22 @@ def main():
             "value": round(value, 4), "unit": "panels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"{args.size}x{args.size}, 50-step Euler, CFG 7.5, 2 character refs (padded to 4) + "
-                                   f"2 dialog boxes, num_samples={ns} per call (UNet batch {2 * ns}), one call per step",
+            "config": {"workload": f"{args.size}x{args.size}, 50-step Euler, CFG 7.5, {args.refs} character refs (padded to 4) + "
+                                   f"{0 if args.no_dialog else 2} dialog boxes, num_samples={ns} per call (UNet batch {2 * ns}), "
+                                   f"one call per step",
+                       "output": out_type,
                        "timed_region": "2 SDXL text encoders (prompt + negative prompt), CLIP-H + ViT-MAE + Resampler "
                                        "character encoding, 50 x (UNet + CFG + scheduler step)" +
                                        ("; VAE decode excluded (output: latents)" if args.no_vae else
-                                        ", SDXL VAE decode + denormalize (bf16 HIP engine; output: [0,1] fp32 images on the device)"),
+                                        ", SDXL VAE decode + denormalize (bf16 HIP engine)" +
+                                        ("; uint8 conversion on the device, D2H, PIL images on the host (reference :367)"
+                                         if out_type == "pil" else "; output: [0,1] fp32 images on the device")),
                        "mllm_prepass": ("LLaMA-2-13B dims, 111-token prompt + 66 new tokens (64-token image block), both "
                                         "QwenResamplers, blend; timed") if args.mllm else None,
                        "num_samples": ns, "unet_batch": 2 * ns, "hipgraph": pipe.last_run_info.get("graph"),
                        "kernel_launches_per_denoise_step": pipe.last_run_info.get("ops_per_step"),
                        "weights": "seeded random at SDXL UNet / CLIP-L + bigG text / CLIP-H / ViT-MAE / Resampler / VAE decoder shapes", **setup},
-            "roofline": roofline, "cpu_baseline": cpu_baseline,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity,
         }
         if extra:
             line["unet_forward"] = {k: extra[k] for k in ("unet_forward_ms_event_sum", "unet_forward_algorithmic_tflop",

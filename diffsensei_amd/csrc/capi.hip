@@ -339,6 +339,9 @@ int ds_nhwc_to_nchw_f16(const void* x, void* y, int B, int HW, int C, void* stre
 int ds_nchw_to_nhwc_f16(const void* x, void* y, int B, int HW, int C, void* stream) {
     return ds_launch_nchw_to_nhwc(H(x), HM(y), B, HW, C, S(stream));
 }
+int ds_image_f32_to_u8_nhwc(const float* image, uint8_t* out, int B, int H_, int W_, void* stream) {
+    return ds_launch_image_to_u8(image, out, B, H_, W_, S(stream));
+}
 int ds_pad_rows_f16(const void* x, void* y, int B, int rows_in, int rows_out, int row_off, int total_rows, int C,
                     void* stream) {
     return ds_launch_pad_rows(H(x), HM(y), B, rows_in, rows_out, row_off, total_rows, C, S(stream));

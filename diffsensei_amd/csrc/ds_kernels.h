@@ -128,6 +128,7 @@ int ds_launch_prepare_model_input(const half_t* latents, half_t* model_in, const
                                   int HW, int C, int do_cfg, hipStream_t stream);
 int ds_launch_advance_counter(int* ctr, hipStream_t stream);
 int ds_launch_nhwc_to_nchw(const half_t* x, half_t* y, int B, int HW, int C, hipStream_t stream);
+int ds_launch_image_to_u8(const float* img, uint8_t* out, int B, int H, int W, hipStream_t stream);
 int ds_launch_nchw_to_nhwc(const half_t* x, half_t* y, int B, int HW, int C, hipStream_t stream);
 int ds_launch_embed_tokens(const int* ids, const half_t* tok_emb, const half_t* pos_emb, half_t* out, int B, int T,
                            int D, int vocab, hipStream_t stream);

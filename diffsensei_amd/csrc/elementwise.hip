@@ -319,6 +319,31 @@ __global__ void embed_tokens_kernel(const int* ids, const half_t* tok_emb, const
     *reinterpret_cast<h8*>(out + bt * D + c * 8) = o;
 }
 
+// VaeImageProcessor.postprocess(output_type="pil") tail (reference src/pipelines/pipeline_diffsensei.py:367 ->
+// pt_to_numpy + numpy_to_pil [3P]): [B,3,H,W] fp32 in [0,1] -> [B,H,W,3] uint8 = (x * 255).round() (numpy rounds half
+// to even = v_rndne_f32).  One thread per 4 pixels: 3 x 16-byte plane reads, one 12-byte interleaved store.
+__global__ __launch_bounds__(256) void image_to_u8_kernel(const float* __restrict__ img, uint8_t* __restrict__ out, int B,
+                                                          long plane) {
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;  // group of 4 pixels
+    const long groups = plane / 4;
+    const int b = blockIdx.y;
+    if (q >= groups) return;
+    const float* ip = img + (long)b * 3 * plane + q * 4;
+    const float4 r = *reinterpret_cast<const float4*>(ip);
+    const float4 g = *reinterpret_cast<const float4*>(ip + plane);
+    const float4 bl = *reinterpret_cast<const float4*>(ip + 2 * plane);
+    auto cv = [](float v) -> unsigned {
+        return (unsigned)__builtin_rintf(fminf(fmaxf(v * 255.0f, 0.f), 255.f));
+    };
+    const unsigned px[12] = {cv(r.x), cv(g.x), cv(bl.x), cv(r.y), cv(g.y), cv(bl.y),
+                             cv(r.z), cv(g.z), cv(bl.z), cv(r.w), cv(g.w), cv(bl.w)};
+    uint3 w;
+    w.x = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
+    w.y = px[4] | (px[5] << 8) | (px[6] << 16) | (px[7] << 24);
+    w.z = px[8] | (px[9] << 8) | (px[10] << 16) | (px[11] << 24);
+    *reinterpret_cast<uint3*>(out + ((long)b * plane + q * 4) * 3) = w;
+}
+
 }  // namespace
 
 int ds_launch_embed_tokens(const int* ids, const half_t* tok_emb, const half_t* pos_emb, half_t* out, int B, int T,
@@ -432,6 +457,15 @@ int ds_launch_pad_rows(const half_t* x, half_t* y, int B, int rows_in, int rows_
     const long total = (long)B * rows_out * (C / 8);
     hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x, y, B, rows_in,
                        rows_out, row_off, total_rows, C);
+    DS_LAUNCH_CHECK();
+    return 0;
+}
+
+int ds_launch_image_to_u8(const float* img, uint8_t* out, int B, int H, int W, hipStream_t stream) {
+    const long plane = (long)H * W;
+    DS_REQUIRE(B > 0 && plane > 0 && plane % 4 == 0, "image_to_u8: H*W (%ld) must be a positive multiple of 4", plane);
+    hipLaunchKernelGGL(image_to_u8_kernel, dim3((unsigned)((plane / 4 + 255) / 256), B), dim3(256), 0, stream, img, out, B,
+                       plane);
     DS_LAUNCH_CHECK();
     return 0;
 }

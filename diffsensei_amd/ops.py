@@ -461,3 +461,14 @@ def llm_swiglu(gate_up: Tensor, out: Optional[Tensor] = None) -> Tensor:
         out = torch.empty((M, I2 // 2), dtype=torch.float16, device=gate_up.device)
     check(_lib.load().ds_llm_swiglu_f16(_p(gate_up), _p(out), M, I2 // 2, _stream()), "ds_llm_swiglu_f16")
     return out
+
+
+def image_to_u8(image: Tensor) -> Tensor:
+    """[B,3,H,W] fp32 in [0,1] -> [B,H,W,3] uint8 = (x*255).round() (half to even), the PIL tail of `postprocess`."""
+    _chk(image, dtype=torch.float32)
+    B, Cc, H, W = image.shape
+    if Cc != 3:
+        raise _lib.DiffSenseiHipError("image_to_u8: 3 channels expected")
+    out = torch.empty((B, H, W, 3), dtype=torch.uint8, device=image.device)
+    check(_lib.load().ds_image_f32_to_u8_nhwc(_p(image), _p(out), B, H, W, _stream()), "ds_image_f32_to_u8_nhwc")
+    return out

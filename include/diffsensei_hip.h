@@ -174,6 +174,10 @@ int ds_nhwc_to_nchw_f16(const void* x, void* y, int B, int HW, int C, void* stre
 int ds_nchw_to_nhwc_f16(const void* x, void* y, int B, int HW, int C, void* stream);
 int ds_pad_rows_f16(const void* x, void* y, int B, int rows_in, int rows_out, int row_off, int total_rows, int C,
                     void* stream);
+/* tail of `image_processor.postprocess(image, output_type="pil")` (reference src/pipelines/pipeline_diffsensei.py:367;
+ * diffusers pt_to_numpy + numpy_to_pil [3P]): image fp32 NCHW [B,3,H,W] in [0,1] -> out uint8 NHWC [B,H,W,3] =
+ * (x * 255).round() with numpy's round-half-to-even.  H*W must be a multiple of 4. */
+int ds_image_f32_to_u8_nhwc(const float* image, uint8_t* out, int B, int H, int W, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * MLLM pre-pass: LLaMA greedy decoding with a KV cache.

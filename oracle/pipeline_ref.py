@@ -46,9 +46,11 @@ def sample_loop(unet: UNetOracle, scheduler, latents: torch.Tensor, enc: torch.T
 
 
 def time_cpu_baseline(cfg, sd, height: int = 512, width: int = 512, steps: int = 20, budget_s: float = 25.0,
-                      threads: Optional[int] = None):
+                      threads: Optional[int] = None, keep_state: bool = False, min_steps: int = 1):
     """Time the oracle on a BOUNDED sample of configs[0]: as many of the 20 Euler steps as fit `budget_s`
-    (at least one), extrapolated to the full 20-step panel.  Returns dict(value=panels/s, ...)."""
+    (at least `min_steps`), extrapolated to the full 20-step panel.  Returns dict(value=panels/s, ...).
+    `keep_state`: also return, under "_state", the seeded inputs and the latents after the measured steps, so that the
+    caller can run the product on the SAME inputs and compare (bench.py's `parity` object)."""
     if threads:
         torch.set_num_threads(threads)
     g = torch.Generator().manual_seed(0)
@@ -73,10 +75,15 @@ def time_cpu_baseline(cfg, sd, height: int = 512, width: int = 512, steps: int =
             eps = unet.forward(xin, float(sch.timesteps[i]), enc, text_embeds, time_ids, bbox, H / W, None)
             x = sch.step(cfg_combine(eps, 7.5), i, x)
             done += 1
-            if time.perf_counter() - t0 > budget_s:
+            if done >= min_steps and time.perf_counter() - t0 > budget_s:
                 break
     dt = time.perf_counter() - t0
     per_step = dt / done
-    return {"value": 1.0 / (per_step * steps), "unit": "panels/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{done} of {steps} Euler steps of a {height}x{width} text-only panel (CFG batch 2), fp32 torch "
-                      f"oracle, {dt:.1f} s measured, extrapolated to {steps} steps; VAE decode not included"}
+    out = {"value": 1.0 / (per_step * steps), "unit": "panels/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"{done} of {steps} Euler steps of a {height}x{width} text-only panel (CFG batch 2), fp32 torch "
+                     f"oracle, {dt:.1f} s measured, extrapolated to {steps} steps; VAE decode not included"}
+    if keep_state:
+        out["_state"] = {"enc": enc, "text_embeds": text_embeds, "time_ids": time_ids, "bbox": bbox, "latents0": lat,
+                         "latents": x, "steps_done": done, "steps": steps, "ip_scale": 0.6, "guidance_scale": 7.5,
+                         "height": height, "width": width}
+    return out

@@ -10,7 +10,10 @@ NOT importable here (diffusers absent) and are restated from their published sem
   Downsample2D         conv3x3 stride 2 pad 1 ; Upsample2D: nearest x2 then conv3x3 pad 1
   Timesteps            sinusoid, flip_sin_to_cos=True, freq_shift=0 ; TimestepEmbedding: linear, SiLU, linear
   text_time            add_emb = MLP(cat[text_embeds, sinusoid256(time_ids).flatten])
-Parity of these against diffusers itself is UNPINNED (see oracle/__init__.py).
+Parity of these against diffusers itself is UNPINNED (see oracle/__init__.py).  The block ORDER, channel widths and
+skip pairing come from oracle/unet_topology_ref.py (a channel-flow simulation of the diffusers forward from the plain
+config dict), NOT from the product's `unet_config.build_topology`; tests/test_oracle_unet.py checks that the two agree
+and pins both to public SDXL-base anchors (1680 tensors, 2 567 463 684 parameters, known up-block conv shapes).
 
 `q` is an optional rounding hook (identity = pure fp32; `lambda t: t.half().float()` emulates the
 reference's fp16 storage between ops, which is what the fp16 HIP path is compared against).
@@ -24,6 +27,7 @@ import torch
 import torch.nn.functional as F
 
 from oracle.attention_ref import masked_ip_cross_attention, self_attention
+from oracle.unet_topology_ref import config_dict, unet_program
 
 Tensor = torch.Tensor
 _id = lambda t: t
@@ -59,11 +63,10 @@ def encode_dialog_bbox(sample: Tensor, dialog_bbox: Tensor, embedding: Tensor) -
 
 class UNetOracle:
     def __init__(self, cfg, sd: Dict[str, Tensor], q: Callable = _id):
-        from diffsensei_amd.unet_config import build_topology  # name/shape table only, no arithmetic
-        self.cfg = cfg
+        self.cfg = cfg          # scalar hyper-parameters only (eps, group count, token counts); no topology table
         self.sd = {k: v.detach().float().cpu() for k, v in sd.items()}
         self.q = q
-        self.topo = build_topology(cfg)
+        self.program = unet_program(config_dict(cfg))
         self.ip_scale = 1.0
 
     # ---- leaf ops
@@ -87,39 +90,40 @@ class UNetOracle:
         return self.q(F.layer_norm(x, (c,), self.sd[name + ".weight"], self.sd[name + ".bias"], 1e-5))
 
     # ---- blocks
-    def resnet(self, x, emb_act, r):
+    def resnet(self, x, emb_act, prefix, cin, cout):
         q, sd = self.q, self.sd
-        h = self._gn(x, r.prefix + ".norm1", self.cfg.norm_eps, True)
-        h = self._conv(h, r.prefix + ".conv1")
-        t = self._lin(emb_act, r.prefix + ".time_emb_proj")
+        assert x.shape[1] == cin, (prefix, x.shape, cin)
+        h = self._gn(x, prefix + ".norm1", self.cfg.norm_eps, True)
+        h = self._conv(h, prefix + ".conv1")
+        t = self._lin(emb_act, prefix + ".time_emb_proj")
         h = q(h + t[:, :, None, None])
-        h = self._gn(h, r.prefix + ".norm2", self.cfg.norm_eps, True)
-        h = self._conv(h, r.prefix + ".conv2")
-        if r.has_shortcut:
-            w = sd[r.prefix + ".conv_shortcut.weight"]
-            x = q(F.conv2d(x, w, sd[r.prefix + ".conv_shortcut.bias"]))
+        h = self._gn(h, prefix + ".norm2", self.cfg.norm_eps, True)
+        h = self._conv(h, prefix + ".conv2")
+        if cin != cout:             # diffusers: use_in_shortcut = in_channels != out_channels -> 1x1 conv_shortcut
+            w = sd[prefix + ".conv_shortcut.weight"]
+            x = q(F.conv2d(x, w, sd[prefix + ".conv_shortcut.bias"]))
         return q(x + h)
 
-    def transformer(self, x, enc, a, bbox, aspect_ratio):
+    def transformer(self, x, enc, prefix, depth, heads, bbox, aspect_ratio):
         q, sd, cfg = self.q, self.sd, self.cfg
         b, c, hh, ww = x.shape
         res = x
-        h = self._gn(x, a.prefix + ".norm", 1e-6, False)
+        h = self._gn(x, prefix + ".norm", 1e-6, False)
         h = h.permute(0, 2, 3, 1).reshape(b, hh * ww, c)
-        h = self._lin(h, a.prefix + ".proj_in")
-        for k in range(a.depth):
-            t = f"{a.prefix}.transformer_blocks.{k}"
+        h = self._lin(h, prefix + ".proj_in")
+        for k in range(depth):
+            t = f"{prefix}.transformer_blocks.{k}"
             n = self._ln(h, t + ".norm1")
             o = self_attention(n, sd[t + ".attn1.to_q.weight"], sd[t + ".attn1.to_k.weight"],
                                sd[t + ".attn1.to_v.weight"], sd[t + ".attn1.to_out.0.weight"],
-                               sd[t + ".attn1.to_out.0.bias"], a.heads, q)
+                               sd[t + ".attn1.to_out.0.bias"], heads, q)
             h = q(o + h)
             n = self._ln(h, t + ".norm2")
             o = masked_ip_cross_attention(
                 n, enc, bbox, aspect_ratio,
                 sd[t + ".attn2.to_q.weight"], sd[t + ".attn2.to_k.weight"], sd[t + ".attn2.to_v.weight"],
                 sd[t + ".attn2.processor.to_k_ip.weight"], sd[t + ".attn2.processor.to_v_ip.weight"],
-                sd[t + ".attn2.to_out.0.weight"], sd[t + ".attn2.to_out.0.bias"], a.heads, self.ip_scale,
+                sd[t + ".attn2.to_out.0.weight"], sd[t + ".attn2.to_out.0.bias"], heads, self.ip_scale,
                 cfg.max_num_ips * cfg.num_vision_tokens, cfg.num_vision_tokens, q)
             h = q(o + h)
             n = self._ln(h, t + ".norm3")
@@ -128,7 +132,7 @@ class UNetOracle:
             g = q(hid * q(F.gelu(gate)))
             o = self._lin(g, t + ".ff.net.2")
             h = q(o + h)
-        h = self._lin(h, a.prefix + ".proj_out")
+        h = self._lin(h, prefix + ".proj_out")
         h = h.reshape(b, hh, ww, c).permute(0, 3, 1, 2)
         return q(h + res)
 
@@ -147,7 +151,7 @@ class UNetOracle:
 
     def forward(self, sample: Tensor, timestep, encoder_hidden_states: Tensor, text_embeds: Tensor,
                 time_ids: Tensor, bbox: Tensor, aspect_ratio: float, dialog_bbox: Optional[Tensor] = None) -> Tensor:
-        q, cfg, topo = self.q, self.cfg, self.topo
+        q, cfg = self.q, self.cfg
         sample = q(sample.float())
         enc = q(encoder_hidden_states.float())
         emb = self.embeddings(timestep, text_embeds, time_ids, sample.shape[0])
@@ -155,27 +159,25 @@ class UNetOracle:
         x = self._conv(sample, "conv_in")
         if dialog_bbox is not None:
             x = q(encode_dialog_bbox(x, dialog_bbox.float(), self.sd["dialog_bbox_embedding"]))
-        skips = [x]
-        for blk in topo.down:
-            for j, r in enumerate(blk["resnets"]):
-                x = self.resnet(x, emb_act, r)
-                if blk["attns"]:
-                    x = self.transformer(x, enc, blk["attns"][j], bbox, aspect_ratio)
+        skips = []
+        for st in self.program:      # reference src/models/unet.py:244-332, flattened by oracle/unet_topology_ref.py
+            op = st[0]
+            if op == "push":
                 skips.append(x)
-            if blk["downsample"]:
-                x = self._conv(x, blk["downsample"], stride=2)
-                skips.append(x)
-        x = self.resnet(x, emb_act, topo.mid["resnets"][0])
-        x = self.transformer(x, enc, topo.mid["attns"][0], bbox, aspect_ratio)
-        x = self.resnet(x, emb_act, topo.mid["resnets"][1])
-        for blk in topo.up:
-            for j, r in enumerate(blk["resnets"]):
+            elif op == "pop_cat":
                 x = torch.cat([x, skips.pop()], dim=1)
-                x = self.resnet(x, emb_act, r)
-                if blk["attns"]:
-                    x = self.transformer(x, enc, blk["attns"][j], bbox, aspect_ratio)
-            if blk["upsample"]:
+            elif op == "resnet":
+                x = self.resnet(x, emb_act, st[1], st[2], st[3])
+            elif op == "attn":
+                assert x.shape[1] == st[2], (st, x.shape)
+                x = self.transformer(x, enc, st[1], st[3], st[4], bbox, aspect_ratio)
+            elif op == "downsample":
+                x = self._conv(x, st[1], stride=2)
+            elif op == "upsample":
                 x = F.interpolate(x, scale_factor=2.0, mode="nearest")
-                x = self._conv(x, blk["upsample"])
+                x = self._conv(x, st[1])
+            else:
+                raise ValueError(st)
+        assert not skips
         x = self._gn(x, "conv_norm_out", cfg.norm_eps, True)
         return self._conv(x, "conv_out")

@@ -573,6 +573,18 @@ def test_layout_helpers(hip_lib):
     assert torch.equal(p[:, :80], e[:, 77:]) and p[:, 80:].abs().sum() == 0
 
 
+def test_image_to_u8_bit_exact_vs_numpy(hip_lib):
+    """`numpy_to_pil`'s (images * 255).round().astype("uint8") [3P] on the device, incl. exact .5 ties (half to even)."""
+    ops = _ops(hip_lib)
+    g = torch.Generator().manual_seed(2)
+    img = torch.rand((3, 3, 40, 52), generator=g)
+    img[0, 0, 0, :20] = (torch.arange(20, dtype=torch.float32) + 0.5) / 255.0      # .5 ties
+    img[1, 1, 3, :4] = torch.tensor([0.0, 1.0, 0.5, 0.25])
+    ref = (img.permute(0, 2, 3, 1).numpy() * 255).round().astype("uint8")
+    got = ops.image_to_u8(img.to(DEV)).cpu().numpy()
+    assert got.shape == ref.shape and (got == ref).all()
+
+
 def test_error_reporting(hip_lib):
     from diffsensei_amd import _lib
     ops = _ops(hip_lib)

@@ -13,7 +13,10 @@ def test_param_inventory_matches_diffusers_decoder_layout():
     assert "decoder.up_blocks.3.upsamplers.0.conv.weight" not in sh and "decoder.up_blocks.2.upsamplers.0.conv.weight" in sh
     assert sh["decoder.mid_block.attentions.0.to_out.0.weight"] == (512, 512)
     n = sum(int(torch.tensor(s).prod()) for s in sh.values())
-    assert 49_000_000 < n < 50_000_000  # the SDXL VAE decoder (+ post_quant_conv) has 49.5 M parameters
+    # public anchor: the SD/SDXL AutoencoderKL has 83 653 863 parameters = encoder 34 163 592 + decoder 49 490 179 +
+    # quant_conv 72 + post_quant_conv 20; this inventory is the decoder + post_quant_conv
+    dec = sum(int(torch.tensor(s).prod()) for k, s in sh.items() if k.startswith("decoder."))
+    assert dec == 49_490_179 and n == 49_490_179 + 20 and 34_163_592 + dec + 72 + 20 == 83_653_863
 
 
 def test_oracle_decode_structure():
