@@ -43,9 +43,9 @@ def _black_image():
 class DiffSenseiPipeline:
     def __init__(self, vae, text_encoder, text_encoder_2, tokenizer, tokenizer_2, scheduler, unet: UNetMangaModel,
                  image_encoder, feature_extractor=None, force_zeros_for_empty_prompt: bool = True):
+        self.scheduler, self.unet = scheduler, unet          # first: the engine conversions below read unet.device
         self.vae = self._as_vae_engine(vae)
         self.tokenizer, self.tokenizer_2 = tokenizer, tokenizer_2
-        self.scheduler, self.unet = scheduler, unet
         self.text_encoder = self._as_text_engine(text_encoder)
         self.text_encoder_2 = self._as_text_engine(text_encoder_2)
         self.image_encoder = self._as_clip_engine(image_encoder)
@@ -67,6 +67,37 @@ class DiffSenseiPipeline:
         self._stream = None
         self.use_graph = os.environ.get("DIFFSENSEI_GRAPH", "1") != "0"
         self.last_run_info = {}
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, unet: Optional[UNetMangaModel] = None, image_encoder=None,
+                        torch_dtype: Optional[torch.dtype] = torch.float16, device: Optional[Union[str, torch.device]] = None,
+                        **components) -> "DiffSenseiPipeline":
+        """The reference's construction call (scripts/demo/gradio_wo_mllm.py:189-194, gradio.py:232-237; inherited there
+        from diffusers' DiffusionPipeline [3P]): read a diffusers-layout directory - `model_index.json`,
+        `scheduler/scheduler_config.json`, `vae/`, `text_encoder/`, `text_encoder_2/`, `tokenizer/`, `tokenizer_2/`
+        (safetensors or .bin) - without diffusers, and build the HIP engines.  Components passed as keyword arguments
+        (`unet=`, `image_encoder=`, also `vae=`, `scheduler=`, ...) are used as given, exactly like the reference does for
+        its UNetMangaModel and CLIP image encoder; a missing `unet=` is loaded from `unet/`."""
+        if torch_dtype not in (None, torch.float16):
+            raise ValueError("the MI355X engines compute in fp16 (the reference's inference dtype): torch_dtype=torch.float16")
+        if not os.path.isdir(os.fspath(pretrained_model_name_or_path)):
+            raise FileNotFoundError(f"{pretrained_model_name_or_path}: a local checkpoint directory is required "
+                                    f"(there is no hub download in this framework)")
+        from .loading import load_pipeline_components
+        dev = torch.device(device) if device is not None else (unet.device if unet is not None else torch.device("cuda"))
+        names = ("vae", "text_encoder", "text_encoder_2", "tokenizer", "tokenizer_2", "scheduler", "feature_extractor")
+        unknown = set(components) - set(names) - {"force_zeros_for_empty_prompt"}
+        if unknown:
+            raise TypeError(f"from_pretrained: unexpected components {sorted(unknown)}")
+        have = {n: components.get(n) for n in names}
+        have.update(unet=unet, image_encoder=image_encoder)
+        if "force_zeros_for_empty_prompt" in components:
+            have["force_zeros_for_empty_prompt"] = components["force_zeros_for_empty_prompt"]
+        c = load_pipeline_components(pretrained_model_name_or_path, dev, have)
+        return cls(vae=c["vae"], text_encoder=c["text_encoder"], text_encoder_2=c["text_encoder_2"], tokenizer=c["tokenizer"],
+                   tokenizer_2=c["tokenizer_2"], scheduler=c["scheduler"], unet=c["unet"], image_encoder=c["image_encoder"],
+                   feature_extractor=c.get("feature_extractor"),
+                   force_zeros_for_empty_prompt=c["force_zeros_for_empty_prompt"])
 
     # ---- plumbing
     @property
