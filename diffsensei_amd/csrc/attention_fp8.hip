@@ -1,0 +1,258 @@
+// FP8 (OCP e4m3) flash self-attention for gfx950 - BASELINE.json configs[4] ("CDNA4 fp8 MFMA attention" at 2048 x 2048),
+// an opt-in variant of self_attn_kernel (attention.hip), i.e. of F.scaled_dot_product_attention at reference
+// src/models/attention_processor.py:76-78.  The reference computes this in fp16; this variant trades precision for
+// matrix-core rate and states its tolerance (tests/test_gpu_attention_fp8.py: relative L2 <= 5e-2 vs fp32 SDPA).
+//
+// Why the MX instruction: gfx950's plain fp8 MFMAs (32x32x16 / 16x16x32) run at the bf16 rate; only
+// v_mfma_f32_32x32x64_f8f6f4 (the block-scaled form, here with the scale operands left at 2^0) contracts K = 64 per issue,
+// twice the f16 rate.  Head dim 64 = exactly one instruction per 32 x 32 block of scores, and a 64-key tile = one
+// instruction per 32 x 32 block of O^T.
+//
+// Data flow
+//   quantize_fp8_kernel   K [B,N,C] f16 -> e4m3 bytes (row-major), V^T [B,heads,64,N] f16 -> e4m3 bytes with the keys of
+//                         every 64-key tile PERMUTED into the order the P operand comes out of the score MFMA (below), once
+//                         per attention call (each K / V byte is then read by N/128 query blocks).
+//   self_attn_fp8_kernel  wave = 2 x 32 query rows (as self_attn_kernel<2>).  Q is scaled by softmax_scale * log2(e) and
+//                         quantized once into registers, so S^T = K Q^T is already the base-2 logit.
+//                         S^T: A = K fragment: lane (key = l&31, half = l>>5) holds K[key][32 half .. +31] (32 bytes),
+//                              B = Q fragment: lane (q = l&31, half) holds Q[q][32 half .. +31];
+//                              D: lane holds column q = l&31, rows key = (r&3) + 8 (r>>2) + 4 half for r < 16 (x2 key blocks).
+//                         P = 2^(s - m + 8): the running maximum keeps s - m <= 0, the +8 lifts the probabilities into
+//                              e4m3's normal range (<= 256 < 448; the smallest subnormal then stands for 2^-17 of the row
+//                              maximum instead of 2^-9); numerator and denominator carry the same factor, so it cancels.
+//                         O^T += V^T P^T: B = P fragment: the lane's 32 scores in register order, i.e. contraction index
+//                              kidx = 32 half + 16 kb + r  <->  key = 32 kb + (r&3) + 8 (r>>2) + 4 half;
+//                              A = V^T fragment: lane (d = l&31, half) holds V^T[d][kidx 32 half .. +31] - contiguous
+//                              32 bytes because quantize_fp8_kernel stored the tile's keys in kidx order.
+//   LDS: K and V^T tiles are 64 rows x 64 bytes; the four 16-byte chunks of a row are XOR-swizzled with (row >> 2) & 3 so
+//   the 16 lanes of a ds_read_b128 group hit 16 different bank quads.  Two buffers, 16 KiB.
+#include "ds_common.h"
+#include "ds_kernels.h"
+
+namespace {
+
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v2i __attribute__((ext_vector_type(2)));
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float NEG_BIG = -1.0e30f;
+constexpr float P_SHIFT = 8.0f;       // probabilities are carried as 2^8 * p
+constexpr float E4M3_MAX = 448.0f;
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float sat(float v) { return fminf(fmaxf(v, -E4M3_MAX), E4M3_MAX); }
+
+// 4 floats -> 4 e4m3 bytes in one dword (byte i = value i)
+__device__ __forceinline__ int pack4_fp8(float a, float b, float c, float d) {
+    int w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+    return w;
+}
+
+// position of key `k` (0..63 within its tile) in the permuted V^T tile: kidx = 32 half + 16 kb + r
+__device__ __forceinline__ int kidx_of_key(int k) {
+    const int kb = k >> 5, g = (k >> 3) & 3, half = (k >> 2) & 1, e = k & 3;
+    return half * 32 + kb * 16 + g * 4 + e;
+}
+
+// x: [rows, cols] f16 with row stride ldx and batch stride sx (elements); out: [batch, rows, cols] bytes, dense.
+// permute: the 64-column groups are stored in kidx order (V^T).  One thread = 8 consecutive columns.
+__global__ __launch_bounds__(256) void quantize_fp8_kernel(const half_t* __restrict__ x, long ldx, long sx,
+                                                           unsigned char* __restrict__ out, int rows, int cols,
+                                                           float scale, int permute) {
+    const long chunks_per_row = cols / 8;
+    const long id = (long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= (long)rows * chunks_per_row) return;
+    const int b = blockIdx.y;
+    const long row = id / chunks_per_row;
+    const int c0 = (int)(id - row * chunks_per_row) * 8;
+    const h8 v = *reinterpret_cast<const h8*>(x + (long)b * sx + row * ldx + c0);
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = sat((float)v[e] * scale);
+    const int lo = pack4_fp8(f[0], f[1], f[2], f[3]), hi = pack4_fp8(f[4], f[5], f[6], f[7]);
+    unsigned char* o = out + ((long)b * rows + row) * cols;
+    if (permute) {
+        const int tile0 = c0 & ~63;
+        *reinterpret_cast<int*>(o + tile0 + kidx_of_key(c0 & 63)) = lo;        // keys c0 .. c0+3   (half 0)
+        *reinterpret_cast<int*>(o + tile0 + kidx_of_key((c0 & 63) + 4)) = hi;  // keys c0+4 .. c0+7 (half 1)
+    } else {
+        v2i w = {lo, hi};
+        *reinterpret_cast<v2i*>(o + c0) = w;
+    }
+}
+
+__device__ __forceinline__ int swz8(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+
+// grid = (ceil(Nq / 256), B * heads), 256 threads = 4 waves x 64 query rows.  k8: [B, Nk, heads*64] bytes; vt8:
+// [B*heads, 64, Nk] bytes in kidx order per 64-key tile; Nk % 64 == 0.
+__global__ __launch_bounds__(256, 2) void self_attn_fp8_kernel(const SelfAttnParams p, const unsigned char* __restrict__ k8,
+                                                               const unsigned char* __restrict__ vt8) {
+    constexpr int QB = 2;
+    __shared__ __attribute__((aligned(16))) char sK[2][64 * 64];
+    __shared__ __attribute__((aligned(16))) char sV[2][64 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int b = blockIdx.y / p.heads, h = blockIdx.y % p.heads;
+    const int C = p.heads * 64;
+    const int q0 = blockIdx.x * 256 + wave * 64;
+    const float c = p.scale * LOG2E;
+
+    // Q fragments: lane holds Q[q][32 lhi .. +31], pre-multiplied by scale * log2(e), as e4m3
+    v8i qf[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const int qrow = min(q0 + qb * 32 + l31, p.Nq - 1);
+        const half_t* qp = p.q + (long)b * p.sq + (long)qrow * p.ldq + h * 64 + lhi * 32;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const h8 v = *reinterpret_cast<const h8*>(qp + j * 8);
+            qf[qb][2 * j] = pack4_fp8(sat((float)v[0] * c), sat((float)v[1] * c), sat((float)v[2] * c), sat((float)v[3] * c));
+            qf[qb][2 * j + 1] = pack4_fp8(sat((float)v[4] * c), sat((float)v[5] * c), sat((float)v[6] * c), sat((float)v[7] * c));
+        }
+    }
+
+    const unsigned char* kbase = k8 + (long)b * p.Nk * C + h * 64;
+    const unsigned char* vbase = vt8 + (long)(b * p.heads + h) * 64 * p.Nk;
+    const int trow = tid >> 2, tch = tid & 3;  // tile loader: row (key for K, d for V^T), 16-byte chunk
+    v4i rk, rv;
+    auto load_tile = [&](int t) {
+        rk = *reinterpret_cast<const v4i*>(kbase + (long)(t * 64 + trow) * C + tch * 16);
+        rv = *reinterpret_cast<const v4i*>(vbase + (long)trow * p.Nk + t * 64 + tch * 16);
+    };
+    auto store_tile = [&](int buf) {
+        *reinterpret_cast<v4i*>(&sK[buf][swz8(trow, tch)]) = rk;
+        *reinterpret_cast<v4i*>(&sV[buf][swz8(trow, tch)]) = rv;
+    };
+    auto frag = [&](const char* tile, int row) -> v8i {  // the lane's 32 bytes: chunks 2 lhi, 2 lhi + 1 of `row`
+        const v4i a = *reinterpret_cast<const v4i*>(tile + swz8(row, 2 * lhi));
+        const v4i d = *reinterpret_cast<const v4i*>(tile + swz8(row, 2 * lhi + 1));
+        v8i o = {a[0], a[1], a[2], a[3], d[0], d[1], d[2], d[3]};
+        return o;
+    };
+
+    f32x16 ot[QB][2];
+    float m_run[QB], l_part[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        m_run[qb] = NEG_BIG;
+        l_part[qb] = 0.f;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ot[qb][d][r] = 0.f;
+    }
+
+    const int nt = p.Nk / 64;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nt) load_tile(t + 1);
+        // ---- S^T = K Q^T, already in base-2 logits: one MFMA per 32-key block and query block
+        f32x16 st[QB][2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const v8i kf = frag(sK[buf], kb * 32 + l31);
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                f32x16 z;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                st[qb][kb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kf, qf[qb], z, 0, 0, 0, 0, 0, 0);
+            }
+        }
+        // ---- online softmax (lane-local rows, one exchange with lane ^ 32), P = 2^(s - m + 8) as e4m3
+        v8i pf[QB];
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            float mloc = NEG_BIG;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, st[qb][kb][r]);
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+            const float m_new = fmaxf(m_run[qb], mloc);
+            const float alpha = fast_exp2(m_run[qb] - m_new);
+            const bool moved = __builtin_amdgcn_ballot_w64(m_new != m_run[qb]) != 0;  // wave-uniform
+            m_run[qb] = m_new;
+            const float off = P_SHIFT - m_new;
+            f32x2 psum2 = {0.f, 0.f};
+            const f32x2 off2 = {off, off};
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; r += 4) {
+                    f32x2 v0 = {st[qb][kb][r], st[qb][kb][r + 1]}, v1 = {st[qb][kb][r + 2], st[qb][kb][r + 3]};
+                    v0 += off2;
+                    v1 += off2;
+                    const f32x2 e0 = {fast_exp2(v0[0]), fast_exp2(v0[1])}, e1 = {fast_exp2(v1[0]), fast_exp2(v1[1])};
+                    psum2 += e0;
+                    psum2 += e1;
+                    pf[qb][kb * 4 + (r >> 2)] = pack4_fp8(e0[0], e0[1], e1[0], e1[1]);
+                }
+            l_part[qb] = fmaf(l_part[qb], alpha, psum2[0] + psum2[1]);
+            if (moved) {
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int d = 0; d < 2; ++d)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ot[qb][d][r] *= alpha;
+            }
+        }
+        // ---- O^T += V^T P^T: one MFMA per 32-row block of d and query block
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+            const v8i vf = frag(sV[buf], db * 32 + l31);
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb)
+                ot[qb][db] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf, pf[qb], ot[qb][db], 0, 0, 0, 0, 0, 0);
+        }
+        if (t + 1 < nt) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const float l = l_part[qb] + __shfl_xor(l_part[qb], 32, 64);
+        const float inv = 1.0f / l;
+        const int qrow = q0 + qb * 32 + l31;
+        if (qrow < p.Nq) {
+            half_t* op = p.o + (long)b * p.so + (long)qrow * p.ldo + h * 64;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    h4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (half_t)(ot[qb][db][4 * g + e] * inv);
+                    *reinterpret_cast<h4*>(op + db * 32 + 8 * g + 4 * lhi) = o;
+                }
+        }
+    }
+}
+
+}  // namespace
+
+int ds_launch_quantize_fp8(const half_t* x, long ldx, long sx, unsigned char* out, int batch, int rows, int cols,
+                           float scale, int permute64, hipStream_t stream) {
+    DS_REQUIRE(batch > 0 && rows > 0 && cols > 0 && cols % 8 == 0 && ldx % 8 == 0 && sx % 8 == 0,
+               "quantize_fp8: cols (%d) / ldx / batch stride must be multiples of 8", cols);
+    DS_REQUIRE(!permute64 || cols % 64 == 0, "quantize_fp8: the V^T key permutation needs cols (%d) %% 64 == 0", cols);
+    const long chunks = (long)rows * (cols / 8);
+    hipLaunchKernelGGL(quantize_fp8_kernel, dim3((unsigned)((chunks + 255) / 256), batch), dim3(256), 0, stream, x, ldx, sx,
+                       out, rows, cols, scale, permute64);
+    DS_LAUNCH_CHECK();
+    return 0;
+}
+
+int ds_launch_self_attn_fp8(const SelfAttnParams& p, const unsigned char* k8, const unsigned char* vt8, hipStream_t stream) {
+    DS_REQUIRE(p.B > 0 && p.heads > 0 && p.Nq > 0 && p.Nk > 0, "self_attn_fp8: empty problem");
+    DS_REQUIRE(p.Nk % 64 == 0, "self_attn_fp8: Nk (%d) must be a multiple of 64 (use the f16 kernel otherwise)", p.Nk);
+    DS_REQUIRE(p.ldq % 8 == 0 && p.ldo % 4 == 0, "self_attn_fp8: ldq/ldo alignment");
+    hipLaunchKernelGGL(self_attn_fp8_kernel, dim3((p.Nq + 255) / 256, p.B * p.heads), dim3(256), 0, stream, p, k8, vt8);
+    DS_LAUNCH_CHECK();
+    return 0;
+}

@@ -67,6 +67,16 @@ int ds_set_option(const char* key, int value) {
         ds_llm_gemv_set_variant(value);
         return 0;
     }
+    if (strcmp(key, "gemm_split_k") == 0) {
+        DS_REQUIRE(value >= 0 && value <= 16, "gemm_split_k must be 0 (auto), 1 (off) or 2..16 k-slices");
+        ds_gemm_pp_set_split(value);
+        return 0;
+    }
+    if (strcmp(key, "gemm_ring") == 0) {
+        DS_REQUIRE(value >= 0 && value <= 1, "gemm_ring must be 0 (auto) or 1 (off)");
+        ds_gemm_set_ring(value);
+        return 0;
+    }
     if (strcmp(key, "gemm_debug") == 0) {
         ds_gemm_set_debug(value);
         return 0;
@@ -552,6 +562,10 @@ int ds_plan_capture(ds_plan* plan, void* stream) {
     if (plan->exec) return 0;
     hipStream_t st = S(stream);
     DS_REQUIRE(st != nullptr, "ds_plan_capture: needs a non-default stream");
+    {   // one-off allocations (split-K workspace) must happen before the capture starts
+        const int prc = ds_gemm_pp_prepare();
+        if (prc != 0) return prc;
+    }
     DS_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
     const int rc = ds_plan_run(plan, stream);
     hipGraph_t g = nullptr;

@@ -33,6 +33,8 @@ int ds_device_info(int* cu_count, int* lds_bytes, char* arch_name, int arch_name
  * large problem sizes; every variant of an operator computes the same result (the tests assert torch.equal between them).
  *   "gemm_variant"       0 auto | 1 register-staged only | 2, 7 two-buffer LDS-DMA | 8, 9 one-buffer LDS-DMA |
  *                        3 256x256 ping-pong (gemm_pp_kernel) | 10 halo-patch conv
+ *   "gemm_split_k"       gemm_pp_kernel's partial last round: 0 auto (cost model) | 1 never split | 2..16 k-slices per tail tile
+ *   "gemm_ring"          0 auto (ring-buffered 64x128 kernel for grids of <= 512 blocks) | 1 never (one-buffer kernel)
  *   "conv_halo_variant"  0 auto (16x16-pixel blocks from 1024 blocks on) | 1 force conv_halo_kernel (8x16 pixels) |
  *                        2 force conv_halo256_kernel (16x16 pixels)
  *   "attn_variant"       0 auto (64 query rows per wave from Nk >= 2048 and >= 512 blocks on) | 1 force
