@@ -41,6 +41,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 MFMA_PEAK_TFLOPS = 2500.0      # dense fp16/bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+FP8_PEAK_TFLOPS = 5000.0       # dense OCP fp8 on the MX-scaled instructions (same guide)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -113,16 +114,18 @@ class SyntheticTokenizer:
         return type("Enc", (), {"input_ids": torch.tensor([ids])})()
 
 
-def synthetic_request(device, size, seed, output_type="pt"):
+def synthetic_request(device, size, seed, output_type="pt", refs=2):
     import numpy as np
     from PIL import Image
     g = torch.Generator().manual_seed(seed)
     rng = np.random.RandomState(seed)
-    imgs = [Image.fromarray(rng.randint(0, 256, (224, 224, 3), dtype=np.uint8)) for _ in range(2)]
+    imgs = [Image.fromarray(rng.randint(0, 256, (224, 224, 3), dtype=np.uint8)) for _ in range(refs)]
+    boxes = [[0.05, 0.10, 0.50, 0.95], [0.50, 0.10, 0.95, 0.95]] if refs <= 2 else \
+        [[0.03, 0.05, 0.48, 0.50], [0.52, 0.05, 0.97, 0.50], [0.03, 0.52, 0.48, 0.97], [0.52, 0.52, 0.97, 0.97]]
     return dict(
         prompt="A young man with a surprised expression holding a baby on his back", height=size, width=size,
         num_inference_steps=50, guidance_scale=7.5, ip_images=imgs,
-        ip_bbox=[[0.05, 0.10, 0.50, 0.95], [0.50, 0.10, 0.95, 0.95]], ip_scale=0.6,
+        ip_bbox=boxes[:refs], ip_scale=0.6,
         dialog_bbox=[[0.05, 0.02, 0.30, 0.15], [0.65, 0.02, 0.95, 0.15]],
         negative_prompt="think lines, pure black background, colored, lowres, bad anatomy, worst quality, low quality",
         generator=torch.Generator().manual_seed(seed), output_type=output_type)
@@ -225,7 +228,11 @@ def main():
     ap.add_argument("--output", choices=("pil", "pt"), default="pil",
                     help="pil: PIL images on the host like the reference's __call__ (default, the metric's region); "
                          "pt: [0,1] fp32 images left on the device (the round-1 region)")
-    ap.add_argument("--refs", type=int, default=2, help="character references in the request (BASELINE config 2: 1)")
+    ap.add_argument("--refs", type=int, default=2, choices=(0, 1, 2, 3, 4),
+                    help="character references in the request (BASELINE config 2: 1, config 5: 4)")
+    ap.add_argument("--attn", choices=("fp16", "fp8"), default="fp16",
+                    help="self-attention arithmetic: fp16 (the reference's; the metric line) or fp8 = OCP e4m3 on the MX matrix "
+                         "instruction (BASELINE config 5: --size 2048 --refs 4 --attn fp8 --num-samples 1)")
     ap.add_argument("--no-dialog", action="store_true", help="no dialog boxes (BASELINE config 2)")
     ap.add_argument("--no-parity", action="store_true", help="skip the GPU-vs-oracle parity run on BASELINE configs[0]")
     ap.add_argument("--mllm", action="store_true",
@@ -252,11 +259,11 @@ def main():
     pipe, setup = build_pipeline(device, world, rank, with_vae=not args.no_vae, agent=agent)
     ns = args.num_samples
     out_type = "latent" if args.no_vae else args.output
-    req = synthetic_request(device, args.size, seed=1234 + rank, output_type=out_type)
-    if args.refs != 2 or args.no_dialog:
-        req["ip_images"], req["ip_bbox"] = req["ip_images"][:args.refs], req["ip_bbox"][:args.refs]
-        if args.no_dialog:
-            req["dialog_bbox"] = []
+    req = synthetic_request(device, args.size, seed=1234 + rank, output_type=out_type, refs=args.refs)
+    if args.no_dialog:
+        req["dialog_bbox"] = []
+    if args.attn != "fp16":
+        pipe.unet.attention_dtype = args.attn
 
     def one_step():
         r = req
@@ -303,8 +310,9 @@ def main():
         dom = max(table.items(), key=lambda kv: kv[1]["ms"])
         name, d = dom
         ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None, "kernel": name,
+        peak = FP8_PEAK_TFLOPS if "fp8" in name else MFMA_PEAK_TFLOPS
+        roofline = {"bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(ach / peak, 4), "traffic": None, "kernel": name,
                     "launches_per_forward": d["launches"], "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 2),
                     "algorithmic_tflop_per_forward": round(d["flops"] / 1e12, 3)}
         # HBM-side traffic comes from separate rocprofv3 --pmc passes (tools/gpu_pmc_pp.sh), committed under profiles/:
@@ -351,7 +359,7 @@ def main():
             "config": {"workload": f"{args.size}x{args.size}, 50-step Euler, CFG 7.5, {args.refs} character refs (padded to 4) + "
                                    f"{0 if args.no_dialog else 2} dialog boxes, num_samples={ns} per call (UNet batch {2 * ns}), "
                                    f"one call per step",
-                       "output": out_type,
+                       "output": out_type, "self_attention": args.attn,
                        "timed_region": "2 SDXL text encoders (prompt + negative prompt), CLIP-H + ViT-MAE + Resampler "
                                        "character encoding, 50 x (UNet + CFG + scheduler step)" +
                                        ("; VAE decode excluded (output: latents)" if args.no_vae else

@@ -67,16 +67,6 @@ int ds_set_option(const char* key, int value) {
         ds_llm_gemv_set_variant(value);
         return 0;
     }
-    if (strcmp(key, "gemm_split_k") == 0) {
-        DS_REQUIRE(value >= 0 && value <= 16, "gemm_split_k must be 0 (auto), 1 (off) or 2..16 k-slices");
-        ds_gemm_pp_set_split(value);
-        return 0;
-    }
-    if (strcmp(key, "gemm_ring") == 0) {
-        DS_REQUIRE(value >= 0 && value <= 1, "gemm_ring must be 0 (auto) or 1 (off)");
-        ds_gemm_set_ring(value);
-        return 0;
-    }
     if (strcmp(key, "gemm_debug") == 0) {
         ds_gemm_set_debug(value);
         return 0;
@@ -195,6 +185,21 @@ int ds_self_attn_f16(const void* q, int64_t ldq, int64_t sq, const void* k, int6
     p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.sq = sq; p.sk = sk; p.so = so;
     p.B = B; p.heads = heads; p.Nq = Nq; p.Nk = Nk; p.scale = scale;
     return ds_launch_self_attn(p, S(stream));
+}
+
+int ds_quantize_fp8_e4m3_f16(const void* x, int64_t ldx, int64_t sx, void* out, int batch, int rows, int cols, float scale,
+                             int permute64, void* stream) {
+    return ds_launch_quantize_fp8(H(x), ldx, sx, reinterpret_cast<unsigned char*>(out), batch, rows, cols, scale, permute64,
+                                  S(stream));
+}
+
+int ds_self_attn_fp8_f16(const void* q, int64_t ldq, int64_t sq, const void* k8, const void* vt8, void* o, int64_t ldo,
+                         int64_t so, int B, int heads, int Nq, int Nk, float scale, void* stream) {
+    SelfAttnParams p;
+    p.q = H(q); p.o = HM(o); p.ldq = ldq; p.ldo = ldo; p.sq = sq; p.so = so;
+    p.B = B; p.heads = heads; p.Nq = Nq; p.Nk = Nk; p.scale = scale;
+    return ds_launch_self_attn_fp8(p, reinterpret_cast<const unsigned char*>(k8), reinterpret_cast<const unsigned char*>(vt8),
+                                   S(stream));
 }
 
 int ds_masked_ip_attn_f16(const void* q, int64_t ldq, const void* kt, const void* vtt, const void* ki,
@@ -451,6 +456,16 @@ static int run_op(const ds_op& o, hipStream_t st) {
                                         reinterpret_cast<int*>(p[2]), reinterpret_cast<int*>(p[3]), st);
         case DS_OP_LLM_ADVANCE:
             return ds_launch_llm_advance(reinterpret_cast<int*>(p[0]), i[0], st);
+        case DS_OP_QUANT_FP8:
+            return ds_launch_quantize_fp8(H(p[0]), l[0], l[1], reinterpret_cast<unsigned char*>(p[1]), i[0], i[1], i[2], o.f[0],
+                                          i[3], st);
+        case DS_OP_SELF_ATTN_FP8: {
+            SelfAttnParams a;
+            a.q = H(p[0]); a.o = HM(p[3]); a.ldq = l[0]; a.ldo = l[1]; a.sq = l[2]; a.so = l[3];
+            a.B = i[0]; a.heads = i[1]; a.Nq = i[2]; a.Nk = i[3]; a.scale = o.f[0];
+            return ds_launch_self_attn_fp8(a, reinterpret_cast<const unsigned char*>(p[1]),
+                                           reinterpret_cast<const unsigned char*>(p[2]), st);
+        }
         default:
             ds_set_error("plan: unknown opcode %d", o.code);
             return -4;
@@ -493,6 +508,12 @@ int ds_op_describe(const ds_op* op, char* name, int name_len, double* flops, dou
             fl = 4.0 * i[0] * (double)i[1] * i[2] * (double)i[3] * 64;
             by = 2.0 * i[0] * (double)i[1] * 64 * (2.0 * i[2] + 2.0 * i[3]);
             break;
+        case DS_OP_SELF_ATTN_FP8:
+            nm = "self_attn_fp8_kernel";
+            fl = 4.0 * i[0] * (double)i[1] * i[2] * (double)i[3] * 64;
+            by = 1.0 * i[0] * (double)i[1] * 64 * (4.0 * i[2] + 2.0 * i[3]);   // q, o f16; k8, vt8 bytes
+            break;
+        case DS_OP_QUANT_FP8: nm = "quantize_fp8_kernel"; by = 3.0 * i[0] * (double)i[1] * i[2]; break;
         case DS_OP_IP_ATTN:
             nm = "ip_attn_kernel";
             fl = 4.0 * i[0] * (double)i[1] * i[2] * (double)(i[3] + i[4]) * 64;
@@ -562,10 +583,6 @@ int ds_plan_capture(ds_plan* plan, void* stream) {
     if (plan->exec) return 0;
     hipStream_t st = S(stream);
     DS_REQUIRE(st != nullptr, "ds_plan_capture: needs a non-default stream");
-    {   // one-off allocations (split-K workspace) must happen before the capture starts
-        const int prc = ds_gemm_pp_prepare();
-        if (prc != 0) return prc;
-    }
     DS_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
     const int rc = ds_plan_run(plan, stream);
     hipGraph_t g = nullptr;

@@ -22,11 +22,6 @@ struct GemmParams {
     int tiles_m = 0, tiles_n = 0;
     int dtype = DS_DTYPE_F16;  // element type of A / W / C / bias / residual (the pointers are 2-byte opaque): bf16 = VAE path
     int debug = 0;  // ablation only (ds_set_option "gemm_debug"): 1 skip MFMA, 2 skip tile loads — results are garbage
-    // gemm_pp_kernel only: tiles [0, pp_full) are computed whole; each of the pp_tail tiles after them (the partial last
-    // round of the persistent grid) is cut into pp_split k-slices whose fp32 partial sums meet in pp_ws (see gemm_pp.hip)
-    int pp_full = 0, pp_tail = 0, pp_split = 1;
-    float* pp_ws = nullptr;
-    int* pp_ctr = nullptr;
 };
 int ds_launch_gemm(const GemmParams& p, int batch, hipStream_t stream);
 bool ds_gemm_pp_applicable(const GemmParams& p);  // gemm_pp.hip: 256 x 256 ping-pong kernel takes this shape
@@ -36,9 +31,6 @@ int ds_launch_conv_halo(const GemmParams& p, hipStream_t stream);
 void ds_conv_halo_set_variant(int v);  // 0 auto, 1 8x16-pixel blocks, 2 16x16-pixel blocks
 const char* ds_gemm_kernel_name(const GemmParams& p, int batch);  // the instantiation ds_launch_gemm dispatches to
 void ds_gemm_set_debug(int v);
-void ds_gemm_set_ring(int v);
-void ds_gemm_pp_set_split(int v);   // 0 auto, 1 never split the tail round, n >= 2 force n k-slices
-int ds_gemm_pp_prepare(void);        // allocates the split-K workspace (call outside stream capture)
 void ds_gemm_set_variant(int v);  // 0 auto, 1 register staging only, 2 glds (BM <= 128), 3 glds, BM = 256 when large
 
 // ---- VAE decoder only (vae.hip) ---------------------------------------------------------------------
@@ -79,6 +71,10 @@ struct SelfAttnParams {
     float scale = 0.125f;
 };
 int ds_launch_self_attn(const SelfAttnParams& p, hipStream_t stream);
+// attention_fp8.hip: e4m3 variant (k / vt of the params are unused; the quantized operands are passed separately)
+int ds_launch_quantize_fp8(const half_t* x, long ldx, long sx, unsigned char* out, int batch, int rows, int cols,
+                           float scale, int permute64, hipStream_t stream);
+int ds_launch_self_attn_fp8(const SelfAttnParams& p, const unsigned char* k8, const unsigned char* vt8, hipStream_t stream);
 void ds_attn_set_variant(int v);  // 0 auto, 1 force 32 query rows per wave
 void ds_ip_attn_set_min_blocks(int v);
 

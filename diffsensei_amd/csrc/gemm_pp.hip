@@ -28,15 +28,6 @@
 //     tile's first k-tiles are issued before the epilogue of the current one, so the pipeline fill hides under the
 //     C stores.
 //
-// Tail round (split-K).  One block per CU means a tile count that is not a multiple of the grid leaves CUs idle in the
-// last round (M = 32768 x N = 1280 = 640 tiles = 2.5 rounds: 17 % of the kernel), and a small problem (num_samples 4:
-// 160 tiles) never fills the chip.  The R tiles of the partial round are therefore cut into S k-slices each (S from the
-// launcher, every slice >= 2 k-tiles): unit u -> tile full + u % R, slice u / R, walked by the same persistent loop.  A
-// slice dumps its accumulators raw (register order: [unit][wave][reg/4][lane] float4, 256 KiB per unit, coalesced),
-// fences, and takes a ticket per (tile, wave); the wave that draws the last ticket adds the S partials IN SLICE ORDER
-// (so the result does not depend on arrival order), resets the counter and runs the normal epilogue.  Everything is
-// per wave - the epilogue has no block barrier - so no block-level synchronisation is added.
-//
 // Column ownership is chosen for the epilogue (the B half-tiles are just a permutation of the 256 tile columns):
 //   plain  half h, LDS row r -> tile column (r>>5)*64 + h*32 + (r&31): a wave ends up with 64 adjacent columns, i.e.
 //          whole 128-byte lines of C per row;
@@ -87,7 +78,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     const int nk = p.K / 64;
     const int l31 = lane & 31, lhi = lane >> 5;
     const bool geglu = p.epi == EPI_GEGLU;
-    const int nunits = p.pp_full + p.pp_tail * p.pp_split;  // whole tiles, then the k-slices of the tail tiles
+    const int ntiles = p.tiles_m * p.tiles_n;
 
     // ---- persistent tile walk: round-major, then one contiguous chunk of the logical order per XCD (block b runs on
     // XCD b % 8), so the tiles an XCD has in flight share A / W panels in its L2
@@ -111,23 +102,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     const half_t* gA[2];
     const half_t* gB[2];
     int krot = 0;
-    int kb = 0, kl = nk;      // first k-tile and number of k-tiles of the current unit
-    int u_tail = -1, u_slice = 0;  // tail-tile index / slice of the current unit (-1: a whole tile)
     auto set_tile = [&](int id, int& m0, int& n0) {
         krot = (id & 31) % nk;
         int tm, tn;
-        if (id >= p.pp_full) {
-            const int u = id - p.pp_full;
-            u_slice = u / p.pp_tail;
-            u_tail = u - u_slice * p.pp_tail;
-            id = p.pp_full + u_tail;
-            kb = u_slice * nk / p.pp_split;
-            kl = (u_slice + 1) * nk / p.pp_split - kb;
-        } else {
-            u_tail = -1;
-            kb = 0;
-            kl = nk;
-        }
         tile_coords(id, p.tiles_m, p.tiles_n, tm, tn);
         if constexpr ((DBG & 32) != 0) tm = tn = 0;  // ablation: every block works on tile (0,0): all operand loads hit L2
         m0 = tm * 256;
@@ -150,7 +127,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
             kp = kt + krot;
             kp -= kp >= nk ? nk : 0;
         }
-        const char* s = reinterpret_cast<const char*>((op == 0 ? gA[half] : gB[half]) + (kb + kp) * 64);
+        const char* s = reinterpret_cast<const char*>((op == 0 ? gA[half] : gB[half]) + kp * 64);
         const unsigned o0 = op == 0 ? oA[0] : oB[0], o1 = op == 0 ? oA[1] : oB[1];
         if constexpr ((DBG & 2) != 0) return;
         __builtin_amdgcn_global_load_lds((glb_void*)(s + (size_t)o0), (lds_void*)d, 16, 0, 0);
@@ -161,9 +138,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
         stage(1, 0, 0, 0);
         stage(1, 1, 0, 0);
         stage(0, 1, 0, 0);
-        stage(1, 0, 1, 1);  // every unit has >= 2 k-tiles
-        stage(0, 0, 1, 1);
-        stage(1, 1, 1, 1);
+        if (nk > 1) {
+            stage(1, 0, 1, 1);
+            stage(0, 0, 1, 1);
+            stage(1, 1, 1, 1);
+        }
     };
 
     // ---- fragment addresses: row r of a half-tile at r*128, 16-byte chunk c at ((c ^ ((r>>1)&7)) << 4)
@@ -207,7 +186,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     auto ktile = [&](auto bufc, int kt) {
         constexpr int B = decltype(bufc)::value;
         constexpr bool n1 = true, n2 = true;
-        const int kt1 = min(kt + 1, kl - 1), kt2 = min(kt + 2, kl - 1);
+        const int kt1 = min(kt + 1, nk - 1), kt2 = min(kt + 2, nk - 1);
         V8 bl[4], br[4], a0[4][2], a1[4][2];
         // ---------------- P1: B0 strip (first: retired before the barrier, see WAR above) + A0 rows
 #pragma unroll
@@ -293,7 +272,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     char* const ep = smem + 8 * HT + wave * 4096;  // wave-private transposition tile
 
     int id = tile_local;
-    if (id >= nunits) return;
+    if (id >= ntiles) return;
     unsigned long long probe_c0 = 0, probe_r0 = 0;
     if constexpr ((DBG & 16) != 0) {  // clock probe: shader cycles vs the constant 100 MHz reference
         probe_c0 = __builtin_readcyclecounter();
@@ -311,72 +290,27 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         // k-tile 0 must have landed; after the first tile the previous epilogue's stores are in the count too
-        if (first) wait_newer(5);  // A0 B0 of k-tile 0: newer = B1 A1 + B0 A0 B1 of k-tile 1
+        if (first) wait_newer(nk > 1 ? 5 : 2);  // A0 B0 of k-tile 0: newer = B1 A1 [+ B0 A0 B1 of k-tile 1]
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         first = false;
         PP_BARRIER();
         if (wr == 1) PP_BARRIER();  // group 1 runs one barrier behind group 0 from here on
-        for (int kt = 0; kt + 1 < kl; kt += 2) {
+        for (int kt = 0; kt < nk; kt += 2) {  // nk is even
             ktile(IC<0>{}, kt);
             ktile(IC<1>{}, kt + 1);
         }
-        if (kl & 1) ktile(IC<0>{}, kl - 1);  // odd slices of a split tail tile (whole tiles have an even count)
         // (the over-fetched stages may still be in flight: a wave only ever writes its own 16 rows of a slot, and its
         // loads return in order, so the next tile's prologue into the same slots lands after them)
         if (wr == 0) PP_BARRIER();  // balance group 1's extra barrier: every ds_read of this tile has retired
 
         // ---- next tile's pipeline fill goes out before this tile's epilogue
         const int cm0 = m0, cn0 = n0;
-        const int c_tail = u_tail, c_slice = u_slice;
         id += G;
-        const bool more = id < nunits;
+        const bool more = id < ntiles;
         if (more) {
             set_tile(id, m0, n0);
             stage_prologue();
         }
-
-        // ---- k-slice of a tail tile: park the partial sums, take a ticket; only the last wave to arrive goes on
-        bool finish = true;
-        if (c_tail >= 0) {
-            typedef __attribute__((ext_vector_type(4))) float f4;
-            const int S = p.pp_split;
-            f4* const wsl = reinterpret_cast<f4*>(p.pp_ws) + ((size_t)(c_tail * S + c_slice) * 8 + wave) * (32 * 64) + lane;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        f4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-                        wsl[((i * 2 + j) * 4 + q) * 64] = v;
-                    }
-            __threadfence();  // release: the partial sums are visible device-wide before the ticket is drawn
-            int ticket = 0;
-            int* const ctr = p.pp_ctr + c_tail * 8 + wave;
-            if (lane == 0) ticket = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-            ticket = __builtin_amdgcn_readfirstlane(ticket);
-            finish = ticket == S - 1;
-            if (finish) {
-                __threadfence();  // acquire
-                const f4* const wst = reinterpret_cast<const f4*>(p.pp_ws) + ((size_t)c_tail * S * 8 + wave) * (32 * 64) + lane;
-                for (int sl = 0; sl < S; ++sl) {  // fixed order: the sum does not depend on which slice arrived last
-                    const f4* const wsr = wst + (size_t)sl * 8 * (32 * 64);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j)
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const f4 v = wsr[((i * 2 + j) * 4 + q) * 64];
-#pragma unroll
-                                for (int e = 0; e < 4; ++e)
-                                    acc[i][j][4 * q + e] = sl == 0 ? v[e] : acc[i][j][4 * q + e] + v[e];
-                            }
-                }
-                if (lane == 0) __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
-            }
-        }
-        if (finish) {
 
         // ---- epilogue.  D layout (operands swapped): lane holds tile row ..+(lane&31); register r of a fragment is
         // column (r&3) + 8*(r>>2) + 4*(lane>>5) of its 32-column strip.
@@ -579,7 +513,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
                 }
             }
         }
-        }  // finish
         if (!more) break;
     }
     if constexpr ((DBG & 16) != 0) {
@@ -593,64 +526,14 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 }
 
 int g_pp_blocks = 0;  // persistent grid size: one block per CU
-int g_pp_split = 0;   // 0 auto, 1 never split, n >= 2 force n k-slices per tail tile (A/B, tests)
-float* g_pp_ws = nullptr;   // split-K partial sums: one 256-KiB register dump per unit, at most one unit per CU and round...
-int* g_pp_ctr = nullptr;    // ...and one ticket counter per (tail tile, wave); both allocated once per process
-constexpr int PP_MAX_UNITS = 1024;  // tail tiles x slices the workspace holds (256 MiB)
 
 }  // namespace
-
-void ds_gemm_pp_set_split(int v) { g_pp_split = v; }
-
-// One-off allocation of the split-K workspace and the kernels' LDS attribute.  hipMalloc is illegal inside a stream
-// capture, so ds_plan_capture calls this first; afterwards launches never allocate.  The workspace is shared by every
-// launch of the process: split GEMMs must not run CONCURRENTLY on two streams (the pipeline is single-stream).
-int ds_gemm_pp_prepare(void) {
-    if (g_pp_blocks != 0) return 0;
-    const size_t lds = 8 * HT + 8 * 4096;
-    DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pp_kernel<half_t, 0>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pp_kernel<bf16_t, 0>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    int dev = 0, cus = 0;
-    DS_HIP(hipGetDevice(&dev));
-    DS_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    DS_HIP(hipMalloc(reinterpret_cast<void**>(&g_pp_ws), (size_t)PP_MAX_UNITS * 65536 * sizeof(float)));
-    DS_HIP(hipMalloc(reinterpret_cast<void**>(&g_pp_ctr), (size_t)PP_MAX_UNITS * 8 * sizeof(int)));
-    DS_HIP(hipMemset(g_pp_ctr, 0, (size_t)PP_MAX_UNITS * 8 * sizeof(int)));
-    DS_HIP(hipDeviceSynchronize());
-    g_pp_blocks = cus > 0 ? cus : 256;
-    return 0;
-}
 
 // Shapes the kernel takes: K a multiple of 128 (an even number of k-tiles), a single A source, M and N multiples of 16 (a wave's 16
 // staged rows are then wholly inside or outside the problem).  ds_launch_gemm decides when it is also the faster choice.
 bool ds_gemm_pp_applicable(const GemmParams& p) {
     return p.conv == 0 && p.A2 == nullptr && p.M % 16 == 0 && p.N % 16 == 0 && p.K % 128 == 0 &&
            (p.epi != EPI_GEGLU || p.N % 128 == 0) && p.lda * 15 + 64 < (1L << 30) && p.ldw * 15 + 64 < (1L << 30);
-}
-
-// k-slices per tail tile.  Cost model in k-tile times (calibrated on MI355X, profiles/r02_gemm_pp_split.txt): a whole
-// tile costs nk + E (E = prologue + epilogue), a slice nk/S + O (pipeline fill + partial dump), the reduction RD per
-// partial read by the finishing wave.  The tail of R tiles takes ceil(R S / G) rounds of slices.
-int ds_gemm_pp_split_for(int tiles, int nk, int grid) {
-    const int R = tiles % grid == 0 ? 0 : tiles % grid;
-    if (R == 0 || g_pp_split == 1) return 1;
-    const int smax = nk / 2 < 16 ? nk / 2 : 16;
-    if (g_pp_split >= 2) return g_pp_split < smax ? g_pp_split : (smax < 1 ? 1 : smax);
-    const float E = 6.f, O = 3.f, RD = 1.5f;
-    float best = (float)nk + E;
-    int bs = 1;
-    for (int S = 2; S <= smax; ++S) {
-        if ((long)R * S > PP_MAX_UNITS) break;
-        const int rounds = (R * S + grid - 1) / grid;
-        const float c = rounds * ((float)nk / S + O) + RD * S + E;
-        if (c < 0.92f * best) {
-            best = c;
-            bs = S;
-        }
-    }
-    return bs;
 }
 
 int ds_launch_gemm_pp(const GemmParams& p0, int batch, hipStream_t stream) {
@@ -672,30 +555,15 @@ int ds_launch_gemm_pp(const GemmParams& p0, int batch, hipStream_t stream) {
 #endif
         {-1, gemm_pp_kernel<bf16_t, 0>}};  // -1: the bf16 build (VAE decoder), no ablation variants
     if (g_pp_blocks == 0) {
-        const int rc = ds_gemm_pp_prepare();
-        if (rc != 0) return rc;
-#ifdef DS_ABLATION
         for (const auto& e : table)
             DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(e.k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-#endif
+        int dev = 0, cus = 0;
+        DS_HIP(hipGetDevice(&dev));
+        DS_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        g_pp_blocks = cus > 0 ? cus : 256;
     }
     const int tiles = p.tiles_m * p.tiles_n;
-    const int G = g_pp_blocks;
-    // the batched form (grid.z) shares one workspace slot per (tile, slice): no split there
-    const int S = batch == 1 ? ds_gemm_pp_split_for(tiles, p.K / 64, G) : 1;
-    if (S > 1) {
-        p.pp_tail = tiles % G;
-        p.pp_full = tiles - p.pp_tail;
-        p.pp_split = S;
-        p.pp_ws = g_pp_ws;
-        p.pp_ctr = g_pp_ctr;
-    } else {
-        p.pp_full = tiles;
-        p.pp_tail = 0;
-        p.pp_split = 1;
-    }
-    const int units = p.pp_full + p.pp_tail * p.pp_split;
-    dim3 grid(units < G ? units : G, 1, batch);
+    dim3 grid(tiles < g_pp_blocks ? tiles : g_pp_blocks, 1, batch);
     kern_t kern = nullptr;
     for (const auto& e : table)
         if (e.dbg == (p.dtype == DS_DTYPE_BF16 ? -1 : (p.debug & 255))) kern = e.k;

@@ -55,6 +55,9 @@ class UNetMangaModel:
         self._engines: Dict[Tuple, UNetEngine] = {}
         self._attn_processors: Dict[str, Any] = {n: AttnProcessor2_0() for n in attn_processor_names(self.config)}
         self._manga = False
+        # "fp16": the reference's arithmetic.  "fp8": self-attention in OCP e4m3 on the 2x-rate MX matrix instruction
+        # (BASELINE.json configs[4]); opt-in, stated tolerance in tests/test_gpu_attention_fp8.py
+        self.attention_dtype = os.environ.get("DIFFSENSEI_ATTENTION", "fp16")
 
     # ---- construction (reference scripts/demo/gradio_wo_mllm.py:161-169)
     @classmethod
@@ -212,10 +215,10 @@ class UNetMangaModel:
     engine_cache_bytes = int(float(os.environ.get("DIFFSENSEI_ENGINE_CACHE_GB", "64")) * (1 << 30))
 
     def engine(self, batch: int, height: int, width: int, aspect_ratio: Optional[float] = None) -> UNetEngine:
-        key = (batch, height, width, None if aspect_ratio is None else round(float(aspect_ratio), 6))
+        key = (batch, height, width, None if aspect_ratio is None else round(float(aspect_ratio), 6), self.attention_dtype)
         eng = self._engines.pop(key, None)
         if eng is None:
-            eng = UNetEngine(self.packed(), batch, height, width, aspect_ratio)
+            eng = UNetEngine(self.packed(), batch, height, width, aspect_ratio, attention=self.attention_dtype)
         self._engines[key] = eng                      # dict order = recency (most recent last)
         total = sum(e.nbytes() for e in self._engines.values())
         for k in list(self._engines):

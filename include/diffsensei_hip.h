@@ -33,8 +33,6 @@ int ds_device_info(int* cu_count, int* lds_bytes, char* arch_name, int arch_name
  * large problem sizes; every variant of an operator computes the same result (the tests assert torch.equal between them).
  *   "gemm_variant"       0 auto | 1 register-staged only | 2, 7 two-buffer LDS-DMA | 8, 9 one-buffer LDS-DMA |
  *                        3 256x256 ping-pong (gemm_pp_kernel) | 10 halo-patch conv
- *   "gemm_split_k"       gemm_pp_kernel's partial last round: 0 auto (cost model) | 1 never split | 2..16 k-slices per tail tile
- *   "gemm_ring"          0 auto (ring-buffered 64x128 kernel for grids of <= 512 blocks) | 1 never (one-buffer kernel)
  *   "conv_halo_variant"  0 auto (16x16-pixel blocks from 1024 blocks on) | 1 force conv_halo_kernel (8x16 pixels) |
  *                        2 force conv_halo256_kernel (16x16 pixels)
  *   "attn_variant"       0 auto (64 query rows per wave from Nk >= 2048 and >= 512 blocks on) | 1 force
@@ -111,6 +109,19 @@ int ds_layernorm_f16(const void* x, void* y, const void* gamma, const void* beta
 int ds_self_attn_f16(const void* q, int64_t ldq, int64_t sq, const void* k, int64_t ldk, int64_t sk, const void* vt,
                      int64_t ldv, void* o, int64_t ldo, int64_t so, int B, int heads, int Nq, int Nk, float scale,
                      void* stream);
+
+/* FP8 (OCP e4m3) variant of the above for BASELINE.json configs[4] ("CDNA4 fp8 MFMA attention"): same SDPA call of
+ * reference src/models/attention_processor.py:76-78, contracted with v_mfma_f32_32x32x64_f8f6f4 (twice the f16 matrix
+ * rate).  Opt-in: it is NOT the reference's fp16 arithmetic; stated tolerance rel-L2 <= 5e-2 vs fp32 SDPA.
+ *   ds_quantize_fp8_e4m3_f16  x [batch][rows, cols] f16 (row stride ldx, batch stride sx, elements) -> out [batch][rows][cols]
+ *                             bytes = e4m3(clamp(x * scale, +-448)); permute64 != 0 stores every 64-column group in the
+ *                             contraction order of the attention kernel (use for V^T, 0 for K).
+ *   ds_self_attn_fp8_f16      q f16 [B,Nq,ldq] (head h at column h*64), k8 [B,Nk,heads*64] bytes, vt8 [B,heads,64,Nk] bytes
+ *                             (permute64), o f16 [B,Nq,ldo]; Nk % 64 == 0. */
+int ds_quantize_fp8_e4m3_f16(const void* x, int64_t ldx, int64_t sx, void* out, int batch, int rows, int cols, float scale,
+                             int permute64, void* stream);
+int ds_self_attn_fp8_f16(const void* q, int64_t ldq, int64_t sq, const void* k8, const void* vt8, void* o, int64_t ldo,
+                         int64_t so, int B, int heads, int Nq, int Nk, float scale, void* stream);
 
 /* Fused text + region-masked IP cross-attention core of MaskedIPAttnProcessor2_0
  * (reference src/models/attention_processor.py:235-258 incl. prepare_attention_mask_ip :115-169):
@@ -272,7 +283,9 @@ enum ds_opcode {
     DS_OP_LLM_RMSNORM = 21,  /* p: x, gamma, y, feat, state l: ldx ldy       i: M H max_out           f: eps */
     DS_OP_LLM_EMBED = 22,    /* p: table, state, out                         i: H vocab */
     DS_OP_LLM_SELECT = 23,   /* p: logits, chain, state, out_ids             i: V n_chain out_cap adv */
-    DS_OP_LLM_ADVANCE = 24   /* p: state                                     i: rows */
+    DS_OP_LLM_ADVANCE = 24,  /* p: state                                     i: rows */
+    DS_OP_QUANT_FP8 = 25,    /* p: x, out                   l: ldx sx        i: batch rows cols permute64   f: scale */
+    DS_OP_SELF_ATTN_FP8 = 26 /* p: q, k8, vt8, o            l: ldq ldo sq so i: B heads Nq Nk               f: scale */
 };
 
 typedef struct ds_op {

@@ -1,0 +1,135 @@
+"""GPU: the FP8 (OCP e4m3) flash self-attention variant (csrc/attention_fp8.hip; BASELINE.json configs[4] "CDNA4 fp8 MFMA
+attention") through the C ABI.
+
+It replaces the same SDPA call as the fp16 kernel (reference src/models/attention_processor.py:76-78) but is NOT the
+reference's fp16 arithmetic, so it is opt-in and carries its own stated tolerance:
+  * quantisation kernel: bit-exact vs torch's float8_e4m3fn cast of the clamped values (round to nearest even), and the
+    V^T key permutation checked index by index;
+  * attention output: relative L2 <= 5e-2 vs fp32 SDPA (3 mantissa bits on Q, K, V and the probabilities), and <= 2e-2 vs
+    a torch emulation that quantises the same four operands (the kernel logic itself, apart from e4m3 noise);
+  * the whole UNet with `attention_dtype="fp8"`: relative L2 <= 5e-2 vs the fp16-storage oracle."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+F8 = torch.float8_e4m3fn
+
+
+def _r(shape, g, scale=1.0):
+    return (torch.randn(shape, generator=g) * scale).half()
+
+
+def _rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-6)).item()
+
+
+def _kidx(k):
+    kb, g, half, e = k >> 5, (k >> 3) & 3, (k >> 2) & 1, k & 3
+    return half * 32 + kb * 16 + g * 4 + e
+
+
+def test_quantize_fp8_bit_exact_and_permutation(hip_lib):
+    from diffsensei_amd import ops
+    g = torch.Generator().manual_seed(0)
+    x = _r((3, 40, 128), g, 4.0)
+    x[0, 0, :8] = torch.tensor([0.0, 1e-3, -2e-3, 500.0, -1000.0, 448.0, 0.0117, 240.0]).half()   # subnormals, saturation
+    for scale in (1.0, 0.25):
+        ref = (x.float() * scale).clamp(-448, 448).to(F8).view(torch.uint8)
+        got = ops.quantize_fp8(x.to(DEV), scale).cpu()
+        assert torch.equal(got, ref), f"scale {scale}: {(got != ref).sum().item()} bytes differ"
+    perm = ops.quantize_fp8(x.to(DEV), 1.0, permute64=True).cpu()
+    plain = x.float().clamp(-448, 448).to(F8).view(torch.uint8)
+    idx = torch.tensor([t * 64 + _kidx(k) for t in range(2) for k in range(64)])
+    expect = torch.empty_like(plain)
+    expect[..., idx] = plain
+    assert torch.equal(perm, expect)
+    assert sorted(_kidx(k) for k in range(64)) == list(range(64))
+
+
+def _emulated(q, k, v, heads, scale):
+    """fp32 attention over operands rounded to e4m3 where the kernel rounds them (global row max instead of the running one)."""
+    B, N, C = q.shape
+    hs = lambda t: t.float().view(B, -1, heads, 64).transpose(1, 2)
+    f8 = lambda t: t.clamp(-448, 448).to(F8).float()
+    q8 = f8(hs(q) * (scale * math.log2(math.e)))
+    k8, v8 = f8(hs(k)), f8(hs(v))
+    s = q8 @ k8.transpose(-1, -2)
+    p = torch.exp2(s - s.amax(-1, keepdim=True) + 8.0)
+    o = (f8(p) @ v8) / p.sum(-1, keepdim=True)
+    return o.transpose(1, 2).reshape(B, N, C)
+
+
+@pytest.mark.parametrize("B,heads,N,sharp", [(1, 2, 256, 1.0), (2, 10, 1024, 1.0), (1, 3, 4096, 1.0), (2, 5, 960 + 64, 2.5),
+                                             (1, 20, 1024, 1.0), (1, 1, 64, 1.0)])
+def test_self_attention_fp8_vs_sdpa(hip_lib, B, heads, N, sharp):
+    from diffsensei_amd import ops
+    g = torch.Generator().manual_seed(B + heads + N)
+    C = heads * 64
+    q, k, v = _r((B, N, C), g, sharp), _r((B, N, C), g, sharp), _r((B, N, C), g)
+    hs = lambda t: t.float().view(B, N, heads, 64).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(hs(q), hs(k), hs(v)).transpose(1, 2).reshape(B, N, C)
+    vt = v.view(B, N, heads, 64).permute(0, 2, 3, 1).contiguous()
+    y = ops.self_attention_fp8(q.to(DEV), k.to(DEV), vt.to(DEV), heads)
+    assert torch.isfinite(y).all()
+    e_ref, e_emu = _rel(y, ref), _rel(y, _emulated(q, k, v, heads, 0.125))
+    print(f"fp8 attention B={B} h={heads} N={N}: rel-L2 vs fp32 SDPA {e_ref:.3e}, vs e4m3 emulation {e_emu:.3e}")
+    assert e_ref <= 5e-2, e_ref
+    assert e_emu <= 2e-2, e_emu
+    y16 = ops.self_attention(q.to(DEV), k.to(DEV), vt.to(DEV), heads)
+    assert _rel(y, y16) <= 5e-2
+
+
+def test_self_attention_fp8_one_dominant_key(hip_lib):
+    """A late key dominates one query row: the running maximum jumps, accumulators are rescaled, P saturates at 2^8."""
+    from diffsensei_amd import ops
+    g = torch.Generator().manual_seed(3)
+    B, heads, N = 1, 1, 320 - 64
+    q, k, v = _r((B, N, 64), g), _r((B, N, 64), g), _r((B, N, 64), g)
+    k[0, 200] = q[0, 17] * 6.0
+    ref = F.scaled_dot_product_attention(q.float()[:, None], k.float()[:, None], v.float()[:, None])[:, 0]
+    vt = v.view(B, N, 1, 64).permute(0, 2, 3, 1).contiguous()
+    y = ops.self_attention_fp8(q.to(DEV), k.to(DEV), vt.to(DEV), 1)
+    assert _rel(y, ref) <= 6e-2, _rel(y, ref)
+    assert (y[0, 17].float().cpu() - v[0, 200].float()).abs().max() <= 0.07 * v[0, 200].float().abs().max() + 0.02
+    with pytest.raises(Exception):
+        ops.self_attention_fp8(q[:, :72].contiguous().to(DEV), k[:, :72].contiguous().to(DEV),
+                               vt[..., :72].contiguous().to(DEV), 1)       # Nk % 64 != 0 is refused
+
+
+def test_unet_forward_with_fp8_attention(hip_lib):
+    """`UNetMangaModel.attention_dtype = "fp8"`: the launch plan swaps every self-attention whose token count is a multiple
+    of 64 for quantize + fp8 attention.  Tiny config at 32x32 latents (levels of 256 and 64 tokens): vs the oracle."""
+    from diffsensei_amd.unet import UNetMangaModel
+    from diffsensei_amd.unet_config import random_state_dict, tiny_config
+    from oracle.unet_ref import UNetOracle
+    hq = lambda t: t.half().float()
+    cfg = tiny_config()
+    sd = {k: v.half() for k, v in random_state_dict(cfg, 0).items()}
+    g = torch.Generator().manual_seed(5)
+    B, H, W = 2, 32, 32
+    x = torch.randn(B, 4, H, W, generator=g).half()
+    enc = torch.randn(B, cfg.num_text_tokens + cfg.num_ip_tokens, cfg.cross_attention_dim, generator=g).half()
+    te = torch.randn(B, cfg.projection_class_embeddings_input_dim - 6 * cfg.addition_time_embed_dim, generator=g).half()
+    tid = torch.tensor([[256, 256, 0, 0, 256, 256]] * B, dtype=torch.float16)
+    bbox = torch.zeros(B, 4, 4)
+    bbox[1, 0] = torch.tensor([0.05, 0.10, 0.50, 0.95])
+    kw = dict(cross_attention_kwargs={"bbox": bbox, "aspect_ratio": 1.0}, added_cond_kwargs={"text_embeds": te, "time_ids": tid})
+    outs = {}
+    for mode in ("fp16", "fp8"):
+        m = UNetMangaModel(cfg, device=DEV)
+        m.load_state_dict(sd)
+        m.attention_dtype = mode
+        outs[mode] = m(x.to(DEV), 801.0, enc.to(DEV), **kw).sample
+        names = [n for n in (e.attention for e in m._engines.values())]
+        assert names == [mode]
+    with torch.no_grad():
+        ref = UNetOracle(cfg, sd, q=hq).forward(x, 801.0, enc, te, tid, bbox, 1.0, None)
+    e16, e8 = _rel(outs["fp16"], ref), _rel(outs["fp8"], ref)
+    print(f"tiny UNet 32x32: rel-L2 vs oracle fp16 {e16:.3e}, fp8 attention {e8:.3e}")
+    assert e16 <= 2e-2 and e8 <= 5e-2
+    assert not torch.equal(outs["fp16"], outs["fp8"])

@@ -104,60 +104,15 @@ def test_gemm_pingpong_kernel(hip_lib, M, N, K):
     ref = (x.float() @ w.float().t() + b.float()).half().float() + r.float()
     try:
         assert lib.ds_set_option(b"gemm_variant", 3) == 0
-        assert lib.ds_set_option(b"gemm_split_k", 1) == 0      # whole tiles only: same summation order as the reference kernel
         got = ops.gemm(x.to(DEV), w.to(DEV), b.to(DEV), r.to(DEV))
         got_act = ops.gemm(x.to(DEV), w.to(DEV), b.to(DEV), act="gelu")
         assert lib.ds_set_option(b"gemm_variant", 1) == 0
         base = ops.gemm(x.to(DEV), w.to(DEV), b.to(DEV), r.to(DEV))
     finally:
         lib.ds_set_option(b"gemm_variant", 0)
-        lib.ds_set_option(b"gemm_split_k", 0)
     _close(got, ref, what="pingpong bias+residual")
     assert torch.equal(got, base)
     _close(got_act, F.gelu(x.float() @ w.float().t() + b.float()), what="pingpong gelu")
-
-
-@pytest.mark.parametrize("M,N,K,S", [(512, 768, 1280, 2), (512, 768, 1280, 3), (2048, 1280, 1280, 5), (4096, 2560, 640, 2),
-                                     (272, 640, 384, 3), (8192, 10240, 640, 2), (16384, 2560, 1280, 4), (1040, 1408, 5120, 8)])
-def test_gemm_pingpong_split_k_tail(hip_lib, M, N, K, S):
-    """Split-K of the persistent kernel's partial last round (gemm_pp.hip): the tail tiles are cut into S k-slices (odd
-    slice lengths included: 20 k-tiles / 3), partial sums meet in the fp32 workspace, the last wave to arrive reduces them in
-    slice order.  vs fp32; vs the unsplit kernel (<= 1 fp16 ulp: only the fp32 summation order differs); bit-stable across
-    repeated launches (arrival order must not matter); bias + residual, GELU and GEGLU epilogues after the reduction."""
-    from diffsensei_amd import _lib
-    from diffsensei_amd.engine import pack_geglu
-    ops = _ops(hip_lib)
-    lib = _lib.load()
-    g = torch.Generator().manual_seed(M + N + K + S)
-    x, w, b, r = _r((M, K), g), _r((N, K), g, 1 / math.sqrt(K)), _r((N,), g), _r((M, N), g)
-    xd, wd, bd, rd = x.to(DEV), w.to(DEV), b.to(DEV), r.to(DEV)
-    ref = (x.float() @ w.float().t() + b.float()).half().float() + r.float()
-    geglu = N % 128 == 0
-    if geglu:
-        wp, bp = pack_geglu(w, b)
-        wpd, bpd = wp.to(DEV), bp.to(DEV)
-        pq = (x.float() @ w.float().t() + b.float()).half().float()
-        hid, gate = pq.chunk(2, dim=-1)
-        ref_g = hid * F.gelu(gate).half().float()
-    try:
-        assert lib.ds_set_option(b"gemm_variant", 3) == 0
-        assert lib.ds_set_option(b"gemm_split_k", 1) == 0
-        base = ops.gemm(xd, wd, bd, rd)
-        assert lib.ds_set_option(b"gemm_split_k", S) == 0
-        runs = [ops.gemm(xd, wd, bd, rd) for _ in range(4)]
-        act = ops.gemm(xd, wd, bd, act="gelu")
-        gg = ops.gemm(xd, wpd, bpd, geglu=True) if geglu else None
-    finally:
-        lib.ds_set_option(b"gemm_variant", 0)
-        lib.ds_set_option(b"gemm_split_k", 0)
-    _close(runs[0], ref, what=f"split-K S={S}")
-    for o in runs[1:]:
-        assert torch.equal(o, runs[0]), "split-K result depends on the arrival order"
-    d = (runs[0].float() - base.float()).abs().max().item()
-    assert d <= 2 * 4.9e-4 * max(ref.abs().max().item(), 1.0), f"split vs unsplit differ by {d}"
-    _close(act, F.gelu(x.float() @ w.float().t() + b.float()), what="split-K gelu")
-    if geglu:
-        _close(gg, ref_g, what="split-K geglu")
 
 
 def test_gemm_pingpong_geglu_and_dispatch(hip_lib):
@@ -190,38 +145,6 @@ def test_gemm_pingpong_geglu_and_dispatch(hip_lib):
         lib.ds_set_option(b"gemm_variant", 0)
     assert torch.equal(auto, forced)
     _close(auto, x2.float() @ w2.float().t(), what="auto dispatch")
-
-
-@pytest.mark.parametrize("M,N,K", [(2048, 1280, 1280), (2048, 2560, 1280), (2048, 1280, 5120), (8192, 640, 640),
-                                   (200, 136, 256), (64, 128, 320), (1000, 640, 2560), (4096, 1280, 1280)])
-def test_gemm_ring_buffered_small_grid_kernel(hip_lib, M, N, K):
-    """`gemm_glds_kernel<64,false,3|4>` (ring of LDS buffers, the automatic choice for grids of <= 512 blocks: the
-    num_samples-1 shapes M = 2048 / 8192): vs fp32, and bit-identical to the one-buffer kernel it replaces
-    (gemm_ring 1), with bias + residual, split A, GEGLU and the batched V^T form."""
-    from diffsensei_amd import _lib
-    from diffsensei_amd.engine import pack_geglu
-    ops = _ops(hip_lib)
-    lib = _lib.load()
-    g = torch.Generator().manual_seed(M + 3 * N + K)
-    x, w, b, r = _r((M, K), g), _r((N, K), g, 1 / math.sqrt(K)), _r((N,), g), _r((M, N), g)
-    ref = (x.float() @ w.float().t() + b.float()).half().float() + r.float()
-    K1 = (K // 128) * 64
-    out = {}
-    try:
-        for v in (0, 1):
-            assert lib.ds_set_option(b"gemm_ring", v) == 0
-            o = [ops.gemm(x.to(DEV), w.to(DEV), b.to(DEV), r.to(DEV)),
-                 ops.gemm(x[:, :K1].contiguous().to(DEV), w.to(DEV), x2=x[:, K1:].contiguous().to(DEV))]
-            if N % 128 == 0:
-                wp, bp = pack_geglu(w, b)
-                o.append(ops.gemm(x.to(DEV), wp.to(DEV), bp.to(DEV), geglu=True))
-            out[v] = o
-    finally:
-        lib.ds_set_option(b"gemm_ring", 0)
-    _close(out[0][0], ref, what="ring bias+residual")
-    _close(out[0][1], x.float() @ w.float().t(), what="ring split A")
-    for a, c in zip(out[0], out[1]):
-        assert torch.equal(a, c), "ring-buffered and one-buffer kernels differ"
 
 
 @pytest.mark.parametrize("M,C", [(256, 128), (2048, 640), (777, 256)])
