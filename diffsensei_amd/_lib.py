@@ -109,6 +109,10 @@ def load() -> C.CDLL:
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    for kv in filter(None, os.environ.get("DS_OPTIONS", "").split(",")):   # A/B runs: DS_OPTIONS=key=value,key=value
+        k, _, val = kv.partition("=")
+        if lib.ds_set_option(k.strip().encode(), int(val)) != 0:
+            raise DiffSenseiHipError(lib.ds_last_error().decode())
     v = os.environ.get("DS_GEMM_VARIANT")
     if v is not None:  # tuning/A-B knob only; 0 = the library's own choice
         if lib.ds_set_option(b"gemm_variant", int(v)) != 0:

@@ -349,6 +349,15 @@ __global__ __launch_bounds__(256, 2) void ip_attn_kernel(const IPAttnParams p, i
 #pragma unroll
             for (int r = 0; r < 16; ++r) ot[d][r] = 0.f;
 
+        // A masked key's probability is exactly 0 (exp(-10000 + ...) underflows in fp32 as it does in the reference's
+        // fp16), so a 32-key block of the IP panel in which NO query row of this wave has an attendable key contributes
+        // nothing and is skipped whole (wave-uniform): the unconditional half of the CFG batch only ever attends the
+        // dummy tokens, a panel with two characters never touches the fourth character's block.  Every row keeps at
+        // least one attendable key in an active block as long as dummy tokens exist (no box -> dummies).
+        bool act_ip[3];
+#pragma unroll
+        for (int kb = 0; kb < 3; ++kb)
+            act_ip[kb] = p.n_dummy == 0 || __builtin_amdgcn_ballot_w64(open_ip[kb] != 0u) != 0;
 #pragma unroll
         for (int part = 0; part < 2; ++part) {  // 0: text keys, 1: IP keys
             const char* sK = part ? sKi : sKt;
@@ -357,6 +366,7 @@ __global__ __launch_bounds__(256, 2) void ip_attn_kernel(const IPAttnParams p, i
             f32x16 st[3];
 #pragma unroll
             for (int kb = 0; kb < 3; ++kb) {
+                if (part && !act_ip[kb]) continue;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
                 const int row = kb * 32 + l31;
@@ -381,7 +391,8 @@ __global__ __launch_bounds__(256, 2) void ip_attn_kernel(const IPAttnParams p, i
                     gb[g] = (part && !((open_ip[g >> 1] >> ((g & 1) * 16)) & 1u)) ? -10000.0f : 0.0f;
                 const f32x2 sc2 = {p.qk_scale, p.qk_scale};
 #pragma unroll
-                for (int kb = 0; kb < 3; ++kb)
+                for (int kb = 0; kb < 3; ++kb) {
+                    if (part && !act_ip[kb]) continue;
 #pragma unroll
                     for (int r = 0; r < 16; r += 2) {
                         const float g = gb[kb * 2 + (r >> 3)];
@@ -396,9 +407,11 @@ __global__ __launch_bounds__(256, 2) void ip_attn_kernel(const IPAttnParams p, i
                         st[kb][r + 1] = v[1];
                         mloc = fmaxf(mloc, fmaxf(v[0], v[1]));
                     }
+                }
             } else {
 #pragma unroll
-                for (int kb = 0; kb < 3; ++kb)
+                for (int kb = 0; kb < 3; ++kb) {
+                    if (part && !act_ip[kb]) continue;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int kbit = (r & 3) + 8 * (r >> 2) + 4 * lhi;
@@ -408,13 +421,15 @@ __global__ __launch_bounds__(256, 2) void ip_attn_kernel(const IPAttnParams p, i
                         st[kb][r] = sv;
                         mloc = fmaxf(mloc, sv);
                     }
+                }
             }
             mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
             f32x2 psum2 = {0.f, 0.f};
             {
                 const f32x2 l2 = {LOG2E, LOG2E}, m2 = {-mloc * LOG2E, -mloc * LOG2E};
 #pragma unroll
-                for (int kb = 0; kb < 3; ++kb)
+                for (int kb = 0; kb < 3; ++kb) {
+                    if (part && !act_ip[kb]) continue;
 #pragma unroll
                     for (int r = 0; r < 16; r += 2) {
                         f32x2 v = {st[kb][r], st[kb][r + 1]};
@@ -424,6 +439,7 @@ __global__ __launch_bounds__(256, 2) void ip_attn_kernel(const IPAttnParams p, i
                         st[kb][r + 1] = e[1];
                         psum2 += e;
                     }
+                }
             }
             float psum = psum2[0] + psum2[1];
             psum += __shfl_xor(psum, 32, 64);
@@ -431,7 +447,8 @@ __global__ __launch_bounds__(256, 2) void ip_attn_kernel(const IPAttnParams p, i
             {
                 const f32x2 w2 = {w, w};
 #pragma unroll
-                for (int kb = 0; kb < 3; ++kb)
+                for (int kb = 0; kb < 3; ++kb) {
+                    if (part && !act_ip[kb]) continue;
 #pragma unroll
                     for (int r = 0; r < 16; r += 2) {
                         f32x2 v = {st[kb][r], st[kb][r + 1]};
@@ -439,10 +456,12 @@ __global__ __launch_bounds__(256, 2) void ip_attn_kernel(const IPAttnParams p, i
                         st[kb][r] = v[0];
                         st[kb][r + 1] = v[1];
                     }
+                }
             }
             // O^T += V^T P^T
 #pragma unroll
-            for (int kb = 0; kb < 3; ++kb)
+            for (int kb = 0; kb < 3; ++kb) {
+                if (part && !act_ip[kb]) continue;
 #pragma unroll
                 for (int hb = 0; hb < 2; ++hb) {
                     const h8 pf = pack8(st[kb], hb * 8);
@@ -458,6 +477,7 @@ __global__ __launch_bounds__(256, 2) void ip_attn_kernel(const IPAttnParams p, i
                         ot[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, ot[db], 0, 0, 0);
                     }
                 }
+            }
         }
         if (q0 + l31 < p.N) {
             half_t* op = p.o + ((long)b * p.N + q0 + l31) * p.ldo + h * 64;

@@ -1,7 +1,8 @@
 // FP8 (OCP e4m3) flash self-attention for gfx950 - BASELINE.json configs[4] ("CDNA4 fp8 MFMA attention" at 2048 x 2048),
 // an opt-in variant of self_attn_kernel (attention.hip), i.e. of F.scaled_dot_product_attention at reference
 // src/models/attention_processor.py:76-78.  The reference computes this in fp16; this variant trades precision for
-// matrix-core rate and states its tolerance (tests/test_gpu_attention_fp8.py: relative L2 <= 5e-2 vs fp32 SDPA).
+// matrix-core rate and states its tolerance (tests/test_gpu_attention_fp8.py: exact on an e4m3 lattice; relative L2 <= 7e-2 vs
+// fp32 SDPA on white noise, <= 1e-2 on coherent values).
 //
 // Why the MX instruction: gfx950's plain fp8 MFMAs (32x32x16 / 16x16x32) run at the bf16 rate; only
 // v_mfma_f32_32x32x64_f8f6f4 (the block-scaled form, here with the scale operands left at 2^0) contracts K = 64 per issue,

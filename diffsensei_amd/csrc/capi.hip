@@ -67,6 +67,10 @@ int ds_set_option(const char* key, int value) {
         ds_llm_gemv_set_variant(value);
         return 0;
     }
+    if (strcmp(key, "gemm_pp_even") == 0) {
+        ds_gemm_pp_set_even(value);
+        return 0;
+    }
     if (strcmp(key, "gemm_debug") == 0) {
         ds_gemm_set_debug(value);
         return 0;

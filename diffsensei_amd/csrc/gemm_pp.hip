@@ -526,8 +526,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 }
 
 int g_pp_blocks = 0;  // persistent grid size: one block per CU
+int g_pp_even = 0;    // experiment knob "gemm_pp_even": 1 = shrink the grid so that every round is full (ceil(T / rounds) blocks)
 
 }  // namespace
+
+void ds_gemm_pp_set_even(int v) { g_pp_even = v; }
 
 // Shapes the kernel takes: K a multiple of 128 (an even number of k-tiles), a single A source, M and N multiples of 16 (a wave's 16
 // staged rows are then wholly inside or outside the problem).  ds_launch_gemm decides when it is also the faster choice.
@@ -563,7 +566,14 @@ int ds_launch_gemm_pp(const GemmParams& p0, int batch, hipStream_t stream) {
         g_pp_blocks = cus > 0 ? cus : 256;
     }
     const int tiles = p.tiles_m * p.tiles_n;
-    dim3 grid(tiles < g_pp_blocks ? tiles : g_pp_blocks, 1, batch);
+    int nblk = tiles < g_pp_blocks ? tiles : g_pp_blocks;
+    if (g_pp_even && tiles > g_pp_blocks) {  // same number of rounds, all of them full, on fewer CUs
+        const int rounds = (tiles + g_pp_blocks - 1) / g_pp_blocks;
+        nblk = (tiles + rounds - 1) / rounds;
+        nblk = (nblk + 7) / 8 * 8;           // keep the XCD-chunked tile walk (grid % 8 == 0)
+        if (nblk > g_pp_blocks) nblk = g_pp_blocks;
+    }
+    dim3 grid(nblk, 1, batch);
     kern_t kern = nullptr;
     for (const auto& e : table)
         if (e.dbg == (p.dtype == DS_DTYPE_BF16 ? -1 : (p.debug & 255))) kern = e.k;

@@ -112,7 +112,8 @@ int ds_self_attn_f16(const void* q, int64_t ldq, int64_t sq, const void* k, int6
 
 /* FP8 (OCP e4m3) variant of the above for BASELINE.json configs[4] ("CDNA4 fp8 MFMA attention"): same SDPA call of
  * reference src/models/attention_processor.py:76-78, contracted with v_mfma_f32_32x32x64_f8f6f4 (twice the f16 matrix
- * rate).  Opt-in: it is NOT the reference's fp16 arithmetic; stated tolerance rel-L2 <= 5e-2 vs fp32 SDPA.
+ * rate).  Opt-in: it is NOT the reference's fp16 arithmetic; stated tolerance: exact on e4m3-representable inputs, rel-L2
+ * <= 7e-2 vs fp32 SDPA on white noise (worst case), <= 1e-2 on coherent values (tests/test_gpu_attention_fp8.py).
  *   ds_quantize_fp8_e4m3_f16  x [batch][rows, cols] f16 (row stride ldx, batch stride sx, elements) -> out [batch][rows][cols]
  *                             bytes = e4m3(clamp(x * scale, +-448)); permute64 != 0 stores every 64-column group in the
  *                             contraction order of the attention kernel (use for V^T, 0 for K).
