@@ -35,11 +35,12 @@ SIGNATURES = {
     "ds_gemm_f16": (i32, [vp, i64, vp, i64, i32, vp, i64, vp, vp, i64, vp, i64, i32, i32, i32, i32, vp]),
     "ds_gemm_f16_batched": (i32, [vp, i64, i64, vp, i64, i64, vp, i64, i64, i32, i32, i32, i32, vp]),
     "ds_conv3x3_f16": (i32, [vp, vp, vp, vp, i64, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "ds_conv3x3_resize_f16": (i32, [vp, vp, vp, vp, i64, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "ds_conv3x3_bf16": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "ds_gemm_bf16": (i32, [vp, i64, vp, i64, vp, vp, i64, vp, i64, i32, i32, i32, vp]),
     "ds_gemm_bf16_batched": (i32, [vp, i64, i64, vp, i64, i64, vp, i64, i64, i32, i32, i32, i32, vp]),
     "ds_groupnorm_bf16": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp]),
-    "ds_wide_attn_bf16": (i32, [vp, vp, vp, vp, i32, i32, f32, vp]),
+    "ds_wide_attn_bf16": (i32, [vp, vp, vp, vp, i32, i32, i32, f32, vp]),
     "ds_vae_conv_in_bf16": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp]),
     "ds_vae_conv_out_bf16": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "ds_groupnorm_workspace_bytes": (sz, [i32, i32]),

@@ -548,8 +548,10 @@ __global__ __launch_bounds__(256) void small_attn_kernel(const half_t* __restric
 
 int ds_launch_self_attn(const SelfAttnParams& p, hipStream_t stream) {
     DS_REQUIRE(p.B > 0 && p.heads > 0 && p.Nq > 0 && p.Nk > 0, "self_attn: empty problem");
-    DS_REQUIRE(p.Nk % 8 == 0 && p.ldv % 8 == 0 && p.ldq % 8 == 0 && p.ldk % 8 == 0 && p.ldo % 4 == 0,
-               "self_attn: Nk/ld* alignment (Nk=%d)", p.Nk);
+    // any Nk: V^T rows are read 8 keys at a time, so their stride must cover Nk rounded up to 8 (the pad columns may hold
+    // anything finite: keys >= Nk are masked to probability 0 on the last tile)
+    DS_REQUIRE(p.ldv % 8 == 0 && p.ldv >= (p.Nk + 7) / 8 * 8 && p.ldq % 8 == 0 && p.ldk % 8 == 0 && p.ldo % 4 == 0,
+               "self_attn: ld* alignment (Nk=%d ldv=%ld)", p.Nk, p.ldv);
     // 64 query rows per wave when that still leaves >= 2 blocks per CU; 32 rows per wave otherwise
     const long blocks2 = (long)((p.Nq + 255) / 256) * p.B * p.heads;
     // (measured on MI355X: 64-row waves win from N = 4096 up, lose at N = 1024 — profiles/r01_attn_variants.txt)

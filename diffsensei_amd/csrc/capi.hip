@@ -99,16 +99,22 @@ int ds_gemm_f16_batched(const void* x, int64_t ldx, int64_t sx, const void* w, i
 
 static int conv3x3_impl(const void* x, const void* w, const void* bias, const void* rowbias, int64_t rowbias_ld,
                         const void* residual, void* y, int B, int H_, int W_, int Cin, int Cout, int stride,
-                        int upsample, hipStream_t stream, int dtype = DS_DTYPE_F16) {
+                        int upsample, hipStream_t stream, int dtype = DS_DTYPE_F16, int out_h = 0, int out_w = 0) {
     DS_REQUIRE(stride == 1 || stride == 2, "conv3x3: stride must be 1 or 2");
     DS_REQUIRE(!(upsample && stride != 1), "conv3x3: upsample with stride 2 is not a thing");
+    DS_REQUIRE((out_h == 0 && out_w == 0) || (upsample && out_h > 0 && out_w > 0),
+               "conv3x3: an explicit output size needs the upsample flag");
     GemmParams p;
     p.conv = 1;
     p.A = H(x); p.W = H(w); p.ldw = 9L * Cin; p.bias = H(bias); p.rowbias = H(rowbias); p.rowbias_ld = (int)rowbias_ld;
     p.residual = H(residual); p.ldr = Cout; p.C = HM(y); p.ldc = Cout;
     p.Hin = H_; p.Win = W_; p.Cin = Cin; p.cstride = stride; p.upsample = upsample;
-    p.Hout = upsample ? 2 * H_ : (stride == 2 ? (H_ + 1) / 2 : H_);
-    p.Wout = upsample ? 2 * W_ : (stride == 2 ? (W_ + 1) / 2 : W_);
+    p.Hout = upsample ? (out_h ? out_h : 2 * H_) : (stride == 2 ? (H_ + 1) / 2 : H_);
+    p.Wout = upsample ? (out_w ? out_w : 2 * W_) : (stride == 2 ? (W_ + 1) / 2 : W_);
+    if (upsample) {  // ATen: scale = float(input_size) / output_size
+        p.up_sy = (float)H_ / (float)p.Hout;
+        p.up_sx = (float)W_ / (float)p.Wout;
+    }
     p.M = B * p.Hout * p.Wout; p.N = Cout; p.K = 9 * Cin; p.K1 = p.K;
     p.rows_per_group = p.Hout * p.Wout;
     p.dtype = dtype;
@@ -119,6 +125,13 @@ int ds_conv3x3_f16(const void* x, const void* w, const void* bias, const void* r
                    const void* residual, void* y, int B, int H_, int W_, int Cin, int Cout, int stride, int upsample,
                    void* stream) {
     return conv3x3_impl(x, w, bias, rowbias, rowbias_ld, residual, y, B, H_, W_, Cin, Cout, stride, upsample, S(stream));
+}
+
+int ds_conv3x3_resize_f16(const void* x, const void* w, const void* bias, const void* rowbias, int64_t rowbias_ld,
+                          const void* residual, void* y, int B, int H_, int W_, int Cin, int Cout, int Hout, int Wout,
+                          void* stream) {
+    return conv3x3_impl(x, w, bias, rowbias, rowbias_ld, residual, y, B, H_, W_, Cin, Cout, 1, 1, S(stream), DS_DTYPE_F16, Hout,
+                        Wout);
 }
 
 // ---- bf16 entry points: the VAE decoder (fp16 overflows there; the reference runs it in fp32) ----------------------
@@ -151,8 +164,9 @@ int ds_groupnorm_bf16(const void* x, void* y, const void* gamma, const void* bet
     return ds_launch_groupnorm(p, S(stream));
 }
 
-int ds_wide_attn_bf16(const void* q, const void* k, const void* vt, void* o, int B, int N, float scale, void* stream) {
-    return ds_launch_wide_attn(q, k, vt, o, B, N, DS_DTYPE_BF16, scale, S(stream));
+int ds_wide_attn_bf16(const void* q, const void* k, const void* vt, void* o, int B, int N, int n_valid, float scale,
+                      void* stream) {
+    return ds_launch_wide_attn(q, k, vt, o, B, N, n_valid, DS_DTYPE_BF16, scale, S(stream));
 }
 
 int ds_vae_conv_in_bf16(const float* latents, const float* post_quant_w, const float* post_quant_b, const void* w,
@@ -384,7 +398,8 @@ static int run_op(const ds_op& o, hipStream_t st) {
             return ds_launch_gemm(g, i[5] > 0 ? i[5] : 1, st);
         }
         case DS_OP_CONV3X3:
-            return conv3x3_impl(p[0], p[1], p[3], p[4], i[7], p[5], p[2], i[0], i[1], i[2], i[3], i[4], i[5], i[6], st);
+            return conv3x3_impl(p[0], p[1], p[3], p[4], i[7], p[5], p[2], i[0], i[1], i[2], i[3], i[4], i[5], i[6], st,
+                                DS_DTYPE_F16, i[8], i[9]);
         case DS_OP_GROUPNORM: {
             GroupNormParams g;
             g.x1 = H(p[0]); g.x2 = H(p[1]); g.y = HM(p[2]); g.gamma = H(p[3]); g.beta = H(p[4]);
@@ -495,8 +510,8 @@ int ds_op_describe(const ds_op* op, char* name, int name_len, double* flops, dou
         }
         case DS_OP_CONV3X3: {
             GemmParams g;
-            const int Ho = i[6] ? 2 * i[1] : (i[5] == 2 ? (i[1] + 1) / 2 : i[1]);
-            const int Wo = i[6] ? 2 * i[2] : (i[5] == 2 ? (i[2] + 1) / 2 : i[2]);
+            const int Ho = i[6] ? (i[8] ? i[8] : 2 * i[1]) : (i[5] == 2 ? (i[1] + 1) / 2 : i[1]);
+            const int Wo = i[6] ? (i[9] ? i[9] : 2 * i[2]) : (i[5] == 2 ? (i[2] + 1) / 2 : i[2]);
             g.M = i[0] * Ho * Wo; g.N = i[4]; g.K = 9 * i[3];
             g.conv = 1;
             g.Hin = i[1]; g.Win = i[2]; g.Cin = i[3]; g.Hout = Ho; g.Wout = Wo; g.cstride = i[5]; g.upsample = i[6];

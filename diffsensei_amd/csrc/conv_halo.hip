@@ -16,7 +16,7 @@
 // every other tile (16-byte chunk c of row q at slot c ^ ((q>>1)&7)); because the tap shift changes q per lane, the
 // reader rebuilds its swizzle per tap: base = q*128 + ((lhi ^ (q>>1)&7) << 4), k-step kk at base ^ (kk << 5).
 // Halo pixels outside the image come from a zero page.  With upsample the patch is gathered from input pixel
-// (uy>>1, ux>>1): the upsampled tensor never exists.
+// nearest_src(uy), nearest_src(ux) (= uy>>1, ux>>1 for the plain x2 case): the upsampled tensor never exists.
 //
 // K order: channel slices outer, taps inner (k = tap*Cin + ci in the weight rows) - the sum is the same set of
 // products as the tap-major kernel's, in a different order, so results agree to fp32-accumulation rounding.
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256, 3) void conv_halo_kernel(const GemmParams p) {
         const int qy = q / HWD, qx = q - qy * HWD;
         const int uy = oy0 - 1 + qy, ux = ox0 - 1 + qx;  // output-resolution pixel
         const bool ok = (q < HROWS) & (uy >= 0) & (uy < p.Hout) & (ux >= 0) & (ux < p.Wout);
-        const int iy = p.upsample ? uy >> 1 : uy, ix = p.upsample ? ux >> 1 : ux;
+        const int iy = p.upsample ? nearest_src(uy, p.up_sy, p.Hin) : uy, ix = p.upsample ? nearest_src(ux, p.up_sx, p.Win) : ux;
         const int chunk = slot ^ ((q >> 1) & 7);
         poff[j] = ok ? ((b * p.Hin + iy) * p.Win + ix) * p.Cin + chunk * 8 : -1;
     }
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo256_kernel(const GemmParams p
         const int qy = q / HWD, qx = q - qy * HWD;
         const int uy = oy0 - 1 + qy, ux = ox0 - 1 + qx;
         const bool ok = (q < HROWS2) & (uy >= 0) & (uy < p.Hout) & (ux >= 0) & (ux < p.Wout);
-        const int iy = p.upsample ? uy >> 1 : uy, ix = p.upsample ? ux >> 1 : ux;
+        const int iy = p.upsample ? nearest_src(uy, p.up_sy, p.Hin) : uy, ix = p.upsample ? nearest_src(ux, p.up_sx, p.Win) : ux;
         const int chunk = slot ^ ((q >> 1) & 7);
         poff[j] = ok ? ((b * p.Hin + iy) * p.Win + ix) * p.Cin + chunk * 8 : -1;
     }

@@ -88,6 +88,14 @@ __device__ __forceinline__ float ds_gelu_erf(float x) {
     return x * (x < 0.f ? r : 1.0f - r);
 }
 
+// Source index of nearest-neighbour resizing exactly as ATen computes it (F.interpolate(mode="nearest"), the op behind
+// diffusers' Upsample2D [3P]): min(int(floorf(dst * scale)), in - 1) with scale = float(in) / out (0.5 for the plain x2
+// case, where it equals dst >> 1).  The reference reaches the general case whenever a latent side is not a multiple of 4:
+// diffusers then resizes to the skip tensor's size (forward_upsample_size).
+__device__ __forceinline__ int nearest_src(int dst, float scale, int in_size) {
+    return min((int)floorf((float)dst * scale), in_size - 1);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

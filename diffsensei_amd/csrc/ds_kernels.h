@@ -19,6 +19,7 @@ struct GemmParams {
     int epi = EPI_NONE;
     int conv = 0;
     int Hin = 0, Win = 0, Cin = 0, Hout = 0, Wout = 0, cstride = 1, upsample = 0;
+    float up_sy = 0.5f, up_sx = 0.5f;  // upsample: nearest-resize scales float(Hin)/Hout, float(Win)/Wout (ATen's definition)
     int tiles_m = 0, tiles_n = 0;
     int dtype = DS_DTYPE_F16;  // element type of A / W / C / bias / residual (the pointers are 2-byte opaque): bf16 = VAE path
     int debug = 0;  // ablation only (ds_set_option "gemm_debug"): 1 skip MFMA, 2 skip tile loads — results are garbage
@@ -35,8 +36,8 @@ void ds_gemm_pp_set_even(int v);  // experiment: 1 = persistent grid shrunk so t
 void ds_gemm_set_variant(int v);  // 0 auto, 1 register staging only, 2 glds (BM <= 128), 3 glds, BM = 256 when large
 
 // ---- VAE decoder only (vae.hip) ---------------------------------------------------------------------
-int ds_launch_wide_attn(const void* q, const void* k, const void* vt, void* o, int B, int N, int dtype, float scale,
-                        hipStream_t stream);  // one head of dim 512: q,k,o [B,N,512]; vt [B,512,N]
+int ds_launch_wide_attn(const void* q, const void* k, const void* vt, void* o, int B, int N, int n_valid, int dtype,
+                        float scale, hipStream_t stream);  // one head of dim 512: q,k,o [B,N,512]; vt [B,512,N]; keys >= n_valid masked
 int ds_launch_vae_conv_in(const float* lat, const float* wpq, const float* bpq, const void* w, const void* bias, void* y,
                           int B, int H, int W, int C, float scaling_factor, int dtype, hipStream_t stream);
 int ds_launch_vae_conv_out(const void* x, const void* w, const void* bias, float* img, int B, int H, int W, int C,

@@ -257,8 +257,8 @@ __global__ __launch_bounds__(256, (BM > 128 ? 1 : (STAGES == 1 ? (BM == 64 ? 4 :
                 if (p.upsample) {
                     const int uy = a_oy[j] + ky - 1, ux = a_ox[j] + kx - 1;
                     ok = (uy >= 0) & (uy < p.Hout) & (ux >= 0) & (ux < p.Wout);
-                    iy = uy >> 1;
-                    ix = ux >> 1;
+                    iy = nearest_src(uy, p.up_sy, p.Hin);
+                    ix = nearest_src(ux, p.up_sx, p.Win);
                 } else {
                     iy = a_oy[j] * p.cstride + ky - 1;
                     ix = a_ox[j] * p.cstride + kx - 1;
@@ -427,8 +427,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const GemmParams p) {
                 if (p.upsample) {
                     const int uy = a_oy[j] + ky - 1, ux = a_ox[j] + kx - 1;
                     ok = (uy >= 0) & (uy < p.Hout) & (ux >= 0) & (ux < p.Wout);
-                    iy = uy >> 1;
-                    ix = ux >> 1;
+                    iy = nearest_src(uy, p.up_sy, p.Hin);
+                    ix = nearest_src(ux, p.up_sx, p.Win);
                 } else {
                     iy = a_oy[j] * p.cstride + ky - 1;
                     ix = a_ox[j] * p.cstride + kx - 1;

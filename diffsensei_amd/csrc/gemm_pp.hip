@@ -526,7 +526,13 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 }
 
 int g_pp_blocks = 0;  // persistent grid size: one block per CU
-int g_pp_even = 0;    // experiment knob "gemm_pp_even": 1 = shrink the grid so that every round is full (ceil(T / rounds) blocks)
+// Persistent grid = ceil(tiles / rounds) blocks (rounded up to a multiple of 8 for the XCD walk) instead of one per CU: the
+// same number of rounds, but every round full.  Measured (profiles/r02_pp_even_ab.txt): M = 32768 x N = 1280 = 640 tiles =
+// 2.5 rounds of 256 CUs runs 9-10 % FASTER on 216 CUs x 3 full rounds (FF down-projection 449 -> 408 us, 957 -> 1053
+// TF/s; the N = K = 1280 projections 137 -> 126 us); shapes with whole rounds are unchanged.  A half-empty last round
+// leaves the stragglers' operand panels without the sharers the XCD-chunked walk counts on, and on this power-limited
+// part the idle CUs buy nothing.  Knob "gemm_pp_even" 0 restores one block per CU (A/B).
+int g_pp_even = 1;
 
 }  // namespace
 

@@ -32,7 +32,7 @@ __device__ __forceinline__ int kswz(int row, int chunk) { return row * KROW + ((
 template <typename T>
 __global__ __launch_bounds__(256, 1) void wide_attn_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                            const T* __restrict__ vt, T* __restrict__ o, int N,
-                                                           float scale) {
+                                                           int n_valid, float scale) {
     typedef typename Elt<T>::v8 V8;
     typedef typename Elt<T>::v4 V4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256, 1) void wide_attn_kernel(const T* __restrict__
         for (int r = 0; r < 16; ++r) ot[d][r] = 0.f;
     float m_run = NEG_BIG, l_part = 0.f;
     const float c = scale * LOG2E;
-    const int nt = (N + KT - 1) / KT;
+    const int nt = (n_valid + KT - 1) / KT;  // keys [n_valid, N) are padding rows of the caller's token matrices
     load_tile(0, 0);
     store_tile(0);
     __syncthreads();  // drains vmcnt: the K rows have landed
@@ -113,8 +113,8 @@ __global__ __launch_bounds__(256, 1) void wide_attn_kernel(const T* __restrict__
             const V8 kf = *reinterpret_cast<const V8*>(sKb(buf) + kswz(l31, kk * 2 + lhi));
             st = Elt<T>::mfma(kf, qf[kk], st);
         }
-        if (t * KT + KT > N) {  // ragged last tile (N % 32 != 0): clamped rows must not contribute
-            int n_here = N;
+        if (t * KT + KT > n_valid) {  // ragged last tile: clamped / padding rows must not contribute
+            int n_here = n_valid;
             asm volatile("" : "+s"(n_here)::"memory");
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -297,9 +297,11 @@ __global__ __launch_bounds__(256) void vae_conv_out_kernel(const T* __restrict__
 
 }  // namespace
 
-int ds_launch_wide_attn(const void* q, const void* k, const void* vt, void* o, int B, int N, int dtype, float scale,
-                        hipStream_t stream) {
+int ds_launch_wide_attn(const void* q, const void* k, const void* vt, void* o, int B, int N, int n_valid, int dtype,
+                        float scale, hipStream_t stream) {
     DS_REQUIRE(B > 0 && N >= 8 && N % 8 == 0, "wide_attn: token count (%d) must be a positive multiple of 8", N);
+    if (n_valid <= 0) n_valid = N;
+    DS_REQUIRE(n_valid <= N, "wide_attn: n_valid (%d) exceeds the row count (%d)", n_valid, N);
     const size_t lds = 2 * KT * KROW + 2 * DS * VSTR;  // 64 KiB + 18 KiB
     static bool attr_set = false;
     if (!attr_set) {
@@ -312,10 +314,10 @@ int ds_launch_wide_attn(const void* q, const void* k, const void* vt, void* o, i
     dim3 grid((N + 127) / 128, DH / DS, B);
     if (dtype == DS_DTYPE_BF16)
         hipLaunchKernelGGL(wide_attn_kernel<bf16_t>, grid, dim3(256), lds, stream, (const bf16_t*)q, (const bf16_t*)k,
-                           (const bf16_t*)vt, (bf16_t*)o, N, scale);
+                           (const bf16_t*)vt, (bf16_t*)o, N, n_valid, scale);
     else
         hipLaunchKernelGGL(wide_attn_kernel<half_t>, grid, dim3(256), lds, stream, (const half_t*)q, (const half_t*)k,
-                           (const half_t*)vt, (half_t*)o, N, scale);
+                           (const half_t*)vt, (half_t*)o, N, n_valid, scale);
     DS_LAUNCH_CHECK();
     return 0;
 }

@@ -279,21 +279,15 @@ class UNetEngine:
 
     @staticmethod
     def level_sizes(cfg: UNetMangaConfig, height: int, width: int) -> List[Tuple[int, int]]:
-        """(h, w) of every resolution level for a latent of height x width, or ValueError with the rule that failed.
-        The reference accepts any image side that is a multiple of 8; this engine needs every level to halve exactly
-        (latent sides multiples of 2^(levels-1)) and every attention level's token count to be a multiple of 8 (16-byte
-        rows of the key-contiguous V^T operand) - all image sides that are multiples of 64 qualify."""
-        nlev = len(cfg.block_out_channels)
-        q = 1 << (nlev - 1)
-        if height <= 0 or width <= 0 or height % q or width % q:
-            raise ValueError(f"latent size {height}x{width} (image {8 * height}x{8 * width}): both latent sides must be "
-                             f"multiples of {q} (image sides multiples of {8 * q}); multiples of 64 always work")
-        hw = [(height >> l, width >> l) for l in range(nlev)]
-        for l in range(1, nlev):
-            if (hw[l][0] * hw[l][1]) % 8:
-                raise ValueError(f"latent {height}x{width} (image {8 * height}x{8 * width}): attention level {l} would have "
-                                 f"{hw[l][0] * hw[l][1]} tokens; the attention kernels need a multiple of 8 - use image "
-                                 f"sides that are multiples of 64")
+        """(h, w) of every resolution level for a latent of height x width.  Any size works, like the reference (image sides
+        that are multiples of 8): a stride-2 Downsample2D gives ceil(h / 2), and the matching Upsample2D resizes to the skip
+        tensor's size (diffusers `forward_upsample_size` [3P]) - see `ds_conv3x3_resize_f16`."""
+        if height < 1 or width < 1:
+            raise ValueError(f"latent size {height}x{width}: both sides must be >= 1")
+        hw = [(int(height), int(width))]
+        for _ in range(len(cfg.block_out_channels) - 1):
+            h, w = hw[-1]
+            hw.append(((h + 1) // 2, (w + 1) // 2))
         return hw
 
     # -- memory
@@ -302,13 +296,16 @@ class UNetEngine:
         self.keep.append(t)
         return t
 
-    def _buf(self, role: str, level: int, rows: int, cols: int) -> Tensor:
-        """Role-keyed scratch, sized to the largest request per (role, level)."""
+    def _buf(self, role: str, level: int, rows: int, cols: int, zero: bool = False) -> Tensor:
+        """Role-keyed scratch, sized to the largest request per (role, level); `zero`: cleared once at allocation (for
+        buffers whose slack is read but never written)."""
         key = (role, level)
         need = rows * cols
         t = self.scratch.get(key)
         if t is None or t.numel() < need:
             t = self._alloc((need,), torch.float16)
+            if zero:
+                t.zero_()
             self.scratch[key] = t
         return t
 
@@ -349,9 +346,9 @@ class UNetEngine:
         ops.append(make_op("GROUPNORM", i=(self.B, HW, C1, C2, self.cfg.norm_num_groups, int(silu)), f=(eps,),
                            p=(x1, x2, y, gamma, beta, self.gn_ws)))
 
-    def _conv(self, ops, x, wname, y, H, W, Cin, Cout, stride=1, upsample=0, rowbias=None, residual=None):
+    def _conv(self, ops, x, wname, y, H, W, Cin, Cout, stride=1, upsample=0, rowbias=None, residual=None, out_hw=(0, 0)):
         w = self.pk.w
-        ops.append(make_op("CONV3X3", i=(self.B, H, W, Cin, Cout, stride, upsample, self.pk.temb_total),
+        ops.append(make_op("CONV3X3", i=(self.B, H, W, Cin, Cout, stride, upsample, self.pk.temb_total, out_hw[0], out_hw[1]),
                            p=(x, w[wname + ".weight"], y, w[wname + ".bias"], rowbias, residual)))
 
     def _gemm(self, ops, x, wt, y, M, N, K, bias=None, residual=None, geglu=False, x2=None, K1=0):
@@ -387,10 +384,14 @@ class UNetEngine:
         N, Cc = H * W, a.channels
         M = B * N
         p = a.prefix
-        tn = self._buf("t_norm", a.level, M, Cc)
+        # V^T rows are read 8 keys at a time: their stride is N rounded up to 8.  The projection then also covers the
+        # (< 8) rows after an image's tokens - the next image's first rows, or the zeroed slack behind the last image -
+        # and the attention kernel masks those keys; nothing is copied or padded per call.
+        Np = (N + 7) // 8 * 8
+        tn = self._buf("t_norm", a.level, M + 8, Cc, zero=True)
         h = self._buf("t_hidden", a.level, M, Cc)
         qk = self._buf("t_qk", a.level, M, 2 * Cc)
-        vt = self._buf("t_vt", a.level, M, Cc)
+        vt = self._buf("t_vt", a.level, B * Np, Cc)
         ao = self._buf("t_attn", a.level, M, Cc)
         q2 = self._buf("t_q2", a.level, M, Cc)
         ff = self._buf("t_ff", a.level, M, 4 * Cc)
@@ -404,7 +405,7 @@ class UNetEngine:
             # ---- attn1 (AttnProcessor2_0): q|k projection, V^T projection, flash attention, out-proj + residual
             ops.append(make_op("LAYERNORM", i=(M, Cc), f=(1e-5,), p=(h, tn, w[t + ".norm1.weight"], w[t + ".norm1.bias"])))
             self._gemm(ops, tn, w[t + ".attn1.qk.weight"], qk, M, 2 * Cc, Cc)
-            ops.append(make_op("GEMM", i=(Cc, N, Cc, Cc, 0, B, 0, 1), l=(Cc, 0, Cc, N, 0, 0, 0, N * Cc, Cc * N, 0),
+            ops.append(make_op("GEMM", i=(Cc, Np, Cc, Cc, 0, B, 0, 1), l=(Cc, 0, Cc, Np, 0, 0, 0, N * Cc, Cc * Np, 0),
                                p=(w[t + ".attn1.to_v.weight"], None, tn, vt)))
             if self.attention == "fp8" and N % 64 == 0:
                 k8 = self._buf("t_k8", a.level, M, Cc // 2)      # bytes: M*Cc uint8 in an f16-typed scratch
@@ -416,7 +417,7 @@ class UNetEngine:
                                    l=(2 * Cc, Cc, N * 2 * Cc, N * Cc), p=(qk, k8, v8, ao)))
             else:
                 ops.append(make_op("SELF_ATTN", i=(B, a.heads, N, N), f=(scale,),
-                                   l=(2 * Cc, 2 * Cc, N, Cc, N * 2 * Cc, N * 2 * Cc, N * Cc),
+                                   l=(2 * Cc, 2 * Cc, Np, Cc, N * 2 * Cc, N * 2 * Cc, N * Cc),
                                    p=(qk, qk.data_ptr() + 2 * Cc, vt, ao)))
             self._gemm(ops, ao, w[t + ".attn1.to_out.0.weight"], h, M, Cc, Cc, bias=w[t + ".attn1.to_out.0.bias"],
                        residual=h)
@@ -515,7 +516,8 @@ class UNetEngine:
             if blk["upsample"]:
                 h_, w_ = self.hw[lvl]
                 out = new_act(lvl - 1, cur_c, blk["upsample"])
-                self._conv(ops, cur, blk["upsample"], out, h_, w_, cur_c, cur_c, upsample=1)
+                # Upsample2D resizes to the size of the skip it will meet (== 2x unless a side was odd on the way down)
+                self._conv(ops, cur, blk["upsample"], out, h_, w_, cur_c, cur_c, upsample=1, out_hw=self.hw[lvl - 1])
                 cur = out
         assert not skips
         # ---- 6. out (:335-338)

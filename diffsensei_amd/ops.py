@@ -82,14 +82,22 @@ def gemm_batched_nt(a: Tensor, b: Tensor, out: Optional[Tensor] = None) -> Tenso
 
 
 def conv3x3(x: Tensor, w: Tensor, bias: Optional[Tensor], stride: int = 1, upsample: bool = False,
-            rowbias: Optional[Tensor] = None, residual: Optional[Tensor] = None) -> Tensor:
-    """x: [B,H,W,Cin] NHWC, w: [Cout,3,3,Cin] -> [B,Ho,Wo,Cout]; rowbias: [B,Cout] per-image bias."""
+            rowbias: Optional[Tensor] = None, residual: Optional[Tensor] = None,
+            out_size: Optional[Tuple[int, int]] = None) -> Tensor:
+    """x: [B,H,W,Cin] NHWC, w: [Cout,3,3,Cin] -> [B,Ho,Wo,Cout]; rowbias: [B,Cout] per-image bias.  `out_size` (Ho, Wo):
+    nearest-resize to that size first (F.interpolate(size=...) indexing), then the conv (Upsample2D with output_size)."""
     _chk(x, w, bias, rowbias, residual)
     B, H, W, Cin = x.shape
     Cout = w.shape[0]
+    L = _lib.load()
+    if out_size is not None:
+        Ho, Wo = int(out_size[0]), int(out_size[1])
+        y = torch.empty((B, Ho, Wo, Cout), dtype=torch.float16, device=x.device)
+        check(L.ds_conv3x3_resize_f16(_p(x), _p(w), _p(bias), _p(rowbias), 0 if rowbias is None else rowbias.shape[1],
+                                      _p(residual), _p(y), B, H, W, Cin, Cout, Ho, Wo, _stream()), "ds_conv3x3_resize_f16")
+        return y
     Ho, Wo = (2 * H, 2 * W) if upsample else ((H + stride - 1) // stride, (W + stride - 1) // stride)
     y = torch.empty((B, Ho, Wo, Cout), dtype=torch.float16, device=x.device)
-    L = _lib.load()
     check(L.ds_conv3x3_f16(_p(x), _p(w), _p(bias), _p(rowbias), 0 if rowbias is None else rowbias.shape[1],
                            _p(residual), _p(y), B, H, W, Cin, Cout, stride, int(upsample), _stream()),
           "ds_conv3x3_f16")
@@ -345,13 +353,14 @@ def groupnorm_bf16(x: Tensor, gamma: Tensor, beta: Tensor, groups: int, eps: flo
     return y
 
 
-def wide_attention_bf16(q: Tensor, k: Tensor, vt: Tensor, scale: float) -> Tensor:
-    """Single head of dim 512: q, k [B,N,512], vt [B,512,N] -> [B,N,512]."""
+def wide_attention_bf16(q: Tensor, k: Tensor, vt: Tensor, scale: float, n_valid: int = 0) -> Tensor:
+    """Single head of dim 512: q, k [B,N,512], vt [B,512,N] -> [B,N,512]; keys >= n_valid (0 = all) are padding."""
     _chk(q, k, vt, dtype=_BF)
     B, N, D = q.shape
     assert D == 512 and vt.shape == (B, 512, N)
     o = torch.empty_like(q)
-    check(_lib.load().ds_wide_attn_bf16(_p(q), _p(k), _p(vt), _p(o), B, N, scale, _stream()), "ds_wide_attn_bf16")
+    check(_lib.load().ds_wide_attn_bf16(_p(q), _p(k), _p(vt), _p(o), B, N, int(n_valid), scale, _stream()),
+          "ds_wide_attn_bf16")
     return o
 
 

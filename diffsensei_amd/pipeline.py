@@ -326,8 +326,6 @@ class DiffSenseiPipeline:
         self.check_inputs(prompt, prompt_2, ip_images, ip_image_embeds, ip_bbox)
         if height % self.vae_scale_factor or width % self.vae_scale_factor:
             raise ValueError(f"`height` and `width` have to be divisible by {self.vae_scale_factor} but are {height} and {width}.")
-        from .engine import UNetEngine                  # fail before any encoder runs, with the engine's own shape rule
-        UNetEngine.level_sizes(self.unet.config, height // self.vae_scale_factor, width // self.vae_scale_factor)
         self._guidance_scale = guidance_scale
         device = self._execution_device
         self.set_ip_scale(ip_scale)

@@ -12,8 +12,9 @@ Layout: NHWC between kernels.  Kernels: `conv_halo_kernel<bf16>` (every 3x3 conv
 `vae_conv_in_kernel` (post_quant_conv + conv_in), `vae_conv_out_kernel`.  No torch arithmetic on the data path: the
 only host-side math is the one-off weight re-layout (and folding the V bias through to_out, see `_pack`).
 
-Shape rules of the kernels: latent height x width a multiple of 16 (any image side that is a multiple of 32 qualifies;
-conv patches at ragged edges are masked), channel widths multiples of 128, mid-block width exactly 512 (SDXL / SD VAE).
+Shape rules of the kernels: any latent height x width (conv patches at ragged edges are masked; the mid-block attention
+pads its token matrices to a multiple of 16 rows and masks the padding keys), channel widths multiples of 128, mid-block
+width exactly 512 (SDXL / SD VAE).
 """
 from __future__ import annotations
 
@@ -199,13 +200,27 @@ class VaeDecoderEngine:
     def _attention(self, x: Tensor, p: str) -> Tensor:
         B, H, W, C = x.shape
         N = H * W
-        h = self._gn(x, f"{p}.group_norm", False).view(B * N, C)
-        q = ops.gemm_bf16(h, self.w[f"{p}.to_q.weight"], self.w[f"{p}.to_q.bias"]).view(B, N, C)
-        k = ops.gemm_bf16(h, self.w[f"{p}.to_k.weight"], self.w[f"{p}.to_k.bias"]).view(B, N, C)
-        vt = ops.gemm_batched_nt_bf16(self.w[f"{p}.to_v.weight"], h.view(B, N, C))          # [B, C, N], bias deferred
-        o = ops.wide_attention_bf16(q, k, vt, 1.0 / math.sqrt(C))
-        out = ops.gemm_bf16(o.view(B * N, C), self.w[f"{p}.to_out.0.weight"], self.w[f"{p}.to_out.0.bias+v"],
-                            residual=x.view(B * N, C))
+        h = self._gn(x, f"{p}.group_norm", False).view(B, N, C)
+        # The bf16 GEMMs take row counts that are multiples of 16.  Other latent sizes (the reference accepts every image
+        # side that is a multiple of 8): the token matrices get zero rows up to the next multiple of 16 - pure copies, the
+        # statistics above were taken on the real tokens - and the attention kernel masks the padding keys.
+        Np = (N + 15) // 16 * 16
+        res = x.view(B, N, C)
+        if Np != N:
+            hp = torch.zeros((B, Np, C), dtype=h.dtype, device=h.device)
+            hp[:, :N] = h
+            rp = torch.zeros((B, Np, C), dtype=x.dtype, device=x.device)
+            rp[:, :N] = res
+            h, res = hp, rp
+        h2 = h.view(B * Np, C)
+        q = ops.gemm_bf16(h2, self.w[f"{p}.to_q.weight"], self.w[f"{p}.to_q.bias"]).view(B, Np, C)
+        k = ops.gemm_bf16(h2, self.w[f"{p}.to_k.weight"], self.w[f"{p}.to_k.bias"]).view(B, Np, C)
+        vt = ops.gemm_batched_nt_bf16(self.w[f"{p}.to_v.weight"], h)                         # [B, C, Np], bias deferred
+        o = ops.wide_attention_bf16(q, k, vt, 1.0 / math.sqrt(C), n_valid=N)
+        out = ops.gemm_bf16(o.view(B * Np, C), self.w[f"{p}.to_out.0.weight"], self.w[f"{p}.to_out.0.bias+v"],
+                            residual=res.reshape(B * Np, C)).view(B, Np, C)
+        if Np != N:
+            out = out[:, :N].contiguous()
         return out.view(B, H, W, C)
 
     # ---- the decode (mirrors AutoencoderKL.decode / Decoder.forward)
@@ -216,8 +231,6 @@ class VaeDecoderEngine:
         if z.dim() != 4 or z.shape[1] != self.config.latent_channels:
             raise ValueError(f"expected latents [B,{self.config.latent_channels},h,w], got {tuple(z.shape)}")
         B, _, h, w = z.shape
-        if (h * w) % 16:
-            raise ValueError(f"latent height x width must be a multiple of 16 (got {h}x{w}): rows of the projection GEMMs")
         # the conv kernel addresses its input with 32-bit element offsets: the widest full-resolution activation
         # ([chunk, 8h, 8w, C1]) bounds how many images go through one launch sequence (7 at 1024^2 -> chunks of 4)
         per_image = (8 * h) * (8 * w) * max(self.config.block_out_channels[1], self.config.block_out_channels[0])

@@ -33,6 +33,8 @@ int ds_device_info(int* cu_count, int* lds_bytes, char* arch_name, int arch_name
  * large problem sizes; every variant of an operator computes the same result (the tests assert torch.equal between them).
  *   "gemm_variant"       0 auto | 1 register-staged only | 2, 7 two-buffer LDS-DMA | 8, 9 one-buffer LDS-DMA |
  *                        3 256x256 ping-pong (gemm_pp_kernel) | 10 halo-patch conv
+ *   "gemm_pp_even"       1 (default) gemm_pp_kernel's persistent grid = ceil(tiles / rounds) blocks, every round full |
+ *                        0 one block per CU with a partial last round
  *   "conv_halo_variant"  0 auto (16x16-pixel blocks from 1024 blocks on) | 1 force conv_halo_kernel (8x16 pixels) |
  *                        2 force conv_halo256_kernel (16x16 pixels)
  *   "attn_variant"       0 auto (64 query rows per wave from Nk >= 2048 and >= 512 blocks on) | 1 force
@@ -76,8 +78,11 @@ int ds_gemm_bf16_batched(const void* x, int64_t ldx, int64_t sx, const void* w, 
 /* GroupNorm (+SiLU) over [B,HW,C]; ws: ds_groupnorm_workspace_bytes(B, C) */
 int ds_groupnorm_bf16(const void* x, void* y, const void* gamma, const void* beta, void* ws, int B, int HW, int C,
                       int groups, float eps, int silu, void* stream);
-/* single-head attention, head dim 512: q,k,o [B,N,512], vt [B,512,N]; N % 8 == 0.  Decoder mid_block.attentions.0 */
-int ds_wide_attn_bf16(const void* q, const void* k, const void* vt, void* o, int B, int N, float scale, void* stream);
+/* single-head attention, head dim 512: q,k,o [B,N,512], vt [B,512,N]; N % 8 == 0.  Decoder mid_block.attentions.0.
+ * n_valid (0 = N): only keys [0, n_valid) take part - rows [n_valid, N) are the caller's padding (latent sizes whose
+ * token count is not a multiple of 16 are padded on the host side of the VAE engine). */
+int ds_wide_attn_bf16(const void* q, const void* k, const void* vt, void* o, int B, int N, int n_valid, float scale,
+                      void* stream);
 /* y[B,H,W,C] = conv_in(post_quant_conv(latents / scaling_factor)); latents fp32 NCHW [B,4,H,W]; post_quant_w [4,4],
  * post_quant_b [4] fp32; w [C,3,3,4], bias [C] bf16 */
 int ds_vae_conv_in_bf16(const float* latents, const float* post_quant_w, const float* post_quant_b, const void* w,
@@ -94,6 +99,13 @@ int ds_vae_conv_out_bf16(const void* x, const void* w, const void* bias, float* 
 int ds_conv3x3_f16(const void* x, const void* w, const void* bias, const void* rowbias, int64_t rowbias_ld,
                    const void* residual, void* y, int B, int H, int W, int Cin, int Cout, int stride, int upsample,
                    void* stream);
+/* Upsample2D with an explicit output size (diffusers resizes to the skip tensor's size when a latent side is not a
+ * multiple of 4 - `forward_upsample_size` [3P]): nearest resize of x [B,H,W,Cin] to Hout x Wout exactly as
+ * F.interpolate(size=..., mode="nearest") indexes it (src = min(floor(dst * float(in)/out), in-1)), then the 3x3 conv.
+ * The resized tensor never exists in HBM. */
+int ds_conv3x3_resize_f16(const void* x, const void* w, const void* bias, const void* rowbias, int64_t rowbias_ld,
+                          const void* residual, void* y, int B, int H, int W, int Cin, int Cout, int Hout, int Wout,
+                          void* stream);
 
 /* GroupNorm (+SiLU) over NHWC; x2 (may be NULL) supplies channels C1..C1+C2 (skip concat).  ws: device scratch
  * of ds_groupnorm_workspace_bytes(B, C1+C2) bytes. */
@@ -260,7 +272,8 @@ int ds_resize_v_norm_u8(const uint8_t* tmp, int Ht, int Wt, const int32_t* first
 enum ds_opcode {
     DS_OP_GEMM = 1,          /* p: x, x2, w, y, bias, rowbias, residual   l: ldx ldx2 ldw ldy ldr sx sx2 sw sy sr
                                 i: M N K K1 epilogue batch rowbias_ld rows_per_group */
-    DS_OP_CONV3X3 = 2,       /* p: x, w, y, bias, rowbias, residual       i: B H W Cin Cout stride upsample rowbias_ld */
+    DS_OP_CONV3X3 = 2,       /* p: x, w, y, bias, rowbias, residual       i: B H W Cin Cout stride upsample rowbias_ld
+                                                                           Hout Wout (upsample only; 0 0 = 2H x 2W) */
     DS_OP_GROUPNORM = 3,     /* p: x1, x2, y, gamma, beta, ws             i: B HW C1 C2 groups silu   f: eps */
     DS_OP_LAYERNORM = 4,     /* p: x, y, gamma, beta                      i: rows C                   f: eps */
     DS_OP_SELF_ATTN = 5,     /* p: q, k, vt, o   l: ldq ldk ldv ldo sq sk so   i: B heads Nq Nk       f: scale */

@@ -160,6 +160,8 @@ class UNetOracle:
         if dialog_bbox is not None:
             x = q(encode_dialog_bbox(x, dialog_bbox.float(), self.sd["dialog_bbox_embedding"]))
         skips = []
+        up_factor = 2 ** sum(1 for st in self.program if st[0] == "upsample")
+        forward_upsample_size = any(d % up_factor != 0 for d in sample.shape[-2:])
         for st in self.program:      # reference src/models/unet.py:244-332, flattened by oracle/unet_topology_ref.py
             op = st[0]
             if op == "push":
@@ -174,7 +176,12 @@ class UNetOracle:
             elif op == "downsample":
                 x = self._conv(x, st[1], stride=2)
             elif op == "upsample":
-                x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+                # diffusers: when a latent side is not a multiple of 2^(number of upsamplers) the forward passes
+                # `upsample_size = down_block_res_samples[-1].shape[2:]` and Upsample2D resizes to it [3P]
+                if forward_upsample_size:
+                    x = F.interpolate(x, size=tuple(skips[-1].shape[-2:]), mode="nearest")
+                else:
+                    x = F.interpolate(x, scale_factor=2.0, mode="nearest")
                 x = self._conv(x, st[1])
             else:
                 raise ValueError(st)

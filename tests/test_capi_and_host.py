@@ -154,8 +154,16 @@ def test_plan_builds_on_host_for_tiny_config(hip_lib):
     assert eng.step_plan.n == eng.forward_plan.n + 2
     assert pk.kv_total == sum(a.channels * a.depth for a in pk.attns)
     assert pk.temb_total == sum(r.cout for r in pk.resnets)
+    # any latent size builds, like the reference (image sides that are multiples of 8): levels halve with ceil, the
+    # upsamplers resize to the skip's size, V^T rows are padded to 8 keys
+    odd = UNetEngine(pk, 2, 18, 13)
+    assert odd.hw == [(18, 13), (9, 7), (5, 4)]
+    ups = [op for op in odd.forward_ops if op.code == 2 and op.i[6] == 1]          # CONV3X3 with the upsample flag
+    assert [(op.i[1], op.i[2], op.i[8], op.i[9]) for op in ups] == [(5, 4, 9, 7), (9, 7, 18, 13)]
+    att = [op for op in odd.forward_ops if op.code == 5]                            # SELF_ATTN: ldv = N rounded up to 8
+    assert {(op.i[2], op.l[2]) for op in att} == {(63, 64), (20, 24)}
     with pytest.raises(ValueError):
-        UNetEngine(pk, 2, 18, 16)
+        UNetEngine(pk, 2, 0, 16)
 
 
 def test_committed_bench_line_follows_the_contract():

@@ -80,8 +80,10 @@ def test_self_attention_fp8_exact_on_an_e4m3_lattice(hip_lib, B, heads, N):
                                              (1, 20, 1024, 1.0), (1, 1, 64, 1.0)])
 def test_self_attention_fp8_vs_sdpa(hip_lib, B, heads, N, sharp):
     """White-noise Q, K, V is the worst case for a 3-bit mantissa: the attention output of i.i.d. values is itself a
-    random-walk sum, so the 2^-4 relative rounding of P and V does not average out (measured 5.1-5.8e-2; the fp16 kernel:
-    2.9e-4).  Stated tolerance: relative L2 <= 7e-2 here, <= 1e-2 when V carries a coherent signal (next test)."""
+    random-walk sum, so the 2^-4 relative rounding of P and V does not average out (measured 5.1-5.8e-2 at unit-variance
+    q, k; the fp16 kernel: 2.9e-4).  The logit error grows with |q||k| (e4m3 rounds each factor to 3.6 % rms), so SHARP
+    white-noise attention (q, k scaled 2.5x: logit std ~6) measures 1.1e-1.  Stated tolerance: relative L2 <= 7e-2 at unit
+    scale, <= 1.5e-1 at 2.5x, <= 1e-2 when V carries a coherent signal (next test); exact on an e4m3 lattice (above)."""
     from diffsensei_amd import ops
     g = torch.Generator().manual_seed(B + heads + N)
     C = heads * 64
@@ -93,9 +95,10 @@ def test_self_attention_fp8_vs_sdpa(hip_lib, B, heads, N, sharp):
     assert torch.isfinite(y).all()
     e_ref = _rel(y, ref)
     print(f"fp8 attention B={B} h={heads} N={N}: rel-L2 vs fp32 SDPA {e_ref:.3e}")
-    assert e_ref <= 7e-2, e_ref
+    tol = 7e-2 if sharp == 1.0 else 1.5e-1
+    assert e_ref <= tol, e_ref
     y16 = ops.self_attention(q.to(DEV), k.to(DEV), vt.to(DEV), heads)
-    assert _rel(y, y16) <= 7e-2
+    assert _rel(y, y16) <= tol
 
 
 def test_self_attention_fp8_coherent_values(hip_lib):

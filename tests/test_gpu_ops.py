@@ -273,6 +273,40 @@ def test_conv_halo256_bf16(hip_lib, B, H, W, Cin, Cout, up):
     assert torch.equal(out[1], out[2])
 
 
+@pytest.mark.parametrize("B,H,W,Ho,Wo,Cin,Cout", [(2, 5, 4, 9, 7, 128, 64), (1, 9, 7, 18, 13, 64, 128), (2, 16, 16, 31, 32, 64, 64),
+                                                   (1, 17, 33, 33, 65, 128, 192), (3, 8, 8, 16, 16, 64, 64)])
+def test_conv3x3_resize_to_explicit_size(hip_lib, B, H, W, Ho, Wo, Cin, Cout):
+    """Upsample2D with `output_size` (diffusers `forward_upsample_size`: latent sides that are not multiples of 4): nearest
+    resize to an explicit size with F.interpolate's index rule, then the 3x3 conv - fused, in every conv kernel family
+    (halo 8x16, halo 16x16, LDS-DMA gather, register-staged) with bit-identical results between the two halo kernels."""
+    from diffsensei_amd import _lib
+    ops = _ops(hip_lib)
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(H * W + Ho + Cin)
+    x = _r((B, Cin, H, W), g)
+    w, b = _r((Cout, Cin, 3, 3), g, 1 / math.sqrt(9 * Cin)), _r((Cout,), g)
+    ref = F.conv2d(F.interpolate(x.float(), size=(Ho, Wo), mode="nearest"), w.float(), b.float(), padding=1)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    wd = w.permute(0, 2, 3, 1).contiguous().to(DEV)
+    outs = {}
+    try:
+        for name, opt, val in (("halo8x16", b"conv_halo_variant", 1), ("halo16x16", b"conv_halo_variant", 2),
+                               ("glds", b"gemm_variant", 2), ("regs", b"gemm_variant", 1)):
+            lib.ds_set_option(b"conv_halo_variant", 0)
+            lib.ds_set_option(b"gemm_variant", 0)
+            assert lib.ds_set_option(opt, val) == 0
+            outs[name] = ops.conv3x3(xd, wd, b.to(DEV), out_size=(Ho, Wo))
+    finally:
+        lib.ds_set_option(b"conv_halo_variant", 0)
+        lib.ds_set_option(b"gemm_variant", 0)
+    for name, y in outs.items():
+        assert y.shape == (B, Ho, Wo, Cout)
+        _close(y.permute(0, 3, 1, 2), ref, what=f"resize conv {name}")
+    assert torch.equal(outs["halo8x16"], outs["halo16x16"])
+    if (Ho, Wo) == (2 * H, 2 * W):      # the explicit size 2H x 2W is the plain upsample
+        assert torch.equal(outs["halo8x16"], ops.conv3x3(xd, wd, b.to(DEV), upsample=True))
+
+
 def test_conv_in_dialog_and_conv_out(hip_lib):
     ops = _ops(hip_lib)
     g = torch.Generator().manual_seed(11)
@@ -384,6 +418,32 @@ def test_self_attention_64row_natural_dispatch(hip_lib):
         lib.ds_set_option(b"attn_variant", 0)
     _close(auto, ref, tol=3e-3, what="self-attn auto N=4096")
     assert torch.equal(auto, small)
+
+
+@pytest.mark.parametrize("B,heads,N", [(2, 2, 63), (1, 4, 99), (1, 2, 1001), (2, 1, 20), (1, 3, 2317)])
+def test_self_attention_any_token_count(hip_lib, B, heads, N):
+    """Token counts that are not multiples of 8 (odd latent sizes): V^T rows padded to 8 keys with arbitrary finite
+    content in the padding (here: large values, which must not leak), both kernel variants."""
+    from diffsensei_amd import _lib
+    ops = _ops(hip_lib)
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(B + heads + N)
+    C = heads * 64
+    q, k, v = _r((B, N, C), g), _r((B, N, C), g), _r((B, N, C), g)
+    hs = lambda t: t.float().view(B, N, heads, 64).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(hs(q), hs(k), hs(v)).transpose(1, 2).reshape(B, N, C)
+    Np = (N + 7) // 8 * 8
+    vt = torch.full((B, heads, 64, Np), 100.0, dtype=torch.float16)
+    vt[..., :N] = v.view(B, N, heads, 64).permute(0, 2, 3, 1)
+    out = {}
+    try:
+        for var in (1, 2):
+            lib.ds_set_option(b"attn_variant", var)
+            out[var] = ops.self_attention(q.to(DEV), k.to(DEV), vt.to(DEV), heads)
+    finally:
+        lib.ds_set_option(b"attn_variant", 0)
+    _close(out[1], ref, tol=3e-3, what="ragged self-attn")
+    assert torch.equal(out[1], out[2])
 
 
 def test_self_attention_forced_rescale(hip_lib):

@@ -130,6 +130,26 @@ def test_guidance_scale_one_uses_the_negative_boxes_like_the_reference(pipe):
     assert _rel(out, ref) <= 3e-2, _rel(out, ref)
 
 
+def test_call_at_a_size_that_is_only_a_multiple_of_8(pipe):
+    """136 x 104 px (latents 17 x 13): the reference's sliders step by 8; whole `__call__` incl. the HIP VAE to PIL."""
+    from diffsensei_amd.vae import VaeConfig, VaeDecoderEngine
+    p, cfg, sd, rs, clip, mae, common = pipe
+    kw = {k: v for k, v in common.items() if k not in ("output_type", "height", "width")}
+    kw.update(ip_images=[], ip_bbox=[], dialog_bbox=[[0.1, 0.1, 0.5, 0.4]], height=136, width=104)
+    lat0 = torch.randn(1, 4, 17, 13, generator=torch.Generator().manual_seed(2)).half()
+    lat = p(latents=lat0.clone(), output_type="latent", **kw).images
+    assert lat.shape == (1, 4, 17, 13) and torch.isfinite(lat).all()
+    assert torch.equal(lat, p(latents=lat0.clone(), output_type="latent", **kw).images)
+    p.vae = VaeDecoderEngine.init_random(VaeConfig(), 3, DEV)
+    try:
+        pil = p(latents=lat0.clone(), **kw).images
+    finally:
+        p.vae = None
+    assert pil[0].size == (104, 136)
+    with pytest.raises(ValueError):
+        p(latents=lat0.clone(), **dict(kw, height=130))          # not a multiple of 8: refused like diffusers does
+
+
 def test_call_returns_images_through_the_hip_vae(pipe):
     """Whole `__call__` to images (reference :339-367): VAE decode + denormalize on the bf16 HIP decoder; "pt"/"np"/"pil"."""
     from PIL import Image

@@ -76,6 +76,23 @@ def test_unet_forward_vs_oracle(tiny, H, W):
     assert torch.equal(out, out4)
 
 
+@pytest.mark.parametrize("H,W", [(18, 13), (7, 9), (33, 20), (17, 17)])
+def test_unet_forward_any_latent_size(tiny, H, W):
+    """The reference takes every image side that is a multiple of 8 (demo sliders step 8): latent sides need not be
+    multiples of 4.  Downsample2D gives ceil(h/2); the up path resizes to the skip's size (diffusers
+    `forward_upsample_size`), token counts need not be multiples of 8.  HIP plan vs the oracle, same tolerances."""
+    cfg, sd, model, o16, o32 = tiny
+    x, enc, te, tid, bbox, db = _inputs(cfg, 2, H, W, seed=H * 100 + W)
+    model._attn_processors = {"x": type("P", (), {"scale": 0.6})()}
+    o16.ip_scale = 0.6
+    out = model(x.to(DEV), 801.0, enc.to(DEV), cross_attention_kwargs={"bbox": bbox, "aspect_ratio": H / W},
+                added_cond_kwargs={"text_embeds": te, "time_ids": tid}, dialog_bbox=db).sample
+    with torch.no_grad():
+        r16 = o16.forward(x, 801.0, enc, te, tid, bbox, H / W, db)
+    assert out.shape == x.shape and torch.isfinite(out).all()
+    assert _rel(out, r16) <= 2e-2, _rel(out, r16)
+
+
 @pytest.mark.parametrize("kind", ["euler", "ddim"])
 def test_sampling_loop_vs_oracle(tiny, kind):
     """4 fused steps (UNet + CFG + scheduler) on the GPU vs oracle/pipeline_ref.sample_loop, eager and hipGraph."""

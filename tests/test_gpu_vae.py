@@ -122,6 +122,13 @@ def test_decoder_engine_vs_oracle(hip_lib):
     got2 = eng.decode(lat2.to(DEV), return_dict=False, scaling_factor=cfg.scaling_factor)[0]
     assert got2.shape == ref2.shape == (1, 3, 96, 160)
     assert ((got2.cpu() - ref2).norm() / ref2.norm()).item() <= 3e-2
+    # any latent size (the reference accepts every image side that is a multiple of 8): 13 x 9 = 117 tokens, not a multiple
+    # of 16 -> the mid-block attention pads its token matrices and masks the padding keys
+    lat3 = torch.randn(2, 4, 13, 9, generator=g) * 0.9
+    ref3 = vae_decode(sd, lat3 / cfg.scaling_factor, cfg.layers_per_block, cfg.norm_num_groups, cfg.eps)
+    got3 = eng.decode(lat3.to(DEV), return_dict=False, scaling_factor=cfg.scaling_factor)[0]
+    assert got3.shape == ref3.shape == (2, 3, 104, 72)
+    assert ((got3.cpu() - ref3).norm() / ref3.norm()).item() <= 3e-2
     with pytest.raises(ValueError):
-        eng.decode(torch.zeros(1, 4, 6, 10, device=DEV))
+        eng.decode(torch.zeros(1, 3, 6, 10, device=DEV))
 

@@ -222,3 +222,18 @@ def test_scheduler_known_answers():
     e50.set_timesteps(50)
     assert abs(e50.sigmas[0] - sig[981]) < 1e-4 and 12.5 < e50.init_noise_sigma < 13.5
     assert VaeConfig().scaling_factor == 0.13025
+
+
+def test_oracle_handles_latent_sizes_that_are_not_multiples_of_four():
+    """diffusers `forward_upsample_size`: the up path resizes to the skip tensors' sizes; the oracle follows it."""
+    cfg = tiny_config()
+    sd = random_state_dict(cfg, 0)
+    u = UNetOracle(cfg, sd)
+    x, enc, te, tid, bbox, db = _inputs(cfg, 1, 18, 13)
+    with torch.no_grad():
+        y = u.forward(x, 500.0, enc, te, tid, bbox, 18 / 13, db)
+        assert y.shape == x.shape and torch.isfinite(y).all()
+        # multiples of 4: resizing to the skip's size and plain x2 are the same thing
+        x2, enc2, te2, tid2, bbox2, db2 = _inputs(cfg, 1, 16, 12)
+        a = u.forward(x2, 500.0, enc2, te2, tid2, bbox2, 16 / 12, db2)
+    assert a.shape == x2.shape
