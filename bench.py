@@ -131,16 +131,10 @@ def synthetic_request(device, size, seed, output_type="pt", refs=2):
         generator=torch.Generator().manual_seed(seed), output_type=output_type)
 
 
-def build_mllm_agent(device, seed=7):
-    """The agent of scripts/demo/gradio.py:255-270 at LLaMA-2-13B dimensions with seeded random weights, and a synthetic
-    tokenised instruction: [bos, 40 text ids, <img>, 64 placeholders, </img>, 3 text ids, <img>] - the trailing <img>
-    starts the forced 64-token image block (random weights never emit it on their own), 66 new tokens in total."""
-    from diffsensei_amd.mllm import (ContinuousLVLM, LlamaConfig, LlamaDecodeEngine, QwenResampler,
-                                     random_llama_state_dict, random_qwen_resampler_state_dict)
-    cfg = LlamaConfig()
-    llm = LlamaDecodeEngine(cfg, random_llama_state_dict(cfg, device, seed), device, max_positions=256, max_new_tokens=128)
-    res_in = QwenResampler(random_qwen_resampler_state_dict(8, cfg.hidden_size, 2048, device, seed + 1), 32, device)
-    res_out = QwenResampler(random_qwen_resampler_state_dict(8, 2048, cfg.hidden_size, device, seed + 2), 32, device)
+def mllm_synthetic_inputs(seed=7):
+    """Synthetic tokenised instruction of scripts/demo/gradio.py:36-60 (no tokenizer files offline):
+    [bos, 40 text ids, <img>, 64 placeholders, </img>, 3 text ids, <img>] - the trailing <img> starts the forced 64-token
+    image block (random weights never emit it on their own), 66 new tokens in total.  Pure host code (CPU-tested)."""
     boi = 32100
     chain = [boi] + [boi + 1 + i for i in range(64)] + [boi + 65]
     g = torch.Generator().manual_seed(seed)
@@ -148,8 +142,18 @@ def build_mllm_agent(device, seed=7):
     ids = [1] + text(40) + chain + text(3) + [boi]
     mask = torch.zeros(len(ids), dtype=torch.bool)
     mask[42:42 + 64] = True
-    return ContinuousLVLM(llm, res_in, res_out), {"input_ids": torch.tensor(ids), "ids_cmp_mask": mask, "chain": chain,
-                                                  "max_new": 66}
+    return {"input_ids": torch.tensor(ids), "ids_cmp_mask": mask, "chain": chain, "max_new": 66}
+
+
+def build_mllm_agent(device, seed=7):
+    """The agent of scripts/demo/gradio.py:255-270 at LLaMA-2-13B dimensions with seeded random weights."""
+    from diffsensei_amd.mllm import (ContinuousLVLM, LlamaConfig, LlamaDecodeEngine, QwenResampler,
+                                     random_llama_state_dict, random_qwen_resampler_state_dict)
+    cfg = LlamaConfig()
+    llm = LlamaDecodeEngine(cfg, random_llama_state_dict(cfg, device, seed), device, max_positions=256, max_new_tokens=128)
+    res_in = QwenResampler(random_qwen_resampler_state_dict(8, cfg.hidden_size, 2048, device, seed + 1), 32, device)
+    res_out = QwenResampler(random_qwen_resampler_state_dict(8, 2048, cfg.hidden_size, device, seed + 2), 32, device)
+    return ContinuousLVLM(llm, res_in, res_out), mllm_synthetic_inputs(seed)
 
 
 def gpu_parity_on_oracle_state(pipe, st):
@@ -317,14 +321,17 @@ def main():
                     "algorithmic_tflop_per_forward": round(d["flops"] / 1e12, 3)}
         # HBM-side traffic comes from separate rocprofv3 --pmc passes (tools/gpu_pmc_pp.sh), committed under profiles/:
         # it cannot be collected inside this process.  Attached only when it was measured for this very kernel.
-        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_gemm_pp.json")
-        if os.path.exists(pmc_path):
+        for pmc_name in ("r02_pmc_gemm_pp.json", "r01_pmc_gemm_pp.json"):      # newest committed pass for this kernel
+            pmc_path = os.path.join(ROOT, "profiles", pmc_name)
+            if not os.path.exists(pmc_path):
+                continue
             pmc = json.load(open(pmc_path))
             if pmc.get("kernel") == name:
                 roofline["traffic"] = pmc["traffic_bytes_per_launch"]
                 roofline["traffic_detail"] = {"unit": "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, L2 fabric side)",
                                               "launch": pmc["shape"], "algorithmic_bytes": pmc["algorithmic_bytes_per_launch"],
-                                              "l2_hit_rate": pmc["l2_hit_rate"], "source": "profiles/r01_pmc_gemm_pp.json"}
+                                              "l2_hit_rate": pmc["l2_hit_rate"], "source": "profiles/" + pmc_name}
+                break
         tot_fl = sum(v["flops"] for v in table.values())
         extra = {"unet_forward_ms_event_sum": round(fwd_ms, 3),
                  "unet_forward_algorithmic_tflop": round(tot_fl / 1e12, 2),

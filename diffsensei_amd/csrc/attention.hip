@@ -580,7 +580,7 @@ int ds_launch_ip_attn(const IPAttnParams& p0, hipStream_t stream) {
     // walk several query tiles per block once there are plenty of blocks (amortises the K/V panel staging)
     const int tiles = (p.N + 127) / 128;
     int qt = 1;
-    while (qt < 4 && (long)((tiles + 2 * qt - 1) / (2 * qt)) * p.B * p.heads >= g_ip_min_blocks) qt *= 2;
+    while (qt < 8 && (long)((tiles + 2 * qt - 1) / (2 * qt)) * p.B * p.heads >= g_ip_min_blocks) qt *= 2;
     dim3 grid((tiles + qt - 1) / qt, p.B * p.heads);
     hipLaunchKernelGGL(ip_attn_kernel, grid, dim3(256), 0, stream, p, qt);
     DS_LAUNCH_CHECK();

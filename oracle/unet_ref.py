@@ -158,7 +158,9 @@ class UNetOracle:
         emb_act = q(F.silu(emb))
         x = self._conv(sample, "conv_in")
         if dialog_bbox is not None:
-            x = q(encode_dialog_bbox(x, dialog_bbox.float(), self.sd["dialog_bbox_embedding"]))
+            # the box tensor keeps its own dtype: the reference holds it in the UNet's dtype (fp16, prepare_dialog_bbox) and
+            # `int(coord * width)` is evaluated in that dtype - 0.65 * 20 is 13 in fp16 and 12.998 in fp32
+            x = q(encode_dialog_bbox(x, dialog_bbox, self.sd["dialog_bbox_embedding"]))
         skips = []
         up_factor = 2 ** sum(1 for st in self.program if st[0] == "upsample")
         forward_upsample_size = any(d % up_factor != 0 for d in sample.shape[-2:])

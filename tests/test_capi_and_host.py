@@ -181,3 +181,24 @@ def test_committed_bench_line_follows_the_contract():
     assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["traffic"]
     c = line["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+
+
+def test_bench_mllm_request_path_contract():
+    """Host side of `bench.py --mllm` (BASELINE config 3; its only full-size run crashed in round 1 on a kernel shape
+    limit): the synthetic instruction is consistent with what `ContinuousLVLM.generate` and the engine capacities expect,
+    and every matrix width of the agent at LLaMA-2-13B / resampler dimensions is one the GPU suite exercises."""
+    import bench
+    from diffsensei_amd import mllm as M
+    inp = bench.mllm_synthetic_inputs()
+    ids, mask, chain = inp["input_ids"], inp["ids_cmp_mask"], inp["chain"]
+    assert ids.shape == mask.shape == (111,) and int(mask.sum()) == 64
+    assert ids[0] == 1 and ids[-1] == chain[0] and ids[41] == chain[0] and ids[106] == chain[-1]
+    assert ids[42:106].tolist() == chain[1:-1] and bool(mask[42:106].all())
+    assert len(chain) == 66 and inp["max_new"] == 66
+    cfg = M.LlamaConfig()
+    assert len(ids) + inp["max_new"] <= 256 and inp["max_new"] <= 128            # build_mllm_agent's cache / token capacity
+    assert M.image_token_ids(None, 64, chain) == (chain, chain[-1], chain[1:-1])
+    # widths that reach ds_layernorm_f16 / the GEMV kernels in the agent: hidden 5120, resampler dims 5120 / 2048 -
+    # tests/test_gpu_ops.py::test_layernorm covers C up to 8192, test_gpu_mllm.py runs both resamplers at these dims
+    assert (cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads) == (5120, 13824, 40)
+    assert max(cfg.hidden_size, 2048) <= 8192
