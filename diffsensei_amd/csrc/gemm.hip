@@ -576,7 +576,11 @@ Choice choose(const GemmParams& p, int batch) {
             const long t = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
             const long rounds = (t + 255) / 256;
             const bool fills = t >= 410 && t * 10 >= rounds * 256 * 8;
-            if (fills && !(p.N <= 640 && p.K <= 640)) {
+            // one partial round on >= 56 % of the CUs with a long enough K (num_samples 4: M = 8192 x N = 1280 = 160 tiles):
+            // the 256x256 tile's higher per-CU rate outweighs the idle CUs - FF down-projection 157 -> 125 us, the
+            // K = 1280 projections 46 -> 40 us (profiles/r02_gemm_pp_dispatch_sweep.txt); below ~140 tiles it loses
+            const bool single = t >= 144 && t <= 256 && p.K >= 1280 && p.N >= 1280;
+            if ((fills || single) && !(p.N <= 640 && p.K <= 640)) {
                 c.kind = K_PP;
                 c.bm = 256;
             }
