@@ -568,19 +568,21 @@ Choice choose(const GemmParams& p, int batch) {
         c.kind = K_GLDS1;
     } else {
         c.kind = (p.K >= 4096 && p.N <= 2048) ? K_GLDS2 : K_GLDS1;
-        // 256 x 256 persistent ping-pong kernel (gemm_pp.hip): one block per CU, so it only pays when the tile count
-        // fills whole rounds of the 256 CUs (>= 2 rounds, last round >= 80 % full) and the problem is not the
-        // short-K, narrow-N projection (profiles/r01_gemm_pp_microbench.txt: +6..20 % on the FF up-projections, the
-        // fused q|k projection and the level-1 FF down-projection; a loss at N = 1280 x M = 16384 = 1.25 rounds).
+        // 256 x 256 persistent ping-pong kernel (gemm_pp.hip), grid = ceil(tiles / rounds) blocks (every round full).  It
+        // pays when the useful fraction of the rounds x 256 CU-tiles it occupies is high enough (interleaved A/B at UNet
+        // batches 6..16, profiles/r02_pp_dispatch_ab.txt; whole rounds: profiles/r01_gemm_pp_microbench.txt):
+        //   * more than one round: >= 75 % useful (M = 10240 x N = 2560 = 400 tiles: 77 us vs 89 us), or >= 60 % with a
+        //     long K (>= 4096: the FF down-projection at 320 tiles: 229 us vs 244 us); N = 640 counts its 17 % column padding;
+        //   * a single partial round: >= 144 tiles with K, N >= 1280 (num_samples 4: 160 tiles, 111 us vs 145 us; 120 tiles
+        //     lose: 115 us vs 90 us);
+        //   * never the short-K, narrow-N projection (N, K <= 640: +6..20 % for the 128 x 128 kernels).
         if (batch == 1 && ds_gemm_pp_applicable(p)) {
             const long t = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
             const long rounds = (t + 255) / 256;
-            const bool fills = t >= 410 && t * 10 >= rounds * 256 * 8;
-            // one partial round on >= 56 % of the CUs with a long enough K (num_samples 4: M = 8192 x N = 1280 = 160 tiles):
-            // the 256x256 tile's higher per-CU rate outweighs the idle CUs - FF down-projection 157 -> 125 us, the
-            // K = 1280 projections 46 -> 40 us (profiles/r02_gemm_pp_dispatch_sweep.txt); below ~140 tiles it loses
+            const double useful = (double)p.M * p.N / ((double)rounds * 256 * 65536);
+            const bool multi = t > 256 && (useful >= 0.75 || (p.K >= 4096 && useful >= 0.6));
             const bool single = t >= 144 && t <= 256 && p.K >= 1280 && p.N >= 1280;
-            if ((fills || single) && !(p.N <= 640 && p.K <= 640)) {
+            if ((multi || single) && !(p.N <= 640 && p.K <= 640)) {
                 c.kind = K_PP;
                 c.bm = 256;
             }
