@@ -156,7 +156,7 @@ def build_mllm_agent(device, seed=7):
     return ContinuousLVLM(llm, res_in, res_out), mllm_synthetic_inputs(seed)
 
 
-def gpu_parity_on_oracle_state(pipe, st):
+def gpu_parity_on_oracle_state(pipe, st, ref_image=None):
     """BASELINE configs[0] (512x512, 20-step Euler, text-only, batch 1) on the HIP engine with the weights, initial latents
     and conditioning the CPU oracle has just been timed on (`north_star`: "outputs match the reference CPU path on identical
     seeds/latents within stated fp16 tolerance").  Compares the latents after the oracle's measured steps; the tolerance,
@@ -178,10 +178,17 @@ def gpu_parity_on_oracle_state(pipe, st):
     assert torch.isfinite(got).all()
     rel = ((got - ref).norm() / ref.norm()).item()
     moved = ((ref - st["latents0"].float()).norm() / ref.norm()).item()
-    return {"config": "C1: 512x512, 20-step Euler, text-only, batch 1 (BASELINE.json configs[0])", "steps": st["steps_done"],
-            "rel_l2": round(rel, 6), "max_abs": round((got - ref).abs().max().item(), 5), "tolerance": 3e-2,
-            "latents_moved_rel": round(moved, 4),
-            "vs": "oracle/pipeline_ref (fp32 torch, CPU) on the same weights / latents / conditioning"}
+    out = {"config": "C1: 512x512, 20-step Euler, text-only, batch 1 (BASELINE.json configs[0])", "steps": st["steps_done"],
+           "rel_l2": round(rel, 6), "max_abs": round((got - ref).abs().max().item(), 5),
+           "tolerance": 3e-2 if st["steps_done"] <= 4 else 6e-2,      # fp16 storage vs pure fp32 compounds over 20 CFG steps
+           "latents_moved_rel": round(moved, 4),
+           "vs": "oracle/pipeline_ref (fp32 torch, CPU) on the same weights / latents / conditioning"}
+    if ref_image is not None:      # the decoded image too: bf16 HIP decoder on the GPU's latents vs the fp32 oracle decode
+        img = pipe.vae.decode(eng.latents, return_dict=False, scaling_factor=pipe.vae.config.scaling_factor)[0].float().cpu()
+        out["image_rel_l2"] = round(((img - ref_image).norm() / ref_image.norm()).item(), 6)
+        out["image_tolerance"] = 5e-2
+        assert out["image_rel_l2"] <= out["image_tolerance"], out
+    return out
 
 
 def profile_forward_ops(pipe, reps=3):
@@ -239,6 +246,10 @@ def main():
                          "instruction (BASELINE config 5: --size 2048 --refs 4 --attn fp8 --num-samples 1)")
     ap.add_argument("--no-dialog", action="store_true", help="no dialog boxes (BASELINE config 2)")
     ap.add_argument("--no-parity", action="store_true", help="skip the GPU-vs-oracle parity run on BASELINE configs[0]")
+    ap.add_argument("--cpu-full", action="store_true",
+                    help="cpu_baseline runs ALL 20 Euler steps of BASELINE configs[0] plus the fp32 VAE decode on the host "
+                         "cores (~6 min on the GPU box) instead of the bounded 2-step sample, and `parity` compares the "
+                         "20-step latents and the decoded image (SURVEY 8d: the whole call, not an extrapolation)")
     ap.add_argument("--mllm", action="store_true",
                     help="BASELINE config 3: run the MLLM pre-pass (LLaMA-2-13B dims, 66 new tokens) inside the timed "
                          "region and feed its ip_image_embeds to the sampler (scripts/demo/gradio.py:85-129); "
@@ -347,12 +358,29 @@ def main():
         from diffsensei_amd.unet_config import sdxl_config
         from oracle.pipeline_ref import time_cpu_baseline
         sd_cpu = {k: v.float().cpu() for k, v in pipe.unet._sd.items()}
-        cpu_baseline = time_cpu_baseline(sdxl_config(), sd_cpu, 512, 512, 20, budget_s=25.0, keep_state=True, min_steps=2)
+        cpu_baseline = time_cpu_baseline(sdxl_config(), sd_cpu, 512, 512, 20, budget_s=1e9 if args.cpu_full else 25.0,
+                                         keep_state=True, min_steps=20 if args.cpu_full else 2)
         state = cpu_baseline.pop("_state")
-        cpu_baseline["value"] = round(cpu_baseline["value"], 6)
         del sd_cpu
+        ref_image = None
+        if args.cpu_full and pipe.vae is not None:      # + the VAE decode, fp32 on the host (the reference upcasts it to fp32)
+            from diffsensei_amd.vae import VaeConfig, random_state_dict as vae_random_sd
+            from oracle.vae_ref import vae_decode
+            vcfg = VaeConfig()
+            vsd = {k: v.to(torch.bfloat16).float() for k, v in vae_random_sd(vcfg, 2).items()}   # build_pipeline: seed + 2
+            t0 = time.perf_counter()
+            with torch.no_grad():
+                ref_image = vae_decode(vsd, state["latents"].float() / vcfg.scaling_factor, vcfg.layers_per_block,
+                                       vcfg.norm_num_groups, vcfg.eps)
+            t_vae = time.perf_counter() - t0
+            t_unet = 1.0 / cpu_baseline["value"]
+            cpu_baseline["value"] = 1.0 / (t_unet + t_vae)
+            cpu_baseline["sample"] = (f"ALL 20 Euler steps of a 512x512 text-only panel (CFG batch 2; {t_unet:.1f} s) + the VAE "
+                                      f"decode ({t_vae:.1f} s), fp32 torch oracle, nothing extrapolated; prompt embeddings given "
+                                      f"(text encoders not timed)")
+        cpu_baseline["value"] = round(cpu_baseline["value"], 6)
         if not args.no_parity:
-            parity = gpu_parity_on_oracle_state(pipe, state)
+            parity = gpu_parity_on_oracle_state(pipe, state, ref_image)
             log("parity:", json.dumps(parity))
             assert parity["rel_l2"] <= parity["tolerance"], \
                 f"GPU latents differ from the CPU oracle on BASELINE configs[0]: {parity}"

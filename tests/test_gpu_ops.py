@@ -328,6 +328,33 @@ def test_conv_in_dialog_and_conv_out(hip_lib):
     _close(y.permute(0, 3, 1, 2), ref, what="conv_out")
 
 
+def test_conv_in_out_grid_stride_sizes(hip_lib):
+    """Sizes beyond the 2048-block cap of conv_in / conv_out (batch-32 shapes walk pixels grid-stride so the weight panel is
+    staged once per resident block): same numerics, dialog boxes included."""
+    ops = _ops(hip_lib)
+    g = torch.Generator().manual_seed(12)
+    B, H, W, C = 6, 128, 96, 64
+    x, w, b, emb = _r((B, 4, H, W), g), _r((C, 4, 3, 3), g, 1 / 6), _r((C,), g), _r((C,), g)
+    boxes = torch.zeros(B, 2, 4, dtype=torch.int32)
+    boxes[1, 0] = torch.tensor([3, 5, 60, 40])
+    boxes[5, 1] = torch.tensor([70, 100, 96, 128])
+    ref = F.conv2d(x.float(), w.float(), b.float(), padding=1).half().float()
+    mask = torch.zeros(B, 1, H, W)
+    for i in range(B):
+        for (x1, y1, x2, y2) in boxes[i].tolist():
+            mask[i, :, y1:y2, x1:x2] = 1
+    ref = ref + mask * emb.float()[None, :, None, None]
+    y = ops.conv_in_dialog(x.permute(0, 2, 3, 1).contiguous().to(DEV), w.permute(0, 2, 3, 1).contiguous().to(DEV),
+                           b.to(DEV), boxes.to(DEV), emb.to(DEV))
+    assert B * H * W * (C // 8) // 256 > 2048
+    _close(y.permute(0, 3, 1, 2), ref, tol=1e-3, what="conv_in grid-stride")
+    xo, wo, bo = _r((B, C, H, W), g), _r((4, C, 3, 3), g, 1 / math.sqrt(9 * C)), _r((4,), g)
+    ref = F.conv2d(xo.float(), wo.float(), bo.float(), padding=1)
+    y = ops.conv_out(xo.permute(0, 2, 3, 1).contiguous().to(DEV), wo.permute(0, 2, 3, 1).contiguous().to(DEV), bo.to(DEV))
+    assert B * H * W // 32 > 2048
+    _close(y.permute(0, 3, 1, 2), ref, what="conv_out grid-stride")
+
+
 # ------------------------------------------------------------------------------------------------ norms
 @pytest.mark.parametrize("B,HW,C1,C2,silu,eps", [(2, 256, 64, 0, True, 1e-5), (2, 1024, 320, 0, True, 1e-5),
                                                   (1, 333, 128, 64, True, 1e-5), (2, 4096, 640, 0, False, 1e-6),
