@@ -164,3 +164,70 @@ def test_mllm_weight_broadcast_world2():
     # every matrix of the model is in the list: 2 layers x (3+1+2+1) H-by-* blocks + embeddings + lm_head + final gain
     assert n0 == n1 == 2 * (3 * 128 * 128 + 128 * 128 + 2 * 256 * 128 + 128 * 256) + 2 * 96 * 128 + 128
     assert before0 != before1 and after0 == before0 and after1 == after0 and sample0 == sample1
+
+
+def _pipeline_bcast_worker(rank, world, port, q):
+    """`broadcast_pipeline` over a pipeline-shaped object: every engine's tensors() + the extra (MLLM-agent-like) module,
+    rank 1 starts from other values, `weights_changed()` is called, and the cross-rank checksum passes; a replica that is
+    then perturbed on one rank makes `verify_replicas` raise on EVERY rank."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from diffsensei_amd.distributed import broadcast_pipeline, init_from_env, tensors_checksum, verify_replicas
+    init_from_env("gloo")
+    g = torch.Generator().manual_seed(5 + 100 * rank)
+
+    class Engine:
+        def __init__(self, shapes, dtype):
+            self.ts = [torch.randn(s, generator=g).to(dtype) for s in shapes]
+
+        def tensors(self):
+            return self.ts
+
+    class UNet(Engine):
+        changed = 0
+
+        def weights_changed(self):
+            self.changed += 1
+
+    class Pipe:
+        def __init__(self):
+            self.unet = UNet([(64, 4, 3, 3), (640, 320), (77,)], torch.float16)
+            self.enc = Engine([(128, 128), (5,)], torch.float16)
+            self.vae = Engine([(32, 32, 3, 3)], torch.bfloat16)
+
+        def tensors(self):
+            return self.unet.tensors() + self.enc.tensors() + self.vae.tensors()
+
+    pipe, agent = Pipe(), Engine([(96, 128), (7,)], torch.float32)
+    before = int(tensors_checksum(pipe.tensors() + agent.tensors())[0])
+    stats = broadcast_pipeline(pipe, extra=[agent], bucket_bytes=1 << 14)
+    after = int(tensors_checksum(pipe.tensors() + agent.tensors())[0])
+    ok = stats["tensors"] == 8 and stats["checksum"] == after and stats["buckets"] >= 3 and pipe.unet.changed == 1
+    raised = False
+    if rank == 1:
+        pipe.enc.ts[0][3, 3] += 1.0                      # one value differs on one rank
+    try:
+        verify_replicas(pipe.tensors())
+    except RuntimeError:
+        raised = True
+    dist.barrier()
+    q.put((rank, before, after, ok, raised))
+    dist.destroy_process_group()
+
+
+def test_broadcast_pipeline_and_replica_check_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipeline_bcast_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, b0, a0, ok0, r0), (_, b1, a1, ok1, r1) = res
+    assert b0 != b1 and a0 == a1 == b0 and ok0 and ok1
+    assert r0 and r1, "a perturbed replica must be detected on both ranks"
