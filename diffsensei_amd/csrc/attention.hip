@@ -22,8 +22,6 @@ static int g_attn_variant = 0;  // 0 auto, 1 force 32 query rows per wave (QB = 
 void ds_attn_set_variant(int v) { g_attn_variant = v; }
 static long g_ip_min_blocks = 1024;  // ip_attn: double the query tiles per block while the grid keeps this many blocks
 void ds_ip_attn_set_min_blocks(int v) { g_ip_min_blocks = v; }
-static int g_ip_occupancy = 2;  // experiment knob "ip_attn_occupancy": 3 = the build limited to 168 VGPRs (3 blocks per CU)
-void ds_ip_attn_set_occupancy(int v) { g_ip_occupancy = v; }
 
 namespace {
 
@@ -269,8 +267,9 @@ __global__ void ip_region_flags_kernel(const float* bbox, uint8_t* flags, int B,
 constexpr int LP = 96;
 constexpr int VSTR = 200;  // bytes per V^T row in LDS (96 keys * 2 B + 8 pad): conflict-free 8-byte reads
 
-template <int OCC>  // resident blocks per CU the register budget is sized for: 2 (202 VGPRs) or 3 (168, spills - experiment)
-__global__ __launch_bounds__(256, OCC) void ip_attn_kernel(const IPAttnParams p, int qt) {
+// (202 VGPRs -> two blocks per CU.  A build limited to 168 VGPRs for three blocks per CU spills 63 registers and is 20 %
+// slower: 128 vs 106 us at B = 32, heads 20, N = 1024 - profiles/r02_ipattn_occupancy.txt.)
+__global__ __launch_bounds__(256, 2) void ip_attn_kernel(const IPAttnParams p, int qt) {
     __shared__ __attribute__((aligned(16))) char sKt[LP * 128];
     __shared__ __attribute__((aligned(16))) char sKi[LP * 128];
     __shared__ __attribute__((aligned(16))) char sVt[64 * VSTR];
@@ -585,8 +584,7 @@ int ds_launch_ip_attn(const IPAttnParams& p0, hipStream_t stream) {
     int qt = 1;
     while (qt < 8 && (long)((tiles + 2 * qt - 1) / (2 * qt)) * p.B * p.heads >= g_ip_min_blocks) qt *= 2;
     dim3 grid((tiles + qt - 1) / qt, p.B * p.heads);
-    if (g_ip_occupancy == 3) hipLaunchKernelGGL(ip_attn_kernel<3>, grid, dim3(256), 0, stream, p, qt);
-    else hipLaunchKernelGGL(ip_attn_kernel<2>, grid, dim3(256), 0, stream, p, qt);
+    hipLaunchKernelGGL(ip_attn_kernel, grid, dim3(256), 0, stream, p, qt);
     DS_LAUNCH_CHECK();
     return 0;
 }

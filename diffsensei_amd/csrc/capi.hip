@@ -52,11 +52,6 @@ int ds_set_option(const char* key, int value) {
         ds_ip_attn_set_min_blocks(value);
         return 0;
     }
-    if (strcmp(key, "ip_attn_occupancy") == 0) {
-        DS_REQUIRE(value == 2 || value == 3, "ip_attn_occupancy must be 2 or 3");
-        ds_ip_attn_set_occupancy(value);
-        return 0;
-    }
     if (strcmp(key, "attn_variant") == 0) {
         DS_REQUIRE(value >= 0 && value <= 2, "attn_variant must be 0..2");
         ds_attn_set_variant(value);

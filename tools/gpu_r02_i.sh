@@ -1,4 +1,6 @@
 #!/usr/bin/env bash
+# (the ip_attn_occupancy knob used below existed only at commit 'conv_in / conv_out walk pixels grid-stride...' and was removed
+# after this run - 3 blocks per CU is 20 % slower)
 # Round 2, GPU call I: conv_in / conv_out grid-stride (test + effect), ip_attn 3-blocks-per-CU build A/B, and the FULL CPU
 # baseline of BASELINE configs[0] (20 steps + VAE decode on the host cores) with 20-step latent + image parity.
 set -u
