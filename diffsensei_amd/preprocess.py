@@ -105,7 +105,7 @@ class DevicePreprocessor:
         return t
 
     def _one(self, image, out_hw: Tuple[int, int], filt: str, crop: bool, mean: Sequence[float], std: Sequence[float]) -> Tensor:
-        rgb = np.asarray(image.convert("RGB"), dtype=np.uint8)           # do_convert_rgb; bytes only
+        rgb = np.array(image.convert("RGB"), dtype=np.uint8)             # do_convert_rgb; bytes only (own, writable copy)
         h, w = rgb.shape[:2]
         src = torch.from_numpy(np.ascontiguousarray(rgb)).to(self.dev)
         nh, nw = out_hw
