@@ -67,11 +67,6 @@ int ds_set_option(const char* key, int value) {
         ds_llm_gemv_set_variant(value);
         return 0;
     }
-    if (strcmp(key, "llm_gemv_min_cols") == 0) {
-        DS_REQUIRE(value >= 1 && value <= 16, "llm_gemv_min_cols must be 1..16");
-        ds_llm_gemv_set_min_cols(value);
-        return 0;
-    }
     if (strcmp(key, "gemm_pp_even") == 0) {
         ds_gemm_pp_set_even(value);
         return 0;

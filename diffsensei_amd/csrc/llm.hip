@@ -572,7 +572,6 @@ __global__ __launch_bounds__(256) void llm_gemv_pipe_kernel(LlmGemvParams p) {
 }
 
 int g_llm_gemv_variant = 0;  // 0 auto (pipelined), 1 one-column-per-wavefront kernel, 2 un-pipelined streaming kernel
-int g_llm_gemv_min_cols = 1;  // "llm_gemv_min_cols": shrink the grid until every wavefront walks at least this many columns
 
 template <int MC, int SWIGLU>
 int launch_gemv_stream(const LlmGemvParams& p, hipStream_t stream) {
@@ -589,10 +588,10 @@ int launch_gemv_stream(const LlmGemvParams& p, hipStream_t stream) {
     // launching exactly the resident set makes every wavefront walk the same number of columns (no tail round)
     const size_t by_regs = g_llm_gemv_variant == 2 ? 8 : 5;
     const int per_cu = (int)min(by_regs, (size_t)(160 * 1024) / (lds + 512));
-    int blocks = min((p.N + 3) / 4, cus * max(per_cu, 1));
-    // a wavefront with a single column has nothing to prefetch under its dot products (o / down projections: N = 5120 =
-    // exactly one column per resident wavefront); fewer, longer-lived wavefronts keep the weight stream pipelined
-    if (g_llm_gemv_min_cols > 1) blocks = max(1, min(blocks, (p.N + 4 * g_llm_gemv_min_cols - 1) / (4 * g_llm_gemv_min_cols)));
+    // (N = 5120 = exactly one column per resident wavefront for the o / down projections.  Fewer, longer-lived wavefronts
+    // with 2-4 columns each to pipeline were measured and are slower: 5.03 -> 5.13 / 5.22 / 5.56 ms per token,
+    // profiles/r02_mllm_min_cols_ab.jsonl - resident wavefronts matter more than per-wavefront prefetch here.)
+    const int blocks = min((p.N + 3) / 4, cus * max(per_cu, 1));
     if (g_llm_gemv_variant == 2) hipLaunchKernelGGL((llm_gemv_stream_kernel<MC, SWIGLU>), dim3(blocks), dim3(256), lds, stream, p);
     else hipLaunchKernelGGL((llm_gemv_pipe_kernel<MC, SWIGLU>), dim3(blocks), dim3(256), lds, stream, p);
     DS_LAUNCH_CHECK();
@@ -623,7 +622,6 @@ int launch_gemv(const LlmGemvParams& p, hipStream_t stream) {
 }  // namespace
 
 void ds_llm_gemv_set_variant(int v) { g_llm_gemv_variant = v; }
-void ds_llm_gemv_set_min_cols(int v) { g_llm_gemv_min_cols = v < 1 ? 1 : v; }
 
 int ds_launch_llm_gemv(const LlmGemvParams& p, hipStream_t stream) {
     DS_REQUIRE(p.M > 0 && p.N > 0 && p.K >= 8 && p.K % 8 == 0, "llm_gemv: bad shape M=%d N=%d K=%d", p.M, p.N, p.K);

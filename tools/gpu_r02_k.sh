@@ -1,4 +1,5 @@
 #!/usr/bin/env bash
+# (the llm_gemv_min_cols knob existed only for this run and was removed afterwards: more columns per wavefront is slower)
 # Round 2, GPU call K: MLLM token loop with >= 1 / 2 / 3 / 4 weight columns per wavefront (o / down projections)
 set -u
 out=gpurun_out
