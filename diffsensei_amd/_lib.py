@@ -67,7 +67,7 @@ SIGNATURES = {
     "ds_nchw_to_nhwc_f16": (i32, [vp, vp, i32, i32, i32, vp]),
     "ds_pad_rows_f16": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "ds_image_f32_to_u8_nhwc": (i32, [vp, vp, i32, i32, i32, vp]),
-    "ds_llm_gemv_f16": (i32, [vp, i64, vp, vp, i64, vp, i64, i32, i32, i32, i32, i32, f32, vp]),
+    "ds_llm_gemv_f16": (i32, [vp, i64, vp, vp, i64, vp, i64, i32, i32, i32, i32, vp, i32, f32, vp]),
     "ds_llm_attn_f16": (i32, [vp, i64, vp, vp, i64, vp, vp, vp, i64, vp, i32, i32, i32, i32, i32, f32, vp]),
     "ds_llm_rmsnorm_f16": (i32, [vp, i64, vp, vp, i64, vp, vp, i32, i32, i32, f32, vp]),
     "ds_llm_embed_f16": (i32, [vp, vp, vp, i32, i32, vp]),

@@ -277,9 +277,10 @@ int ds_skinny_linear_f16(const void* x, const void* w, const void* bias, const v
 
 // ---- MLLM pre-pass (llm.hip): LLaMA greedy decoding
 static int llm_gemv_impl(const void* x, int64_t ldx, const void* w, void* y, int64_t ldy, const void* residual,
-                         int64_t ldr, int M, int N, int K, int rms, int swiglu, float eps, hipStream_t st) {
+                         int64_t ldr, int M, int N, int K, int rms, int swiglu, float eps, hipStream_t st,
+                         const void* rms_gain = nullptr) {
     LlmGemvParams g;
-    g.x = H(x); g.w = H(w); g.y = HM(y); g.residual = H(residual);
+    g.x = H(x); g.w = H(w); g.y = HM(y); g.residual = H(residual); g.gain = rms ? H(rms_gain) : nullptr;
     g.ldx = ldx; g.ldy = ldy; g.ldr = ldr; g.M = M; g.N = N; g.K = K; g.rms = rms; g.swiglu = swiglu; g.eps = eps;
     return ds_launch_llm_gemv(g, st);
 }
@@ -295,8 +296,8 @@ static int llm_attn_impl(const void* qkv, int64_t ldqkv, void* kc, void* vc, int
 }
 
 int ds_llm_gemv_f16(const void* x, int64_t ldx, const void* w, void* y, int64_t ldy, const void* residual,
-                    int64_t ldr, int M, int N, int K, int rms, int swiglu, float eps, void* stream) {
-    return llm_gemv_impl(x, ldx, w, y, ldy, residual, ldr, M, N, K, rms, swiglu, eps, S(stream));
+                    int64_t ldr, int M, int N, int K, int rms, const void* rms_gain, int swiglu, float eps, void* stream) {
+    return llm_gemv_impl(x, ldx, w, y, ldy, residual, ldr, M, N, K, rms, swiglu, eps, S(stream), rms_gain);
 }
 
 int ds_llm_attn_f16(const void* qkv, int64_t ldqkv, void* k_cache, void* v_cache, int64_t ldc, const float* rope_cos,
@@ -460,7 +461,7 @@ static int run_op(const ds_op& o, hipStream_t st) {
             return ds_launch_small_attn(H(p[0]), H(p[1]), H(p[2]), HM(p[3]), l[0], l[1], l[2], l[3], l[4], l[5], l[6],
                                         l[7], i[0], i[1], i[2], i[3], i[4], o.f[0], st);
         case DS_OP_LLM_GEMV:
-            return llm_gemv_impl(p[0], l[0], p[1], p[2], l[1], p[3], l[2], i[0], i[1], i[2], i[3], i[4], o.f[0], st);
+            return llm_gemv_impl(p[0], l[0], p[1], p[2], l[1], p[3], l[2], i[0], i[1], i[2], i[3], i[4], o.f[0], st, p[4]);
         case DS_OP_LLM_ATTN:
             return llm_attn_impl(p[0], l[0], p[1], p[2], l[1], reinterpret_cast<const float*>(p[3]),
                                  reinterpret_cast<const float*>(p[4]), p[5], l[2], reinterpret_cast<const int32_t*>(p[6]),

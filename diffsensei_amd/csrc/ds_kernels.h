@@ -151,7 +151,10 @@ struct LlmGemvParams {
     const half_t* residual = nullptr;  // [M,N] rows (ldr) added after the fp16 rounding; may alias y
     long ldx = 0, ldy = 0, ldr = 0;
     int M = 0, N = 0, K = 0;
-    int rms = 0;                       // scale row m by rsqrt(mean(x[m]^2) + eps): RMSNorm whose gain is folded into w
+    int rms = 0;                       // LlamaRMSNorm in front of the projection: row m is scaled by rsqrt(mean(x[m]^2) + eps)
+    const half_t* gain = nullptr;      // [K] RMSNorm weight.  Given: x' = f16(gain * f16(x * r)) exactly like the reference
+                                       // (normalise in fp32, round to fp16, multiply by the fp16 gain, round) is what meets
+                                       // w; null: the caller folded the gain into w and only r is applied to the dot
     int swiglu = 0;                    // y = silu(x.w[n]) * (x.w[n+N])
     float eps = 1e-6f;
 };

@@ -28,8 +28,18 @@ __device__ __forceinline__ float dot8(const h8 a, const h8 b, float acc) {
     return acc;
 }
 
+// LlamaRMSNorm output for 8 elements, with the reference's rounding points (modeling_llama_xformer.py:77-82):
+// hidden = x(fp32) * r -> .to(fp16) -> weight(fp16) * hidden -> fp16
+__device__ __forceinline__ h8 rms_gain8(const h8& x, const h8& g, float r) {
+    h8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)g[e] * (float)(half_t)((float)x[e] * r));
+    return o;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // y[m][n] = r_m * sum_k x[m][k] w[n][k]  (+ residual[m][n]),  r_m = rsqrt(mean_k x[m][k]^2 + eps) if rms else 1
+// (with p.gain: y[m][n] = sum_k f16(gain[k] * f16(x[m][k] r_m)) w[n][k], the reference's RMSNorm roundings)
 // SWIGLU:  y[m][n] = silu(r_m * x.w[n]) * (r_m * x.w[n+N])     (gate rows [0,N), up rows [N,2N))
 // One wavefront per output column; MC rows of x per pass (x comes from L1/L2, it is MC*K*2 bytes).
 // ---------------------------------------------------------------------------------------------------------------
@@ -78,7 +88,8 @@ __global__ __launch_bounds__(256) void llm_gemv_kernel(LlmGemvParams p) {
 #pragma unroll
                 for (int m = 0; m < MC; ++m) {
                     if (m0 + m < p.M) {
-                        const h8 xv = *reinterpret_cast<const h8*>(p.x + (long)(m0 + m) * p.ldx + k);
+                        h8 xv = *reinterpret_cast<const h8*>(p.x + (long)(m0 + m) * p.ldx + k);
+                        if (p.gain) xv = rms_gain8(xv, *reinterpret_cast<const h8*>(p.gain + k), r[m]);
                         acc[m] = dot8(xv, wv[u], acc[m]);
                         if (SWIGLU) acu[m] = dot8(xv, uv[u], acu[m]);
                     }
@@ -88,8 +99,9 @@ __global__ __launch_bounds__(256) void llm_gemv_kernel(LlmGemvParams p) {
     }
 #pragma unroll
     for (int m = 0; m < MC; ++m) {
-        acc[m] = wave_sum(acc[m]) * r[m];
-        if (SWIGLU) acu[m] = wave_sum(acu[m]) * r[m];
+        const float rr = p.gain ? 1.0f : r[m];  // with a gain the scale is already inside x'
+        acc[m] = wave_sum(acc[m]) * rr;
+        if (SWIGLU) acu[m] = wave_sum(acu[m]) * rr;
     }
     if (lane == 0) {
 #pragma unroll
@@ -420,6 +432,19 @@ __global__ __launch_bounds__(256) void llm_gemv_stream_kernel(LlmGemvParams p) {
             rs[tid] = p.rms ? __builtin_amdgcn_rsqf(s / (float)K + p.eps) : 1.0f;
         }
         __syncthreads();
+        if (p.rms && p.gain) {  // the staged rows become the RMSNorm OUTPUT (reference roundings); no scale left for the dots
+#pragma unroll
+            for (int m = 0; m < MC; ++m) {
+                const float r = rs[m];
+                for (int k = tid * 8; k < K; k += 2048) {
+                    h8* xp = reinterpret_cast<h8*>(xs + (long)m * K + k);
+                    *xp = rms_gain8(*xp, *reinterpret_cast<const h8*>(p.gain + k), r);
+                }
+            }
+            __syncthreads();
+            if (tid < MC) rs[tid] = 1.0f;
+            __syncthreads();
+        }
     }
     constexpr int U = SWIGLU ? 4 : 8;
     for (int n = blockIdx.x * 4 + wave; n < p.N; n += gridDim.x * 4) {
@@ -519,6 +544,19 @@ __global__ __launch_bounds__(256) void llm_gemv_pipe_kernel(LlmGemvParams p) {
             rs[tid] = p.rms ? __builtin_amdgcn_rsqf(s / (float)K + p.eps) : 1.0f;
         }
         __syncthreads();
+        if (p.rms && p.gain) {  // the staged rows become the RMSNorm OUTPUT (reference roundings); no scale left for the dots
+#pragma unroll
+            for (int m = 0; m < MC; ++m) {
+                const float r = rs[m];
+                for (int k = tid * 8; k < K; k += 2048) {
+                    h8* xp = reinterpret_cast<h8*>(xs + (long)m * K + k);
+                    *xp = rms_gain8(*xp, *reinterpret_cast<const h8*>(p.gain + k), r);
+                }
+            }
+            __syncthreads();
+            if (tid < MC) rs[tid] = 1.0f;
+            __syncthreads();
+        }
     }
     while (n < N) {
         float acc[MC], acu[MC];

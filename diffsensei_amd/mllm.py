@@ -14,8 +14,9 @@ copy) to see whether EOS was produced.  The prompt is one pass per layer: projec
 (`ops.gemm`), attention through the decode kernel in 16-row chunks (`prompt_path="mfma"`, 22 ms for 96 tokens at 13B
 dims); `prompt_path="chunks"` runs it through the token kernels 16 rows at a time instead (166 ms; kept for A/B).
 
-Host-side packing (once): q|k|v and gate|up projections stacked, the two RMSNorm gains of each layer folded into them
-(W' = W diag(g)); QwenResampler: the constant query projection and the position-embedding contribution to the keys are
+Host-side packing (once): q|k|v and gate|up projections stacked; the two RMSNorm gains of each layer stay vectors and are
+applied in the GEMV prologue at the reference's rounding points (normalise in fp32, round to fp16, times the fp16 gain -
+folding them into the fp16 weights would round once instead of twice and can flip greedy near-ties); QwenResampler: the constant query projection and the position-embedding contribution to the keys are
 precomputed (they depend on weights only).  There is no CPU/PyTorch execution path: without the HIP library every call
 raises.
 """
@@ -113,22 +114,21 @@ class LlamaDecodeEngine:
         dev = self.dev
         f16 = lambda t: t.detach().to(device=dev, dtype=torch.float16).contiguous()
 
-        def fold(ws: Sequence[Tensor], gain: Tensor) -> Tensor:
-            """cat(ws) * diag(gain), folded in fp32 on the device, stored fp16 (packing, once)."""
-            w = torch.cat([t.detach().to(dev) for t in ws], 0).float() * gain.detach().to(dev).float()[None, :]
-            return w.to(torch.float16).contiguous()
+        stack = lambda ws: torch.cat([t.detach().to(dev) for t in ws], 0).to(torch.float16).contiguous()
 
         self.embed = f16(sd["model.embed_tokens.weight"])
         self.lm_head = f16(sd["lm_head.weight"])
         self.norm_g = f16(sd["model.norm.weight"])
-        self.wqkv, self.wo, self.wgu, self.wdown = [], [], [], []
+        # q|k|v and gate|up are stacked (one weight stream per projection group); the RMSNorm gains stay separate vectors
+        # applied in the GEMV prologue with the reference's rounding points (normalise, round to fp16, times the fp16 gain)
+        self.wqkv, self.wo, self.wgu, self.wdown, self.g_in, self.g_post = [], [], [], [], [], []
         for i in range(L):
             p = f"model.layers.{i}."
-            self.wqkv.append(fold([sd[p + f"self_attn.{n}_proj.weight"] for n in "qkv"],
-                                  sd[p + "input_layernorm.weight"]))
+            self.wqkv.append(stack([sd[p + f"self_attn.{n}_proj.weight"] for n in "qkv"]))
+            self.g_in.append(f16(sd[p + "input_layernorm.weight"]))
             self.wo.append(f16(sd[p + "self_attn.o_proj.weight"]))
-            self.wgu.append(fold([sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"]],
-                                 sd[p + "post_attention_layernorm.weight"]))
+            self.wgu.append(stack([sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"]]))
+            self.g_post.append(f16(sd[p + "post_attention_layernorm.weight"]))
             self.wdown.append(f16(sd[p + "mlp.down_proj.weight"]))
         E = lambda *s, dtype=torch.float16: torch.zeros(s, dtype=dtype, device=dev)
         self.qkv_dim = (Hq + 2 * Hkv) * D
@@ -141,7 +141,6 @@ class LlamaDecodeEngine:
         self.rope_cos, self.rope_sin = fr.cos().to(dev).contiguous(), fr.sin().to(dev).contiguous()
         self.state = E(8, dtype=torch.int32)
         self.state_pf = E(8, dtype=torch.int32)             # prompt pass: per-layer chunk cursor (see _prompt_mfma)
-        self.ones_h = torch.ones(H, dtype=torch.float16, device=dev)
         self.prompt_path = prompt_path
         self.out_ids = E(self.cap, dtype=torch.int32)
         self.feat = E(self.cap, H)
@@ -163,7 +162,7 @@ class LlamaDecodeEngine:
 
     def tensors(self) -> List[Tensor]:
         """Frozen weights in kernel layout (the multi-GPU weight broadcast list)."""
-        return [self.embed, self.lm_head, self.norm_g] + self.wqkv + self.wo + self.wgu + self.wdown
+        return [self.embed, self.lm_head, self.norm_g] + self.wqkv + self.wo + self.wgu + self.wdown + self.g_in + self.g_post
 
     # ---- launch lists ------------------------------------------------------------------------------------
     def _ops(self, M: int, kind: str) -> list:
@@ -177,14 +176,14 @@ class LlamaDecodeEngine:
             ops_.append(make_op("LLM_EMBED", i=(H, V), p=(self.embed, self.state, self.h)))
         for l in range(c.num_hidden_layers):
             ops_.append(make_op("LLM_GEMV", i=(M, self.qkv_dim, H, 1, 0), f=(eps,), l=(H, self.qkv_dim, 0),
-                                p=(self.h, self.wqkv[l], self.qkv, None)))
+                                p=(self.h, self.wqkv[l], self.qkv, None, self.g_in[l])))
             ops_.append(make_op("LLM_ATTN", i=(M, Hq, Hkv, D, self.T_max), f=(scale,), l=(self.qkv_dim, Hkv * D, Hq * D),
                                 p=(self.qkv, self.kc[l], self.vc[l], self.rope_cos, self.rope_sin, self.att,
                                    self.state)))
             ops_.append(make_op("LLM_GEMV", i=(M, H, Hq * D, 0, 0), f=(eps,), l=(Hq * D, H, H),
                                 p=(self.att, self.wo[l], self.h, self.h)))
             ops_.append(make_op("LLM_GEMV", i=(M, I, H, 1, 1), f=(eps,), l=(H, I, 0),
-                                p=(self.h, self.wgu[l], self.act, None)))
+                                p=(self.h, self.wgu[l], self.act, None, self.g_post[l])))
             ops_.append(make_op("LLM_GEMV", i=(M, H, I, 0, 0), f=(eps,), l=(I, H, H),
                                 p=(self.act, self.wdown[l], self.h, self.h)))
         if kind == "chunk":
@@ -283,7 +282,7 @@ class LlamaDecodeEngine:
         h = inputs_embeds.contiguous().clone()
         att = torch.empty((T0, Hq * c.head_dim), dtype=torch.float16, device=self.dev)
         for l in range(c.num_hidden_layers):
-            xn = ops.llm_rmsnorm(h, self.ones_h, eps)                        # gains are folded into wqkv / wgu
+            xn = ops.llm_rmsnorm(h, self.g_in[l], eps)                       # LlamaRMSNorm incl. its gain, then the plain GEMM
             qkv = ops.gemm(xn, self.wqkv[l])
             pf.zero_()                                                       # chunk cursor of this layer's cache
             for r0 in range(0, T0, CHUNK):
@@ -292,7 +291,7 @@ class LlamaDecodeEngine:
                                   scale, out=att[r0:r0 + m])
                 ops.llm_advance(pf, m)
             h = ops.gemm(att, self.wo[l], residual=h)
-            xn = ops.llm_rmsnorm(h, self.ones_h, eps)
+            xn = ops.llm_rmsnorm(h, self.g_post[l], eps)
             act = ops.llm_swiglu(ops.gemm(xn, self.wgu[l]))
             h = ops.gemm(act, self.wdown[l], residual=h)
         ops.llm_rmsnorm(h[T0 - 1:T0], self.norm_g, eps, out=self.hn)

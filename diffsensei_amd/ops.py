@@ -388,18 +388,19 @@ def vae_conv_out(x: Tensor, w: Tensor, bias: Tensor, denormalize: bool = False) 
 
 # ---- MLLM pre-pass: LLaMA greedy decoding (csrc/llm.hip) ----------------------------------------------------
 def llm_gemv(x: Tensor, w: Tensor, out: Optional[Tensor] = None, residual: Optional[Tensor] = None, rms: bool = False,
-             swiglu: bool = False, eps: float = 1e-6) -> Tensor:
-    """x: [M<=any, K] rows; w: [N,K] (swiglu: [2N,K] gate rows then up rows).  `rms`: rows scaled by 1/rms(x) (the
-    RMSNorm gain is expected to be folded into w).  `residual` may be `out` itself (in-place h += ...)."""
-    _chk(x, w, residual)
+             swiglu: bool = False, eps: float = 1e-6, gain: Optional[Tensor] = None) -> Tensor:
+    """x: [M<=any, K] rows; w: [N,K] (swiglu: [2N,K] gate rows then up rows).  `rms`: a LlamaRMSNorm in front - with
+    `gain` [K] the reference's roundings (f16(gain * f16(x / rms))), without it only the 1/rms scale (gain folded into w by
+    the caller).  `residual` may be `out` itself (in-place h += ...)."""
+    _chk(x, w, residual, gain)
     M, K = x.shape
     N = w.shape[0] // (2 if swiglu else 1)
     assert w.shape[1] == K
     if out is None:
         out = torch.empty((M, N), dtype=torch.float16, device=x.device)
     _chk(out)
-    check(_lib.load().ds_llm_gemv_f16(_p(x), K, _p(w), _p(out), N, _p(residual), N, M, N, K, int(rms), int(swiglu),
-                                      eps, _stream()), "ds_llm_gemv_f16")
+    check(_lib.load().ds_llm_gemv_f16(_p(x), K, _p(w), _p(out), N, _p(residual), N, M, N, K, int(rms), _p(gain),
+                                      int(swiglu), eps, _stream()), "ds_llm_gemv_f16")
     return out
 
 

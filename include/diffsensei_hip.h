@@ -214,12 +214,14 @@ int ds_image_f32_to_u8_nhwc(const float* image, uint8_t* out, int B, int H, int 
  *                       max_new_tokens of this call, eos token id, spare, spare}
  * so one token step is a static launch list (DS_OP_LLM_* above) that replays as a hipGraph.
  * ---------------------------------------------------------------------------------------------- */
-/* y[M,N] = r_m * (x[M,K] @ w[N,K]^T) (+ residual), r_m = rsqrt(mean(x_m^2)+eps) when `rms` (an RMSNorm whose gain has
- * been folded into w by the host: LlamaRMSNorm + the q/k/v or gate/up projections, modeling_llama_xformer.py:277-296);
- * `swiglu`: w is [2N,K] (gate rows, then up rows) and y = silu(x.w_gate) * (x.w_up) (LlamaMLP.forward :166-167).
+/* y[M,N] = x'[M,K] @ w[N,K]^T (+ residual).  `rms` != 0 puts a LlamaRMSNorm in front of the projection
+ * (modeling_llama_xformer.py:77-82 + the q/k/v or gate/up projections :277-296): r_m = rsqrt(mean(x_m^2)+eps) and
+ *   rms_gain [K] given:  x'[m][k] = f16(rms_gain[k] * f16(x[m][k] * r_m))   - the reference's rounding points exactly;
+ *   rms_gain NULL:       y = r_m * (x @ w^T)                                  - for a caller that folded the gain into w.
+ * `swiglu`: w is [2N,K] (gate rows, then up rows) and y = silu(x'.w_gate) * (x'.w_up) (LlamaMLP.forward :166-167).
  * M <= 16 rows per pass internally; HBM-bound weight streaming, one wavefront per output column. */
 int ds_llm_gemv_f16(const void* x, int64_t ldx, const void* w, void* y, int64_t ldy, const void* residual,
-                    int64_t ldr, int M, int N, int K, int rms, int swiglu, float eps, void* stream);
+                    int64_t ldr, int M, int N, int K, int rms, const void* rms_gain, int swiglu, float eps, void* stream);
 /* rotary embedding + KV-cache append + attention for M (<= 16) new rows at positions state[0] .. state[0]+M-1
  * (LlamaAttention.forward :192-244: causal inside the prompt chunk, every cached key for a single new token).
  * qkv: [M,(heads+2*kv_heads)*D] un-rotated q|k|v; caches [T_max,kv_heads*D]; rope tables fp32 [T_max,D/2];
@@ -291,7 +293,7 @@ enum ds_opcode {
     DS_OP_NCHW2NHWC = 16,    /* p: x, y                                   i: B HW C */
     DS_OP_PAD_ROWS = 17,     /* p: x, y                                   i: B rows_in rows_out row_off total_rows C */
     DS_OP_SMALL_ATTN = 18,   /* p: q, k, v, o   l: ldq ldk ldv ldo sq sk sv so   i: B heads Nq Nk D   f: scale */
-    DS_OP_LLM_GEMV = 19,     /* p: x, w, y, residual        l: ldx ldy ldr   i: M N K rms swiglu      f: eps */
+    DS_OP_LLM_GEMV = 19,     /* p: x, w, y, residual, rms_gain   l: ldx ldy ldr   i: M N K rms swiglu  f: eps */
     DS_OP_LLM_ATTN = 20,     /* p: qkv, k_cache, v_cache, rope_cos, rope_sin, out, state   l: ldqkv ldc ldo
                                 i: M heads kv_heads D T_max                                           f: scale */
     DS_OP_LLM_RMSNORM = 21,  /* p: x, gamma, y, feat, state l: ldx ldy       i: M H max_out           f: eps */

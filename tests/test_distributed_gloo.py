@@ -126,7 +126,7 @@ def test_sharded_bucketed_serving_world2():
 
 
 def _mllm_worker(rank, world, port, q):
-    """The MLLM engine's packed weights (folded q|k|v / gate|up, o, down, embeddings, lm_head, final gain) are what the
+    """The MLLM engine's packed weights (stacked q|k|v / gate|up, o, down, the RMSNorm gains, embeddings, lm_head) are what the
     N > 1 start-up broadcast must cover: rank 1 starts from different seeds and must end bit-identical to rank 0."""
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
@@ -161,8 +161,9 @@ def test_mllm_weight_broadcast_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     (_, n0, before0, after0, sample0), (_, n1, before1, after1, sample1) = res
-    # every matrix of the model is in the list: 2 layers x (3+1+2+1) H-by-* blocks + embeddings + lm_head + final gain
-    assert n0 == n1 == 2 * (3 * 128 * 128 + 128 * 128 + 2 * 256 * 128 + 128 * 256) + 2 * 96 * 128 + 128
+    # every tensor of the model is in the list: 2 layers x ((3+1+2+1) H-by-* blocks + 2 RMSNorm gains) + embeddings + lm_head
+    # + final gain
+    assert n0 == n1 == 2 * (3 * 128 * 128 + 128 * 128 + 2 * 256 * 128 + 128 * 256 + 2 * 128) + 2 * 96 * 128 + 128
     assert before0 != before1 and after0 == before0 and after1 == after0 and sample0 == sample1
 
 

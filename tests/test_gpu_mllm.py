@@ -45,6 +45,12 @@ def test_llm_gemv_plain_residual_rms(hip_lib, M, N, K):
     _close(y, (x.float() @ w.float().T).half().float() + res.float(), what="residual in place")
     r = torch.rsqrt(x.float().pow(2).mean(-1, keepdim=True) + 1e-5)
     _close(ops.llm_gemv(xd, wd, rms=True, eps=1e-5), (x.float() @ w.float().T) * r, what="rms")
+    # RMSNorm WITH its gain in the prologue, at the reference's rounding points (modeling_llama_xformer.py:77-82:
+    # normalise in fp32, .to(fp16), weight * hidden in fp16) - a tight tolerance: the fp16 products are exact in fp32
+    gain = (1.0 + 0.3 * torch.randn(K, generator=g)).half()
+    xn = (gain.float() * (x.float() * r).half().float()).half()
+    _close(ops.llm_gemv(xd, wd, rms=True, eps=1e-5, gain=gain.to(DEV)), xn.float() @ w.float().T, tol=1.5e-3,
+           what="rms + gain")
 
 
 @pytest.mark.parametrize("M,N,K", [(1, 704, 256), (5, 344, 512), (16, 1024, 1024)])
@@ -56,6 +62,11 @@ def test_llm_gemv_swiglu(hip_lib, M, N, K):
     gate, up = (x.float() @ w[:N].float().T) * r, (x.float() @ w[N:].float().T) * r
     _close(ops.llm_gemv(x.to(DEV), w.to(DEV), rms=True, swiglu=True, eps=1e-6), F.silu(gate) * up, tol=6e-3,
            what="swiglu")
+    gain = (1.0 + 0.3 * torch.randn(K, generator=g)).half()
+    xn = (gain.float() * (x.float() * r).half().float()).half().float()
+    gate, up = (xn @ w[:N].float().T).half().float(), (xn @ w[N:].float().T).half().float()
+    _close(ops.llm_gemv(x.to(DEV), w.to(DEV), rms=True, swiglu=True, eps=1e-6, gain=gain.to(DEV)),
+           F.silu(gate).half().float() * up, tol=6e-3, what="swiglu + gain")
 
 
 def _ref_attention(q, k, v, pos_q, theta=10000.0):

@@ -85,9 +85,11 @@ def test_engine_has_no_cpu_path():
     sd = {k: torch.randn(s, generator=g) * 0.05 for k, s in M.llama_param_shapes(cfg).items()}
     eng = M.LlamaDecodeEngine(cfg, sd, "cpu", max_positions=32, max_new_tokens=8)        # packing is host work
     assert eng.wqkv[0].shape == (3 * 128, 128) and eng.wgu[0].shape == (512, 128)
-    folded = torch.cat([sd["model.layers.0.self_attn.%s_proj.weight" % n] for n in "qkv"]) * \
-        sd["model.layers.0.input_layernorm.weight"][None]
-    assert torch.allclose(eng.wqkv[0].float(), folded, atol=1e-3)
+    stacked = torch.cat([sd["model.layers.0.self_attn.%s_proj.weight" % n] for n in "qkv"])
+    assert torch.equal(eng.wqkv[0], stacked.half())                  # stacked, NOT folded: the RMSNorm gains stay vectors
+    assert torch.equal(eng.g_in[0], sd["model.layers.0.input_layernorm.weight"].half())
+    assert torch.equal(eng.g_post[0], sd["model.layers.0.post_attention_layernorm.weight"].half())
+    assert len(eng.tensors()) == 3 + 6 * cfg.num_hidden_layers
     assert eng.weight_bytes_per_token() == 2 * (3 * 128 * 128 + 128 * 128 + 512 * 128 + 128 * 256 + 64 * 128 + 128)
     with pytest.raises(ValueError):
         eng.generate(torch.zeros(4, 128, dtype=torch.float16), 1, 2, 4)                  # host tensor: refused
