@@ -67,6 +67,11 @@ int ds_set_option(const char* key, int value) {
         ds_llm_gemv_set_variant(value);
         return 0;
     }
+    if (strcmp(key, "gemm_ring") == 0) {
+        DS_REQUIRE(value >= 0 && value <= 1, "gemm_ring must be 0 (auto) or 1 (off)");
+        ds_gemm_set_ring(value);
+        return 0;
+    }
     if (strcmp(key, "gemm_pp_even") == 0) {
         ds_gemm_pp_set_even(value);
         return 0;

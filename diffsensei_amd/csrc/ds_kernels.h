@@ -32,6 +32,7 @@ int ds_launch_conv_halo(const GemmParams& p, hipStream_t stream);
 void ds_conv_halo_set_variant(int v);  // 0 auto, 1 8x16-pixel blocks, 2 16x16-pixel blocks
 const char* ds_gemm_kernel_name(const GemmParams& p, int batch);  // the instantiation ds_launch_gemm dispatches to
 void ds_gemm_set_debug(int v);
+void ds_gemm_set_ring(int v);     // 0 auto (ring-buffered kernel for small grids), 1 never
 void ds_gemm_pp_set_even(int v);  // experiment: 1 = persistent grid shrunk so that every round of tiles is full
 void ds_gemm_set_variant(int v);  // 0 auto, 1 register staging only, 2 glds (BM <= 128), 3 glds, BM = 256 when large
 

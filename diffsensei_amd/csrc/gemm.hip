@@ -23,6 +23,8 @@
 
 static int g_gemm_variant = 0;  // 0 auto; A/B: 1 register staging, 2 two-buffer glds, 3 ping-pong 256x256, 7 two-buffer BM 64, 8/9 one-buffer glds (BM 128/64), 10 halo conv
 void ds_gemm_set_variant(int v) { g_gemm_variant = v; }
+static int g_gemm_ring = 0;  // 0 auto, 1 never use the ring-buffered small-grid kernel (A/B)
+void ds_gemm_set_ring(int v) { g_gemm_ring = v; }
 static int g_gemm_debug = 0;  // ablation switches, see GemmParams::debug
 void ds_gemm_set_debug(int v) { g_gemm_debug = v; }
 
@@ -188,8 +190,12 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x16 (&acc)[WR /
 }
 
 // ---------------------------------------------------------------------------------------------- glds pipeline
-template <int BM, bool CONV, int STAGES = 2>  // STAGES = 1: one 32-KiB LDS buffer, three blocks per CU
-__global__ __launch_bounds__(256, (BM > 128 ? 1 : (STAGES == 1 ? (BM == 64 ? 4 : 3) : 2))) void gemm_glds_kernel(const GemmParams p) {
+// STAGES = 1: one 32-KiB LDS buffer, three (four at BM 64) blocks per CU - independent blocks hide each other's DMA latency;
+// STAGES = 2: two buffers, tile t+1 / t+2 in flight; STAGES >= 3: a ring of buffers with STAGES-1 tiles in flight and ONE
+// barrier per k-tile - for grids too small to give a CU several blocks (num_samples 1: M = 2048 rows), where the
+// one-buffer kernel spends every k-tile waiting out the full L2/HBM latency (profiles/r02_small_grid_gemm.txt).
+template <int BM, bool CONV, int STAGES = 2>
+__global__ __launch_bounds__(256, (BM > 128 ? 1 : (STAGES >= 4 ? 1 : (STAGES == 1 ? (BM == 64 ? 4 : 3) : 2)))) void gemm_glds_kernel(const GemmParams p) {
     constexpr int MI = BM / 64;
     constexpr int ASEG = BM / 32;  // 1-KiB (8-row) A segments per wave per k-tile
     constexpr int BSEG = 4;
@@ -297,6 +303,64 @@ __global__ __launch_bounds__(256, (BM > 128 ? 1 : (STAGES == 1 ? (BM == 64 ? 4 :
     // (tile kt+1 is already in flight in the other buffer: two tiles of latency cover with two buffers); (5) the 16
     // MFMAs run out of registers while the DMA lands.  Raw s_barrier: __syncthreads() would drain vmcnt to 0.
     constexpr int PIECES = ASEG + BSEG;  // LDS-DMA instructions per wave per tile
+    if constexpr (STAGES >= 3) {
+        // ---- ring: tiles kt+1 .. kt+STAGES-2 stay in flight while tile kt is consumed.  Passing the barrier of iteration
+        // kt means every wave has retired its fragment reads of tile kt-1, so that buffer is refilled right away.
+        auto wait_newer = [&](int tiles) {  // all LDS-DMA older than the `tiles` newest k-tiles has landed
+            if (tiles >= 2) {
+                if constexpr (PIECES == 6) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                else if constexpr (PIECES == 8) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            } else if (tiles == 1) {
+                if constexpr (PIECES == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else if constexpr (PIECES == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        };
+        static_assert(STAGES <= 4, "wait_newer covers at most two newer tiles in flight");
+#pragma unroll
+        for (int s = 0; s < STAGES - 1; ++s)
+            if (s < nk) issue(s, s);
+        int buf = 0, fill = STAGES - 1;  // buffer of tile kt / buffer the next issued tile goes to
+        for (int kt = 0; kt < nk; ++kt) {
+            wait_newer(min(STAGES - 2, nk - 1 - kt));
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1, fill);
+            const char* cA = sA + buf * BM * 128;
+            const char* cB = sB + buf * BN * 128;
+            h8 af[4][MI], bf[4][2];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int ch = kk * 2 + lhi;
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    const int r = wm * (BM / 2) + mi * 32 + l31;
+                    af[kk][mi] = *reinterpret_cast<const h8*>(cA + r * 128 + swz(r, ch));
+                }
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const int r = wn * 64 + ni * 32 + l31;
+                    bf[kk][ni] = *reinterpret_cast<const h8*>(cB + r * 128 + swz(r, ch));
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[kk][ni], af[kk][mi], acc[mi][ni], 0, 0, 0);
+            buf = buf + 1 == STAGES ? 0 : buf + 1;
+            fill = fill + 1 == STAGES ? 0 : fill + 1;
+        }
+        __syncthreads();
+        epilogue<BM, BM / 2, 256>(p, acc, smem, m0, n0, bz, wm, wn, l31, lhi, tid);
+        return;
+    }
     const bool deep = STAGES == 2 && !(p.debug & 8);  // debug 8: one barrier per tile, DMA one tile ahead (A/B switch)
     issue(0, 0);
     if (nk > 1 && deep) issue(1, 1);
@@ -518,7 +582,29 @@ int launch_glds1(const GemmParams& p0, int batch, hipStream_t stream) {
     return 0;
 }
 
-enum Kind { K_REG, K_GLDS2, K_GLDS1, K_PP, K_HALO };
+// ring-buffered variant for small grids: STAGES buffers of (64 + 128) x 128 B; 4 stages = 96 KiB (one block per CU),
+// 3 stages = 72 KiB (two blocks per CU)
+template <int STAGES>
+int launch_ring(const GemmParams& p0, int batch, hipStream_t stream) {
+    constexpr int BM = 64;
+    GemmParams p = p0;
+    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_n = (p.N + BN - 1) / BN;
+    const size_t lds = (size_t)STAGES * (BM + BN) * 128;
+    auto kern = gemm_glds_kernel<BM, false, STAGES>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds));
+        attr_set = true;
+    }
+    dim3 grid(p.tiles_m * p.tiles_n, 1, batch);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p);
+    DS_LAUNCH_CHECK();
+    return 0;
+}
+
+enum Kind { K_REG, K_GLDS2, K_GLDS1, K_PP, K_HALO, K_RING };
 struct Choice {
     Kind kind;
     int bm;   // rows of the block tile
@@ -566,6 +652,13 @@ Choice choose(const GemmParams& p, int batch) {
         c.bm = 64;
     } else if (small) {
         c.kind = K_GLDS1;
+        // grids that leave a CU with at most two 64 x 128 blocks: nothing hides the DMA latency of the one-buffer kernel
+        // (33 us per launch at M = 2048, profiles/r02_small_grid_gemm.txt) -> ring of 4 (one block per CU) or 3 (two) buffers
+        const long blocks64 = (long)((p.M + 63) / 64) * ((p.N + 127) / 128) * batch;
+        if (g_gemm_ring != 1 && p.K >= 256 && blocks64 <= 512) {
+            c.kind = K_RING;
+            c.bm = blocks64 <= 256 ? 4 : 3;   // bm carries the ring depth for this kind
+        }
     } else {
         c.kind = (p.K >= 4096 && p.N <= 2048) ? K_GLDS2 : K_GLDS1;
         // 256 x 256 persistent ping-pong kernel (gemm_pp.hip), grid = ceil(tiles / rounds) blocks (every round full).  It
@@ -599,6 +692,7 @@ const char* ds_gemm_kernel_name(const GemmParams& p, int batch) {
     switch (c.kind) {
         case K_PP: return "gemm_pp_kernel<0>";
         case K_HALO: return "conv_halo_kernel";
+        case K_RING: return c.bm == 4 ? "gemm_glds_kernel<64,false,4>" : "gemm_glds_kernel<64,false,3>";
         case K_GLDS1:
             if (c.bm == 128) return conv ? "gemm_glds_kernel<128,true,1>" : "gemm_glds_kernel<128,false,1>";
             return conv ? "gemm_glds_kernel<64,true,1>" : "gemm_glds_kernel<64,false,1>";
@@ -640,6 +734,7 @@ int ds_launch_gemm(const GemmParams& p_in, int batch, hipStream_t stream) {
     switch (c.kind) {
         case K_PP: return ds_launch_gemm_pp(p, batch, stream);
         case K_HALO: return ds_launch_conv_halo(p, stream);
+        case K_RING: return c.bm == 4 ? launch_ring<4>(p, batch, stream) : launch_ring<3>(p, batch, stream);
         case K_GLDS1:
             if (c.bm == 128)
                 return conv ? launch_glds1<128, true>(p, batch, stream) : launch_glds1<128, false>(p, batch, stream);

@@ -147,6 +147,38 @@ def test_gemm_pingpong_geglu_and_dispatch(hip_lib):
     _close(auto, x2.float() @ w2.float().t(), what="auto dispatch")
 
 
+@pytest.mark.parametrize("M,N,K", [(2048, 1280, 1280), (2048, 2560, 1280), (2048, 1280, 5120), (8192, 640, 640),
+                                   (200, 136, 256), (64, 128, 320), (1000, 640, 2560), (4096, 1280, 1280)])
+def test_gemm_ring_buffered_small_grid_kernel(hip_lib, M, N, K):
+    """`gemm_glds_kernel<64,false,3|4>` (ring of LDS buffers, the automatic choice for grids of <= 512 blocks: the
+    num_samples-1 shapes M = 2048 / 8192): vs fp32, and bit-identical to the one-buffer kernel it replaces
+    (gemm_ring 1), with bias + residual, split A, GEGLU and the batched V^T form."""
+    from diffsensei_amd import _lib
+    from diffsensei_amd.engine import pack_geglu
+    ops = _ops(hip_lib)
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M + 3 * N + K)
+    x, w, b, r = _r((M, K), g), _r((N, K), g, 1 / math.sqrt(K)), _r((N,), g), _r((M, N), g)
+    ref = (x.float() @ w.float().t() + b.float()).half().float() + r.float()
+    K1 = (K // 128) * 64
+    out = {}
+    try:
+        for v in (0, 1):
+            assert lib.ds_set_option(b"gemm_ring", v) == 0
+            o = [ops.gemm(x.to(DEV), w.to(DEV), b.to(DEV), r.to(DEV)),
+                 ops.gemm(x[:, :K1].contiguous().to(DEV), w.to(DEV), x2=x[:, K1:].contiguous().to(DEV))]
+            if N % 128 == 0:
+                wp, bp = pack_geglu(w, b)
+                o.append(ops.gemm(x.to(DEV), wp.to(DEV), bp.to(DEV), geglu=True))
+            out[v] = o
+    finally:
+        lib.ds_set_option(b"gemm_ring", 0)
+    _close(out[0][0], ref, what="ring bias+residual")
+    _close(out[0][1], x.float() @ w.float().t(), what="ring split A")
+    for a, c in zip(out[0], out[1]):
+        assert torch.equal(a, c), "ring-buffered and one-buffer kernels differ"
+
+
 @pytest.mark.parametrize("M,C", [(256, 128), (2048, 640), (777, 256)])
 def test_gemm_geglu(hip_lib, M, C):
     from diffsensei_amd.engine import pack_geglu
