@@ -193,7 +193,9 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x16 (&acc)[WR /
 // STAGES = 1: one 32-KiB LDS buffer, three (four at BM 64) blocks per CU - independent blocks hide each other's DMA latency;
 // STAGES = 2: two buffers, tile t+1 / t+2 in flight; STAGES >= 3: a ring of buffers with STAGES-1 tiles in flight and ONE
 // barrier per k-tile - for grids too small to give a CU several blocks (num_samples 1: M = 2048 rows), where the
-// one-buffer kernel spends every k-tile waiting out the full L2/HBM latency (profiles/r02_small_grid_gemm.txt).
+// one-buffer kernel spends every k-tile waiting out the full L2/HBM latency.  Equal to the one-buffer kernel when the
+// operands are MALL-hot (profiles/r02_small_batch_gemm_ab.txt), 6 % faster per launch inside the sampler where every weight
+// is read cold from HBM (31.2 vs 33.3 us, +4.8 % panels/s at num_samples 1: profiles/r02_ring_in_pipeline_ab.txt).
 template <int BM, bool CONV, int STAGES = 2>
 __global__ __launch_bounds__(256, (BM > 128 ? 1 : (STAGES >= 4 ? 1 : (STAGES == 1 ? (BM == 64 ? 4 : 3) : 2)))) void gemm_glds_kernel(const GemmParams p) {
     constexpr int MI = BM / 64;
@@ -653,7 +655,7 @@ Choice choose(const GemmParams& p, int batch) {
     } else if (small) {
         c.kind = K_GLDS1;
         // grids that leave a CU with at most two 64 x 128 blocks: nothing hides the DMA latency of the one-buffer kernel
-        // (33 us per launch at M = 2048, profiles/r02_small_grid_gemm.txt) -> ring of 4 (one block per CU) or 3 (two) buffers
+        // (33 us per launch at M = 2048, profiles/r02_ring_in_pipeline_ab.txt) -> ring of 4 (one block per CU) or 3 (two) buffers
         const long blocks64 = (long)((p.M + 63) / 64) * ((p.N + 127) / 128) * batch;
         if (g_gemm_ring != 1 && p.K >= 256 && blocks64 <= 512) {
             c.kind = K_RING;

@@ -35,6 +35,8 @@ int ds_device_info(int* cu_count, int* lds_bytes, char* arch_name, int arch_name
  *                        3 256x256 ping-pong (gemm_pp_kernel) | 10 halo-patch conv
  *   "gemm_pp_even"       1 (default) gemm_pp_kernel's persistent grid = ceil(tiles / rounds) blocks, every round full |
  *                        0 one block per CU with a partial last round
+ *   "gemm_ring"          0 (default) grids of <= 512 64x128 blocks (num_samples 1) use the ring-buffered
+ *                        gemm_glds_kernel<64,false,3|4> | 1 never (A/B: profiles/r02_ring_in_pipeline_ab.txt)
  *   "conv_halo_variant"  0 auto (16x16-pixel blocks from 1024 blocks on) | 1 force conv_halo_kernel (8x16 pixels) |
  *                        2 force conv_halo256_kernel (16x16 pixels)
  *   "attn_variant"       0 auto (64 query rows per wave from Nk >= 2048 and >= 512 blocks on) | 1 force
