@@ -41,6 +41,12 @@
 namespace {
 
 constexpr int HT = 16384;  // bytes of one half-tile: 128 rows x 64 k of f16
+// Every prologue is FOLLOWED by at least this many vector-memory instructions of the same wave before the tile's first
+// k-tile: the C stores of the previous tile's last two 32-row pieces (GEGLU: of all four) in the branch-free epilogues,
+// eight dummy LDS-DMA pieces (`pad_tail`) behind the first prologue and behind the generic epilogue, whose store count
+// depends on the tile's edges.  The counted waits of the first k-tiles leave exactly this many outstanding: more issued
+// than counted only waits longer, fewer would under-wait.
+constexpr int EX_TAIL = 8;
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
@@ -71,12 +77,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     typedef typename Elt<T>::v8 V8;
     typedef typename Elt<T>::v4 V4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const long bz = blockIdx.z;
     const int nk = p.K / 64;
-    const int l31 = lane & 31, lhi = lane >> 5;
     const bool geglu = p.epi == EPI_GEGLU;
     const int ntiles = p.tiles_m * p.tiles_n;
 
@@ -87,15 +91,26 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 
     // ---- staging: every wave moves LDS rows 16w .. 16w+15 of each half-tile (two 1-KiB LDS-DMA pieces).  The DMA
     // destination is lane-linear, so the XOR swizzle is applied to the lane's SOURCE chunk.
-    const int lrow = lane >> 3, slot = lane & 7;
+    // Everything derived from the lane id is REBUILT per output tile from an opaque v_mbcnt (derive_stage / derive_frag):
+    // kept live across the epilogue these 13 registers (and `lane` itself) pushed the epilogue's own values - packed
+    // bias, residual rows - into scratch, and a scratch reload waits with vmcnt(0).
+    auto lane_id = [&]() -> int {
+        unsigned z = 0;
+        asm volatile("" : "+v"(z));  // opaque start value: the count is recomputed here, not kept in a register per kernel
+        return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z));
+    };
     unsigned oA[2], oB[2];  // BYTE offsets, unsigned: (uniform base) + zext(lane offset) selects the SGPR-base address mode
+    auto derive_stage = [&]() {
+        const int ln = lane_id();
+        const int lrow = ln >> 3, slot = ln & 7;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int r = j * 8 + lrow;                     // row within the wave's 16
-        const int chunk = slot ^ ((r >> 1) & 7);        // (16w + r) >> 1 & 7 == (r >> 1) & 7
-        oA[j] = (unsigned)(r * (int)p.lda + chunk * 8) * 2u;
-        oB[j] = (unsigned)(r * (int)p.ldw + chunk * 8) * 2u;
-    }
+        for (int j = 0; j < 2; ++j) {
+            const int r = j * 8 + lrow;                     // row within the wave's 16
+            const int chunk = slot ^ ((r >> 1) & 7);        // (16w + r) >> 1 & 7 == (r >> 1) & 7
+            oA[j] = (unsigned)(r * (int)p.lda + chunk * 8) * 2u;
+            oB[j] = (unsigned)(r * (int)p.ldw + chunk * 8) * 2u;
+        }
+    };
     // tile columns of this wave's staging rows, per B half (see the header): first column of its 16
     const int cb0 = geglu ? (wave >> 2) * 128 + (wave & 3) * 16 : (wave >> 1) * 64 + (wave & 1) * 16;
     const int cbh = geglu ? 64 : 32;
@@ -145,15 +160,39 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
         }
     };
 
-    // ---- fragment addresses: row r of a half-tile at r*128, 16-byte chunk c at ((c ^ ((r>>1)&7)) << 4)
-    const int sw = (l31 >> 1) & 7;
-    unsigned fA[4], fB[4];  // LDS byte offsets, one per k-step: half / buffer / row-block are immediate ds_read offsets
+    // Interior tiles without a per-row bias or activation take the branch-free epilogues (all tiles of the UNet's shapes)
+    auto is_fast = [&](int tm0, int tn0) -> bool {
+        return tm0 + 256 <= p.M && tn0 + 256 <= p.N && !p.rowbias && (geglu || p.epi == EPI_NONE);
+    };
+    char* const ep = smem + 8 * HT + wave * 4096;  // wave-private transposition tile of the epilogue
+    // One LDS-DMA piece: the bias values of the wave's 64 output columns (GEGLU: 32 hidden | their 32 gates) -> bytes
+    // 0..127 of `ep` (lanes 8.. repeat them).  Issued behind the tile's prologue (and the previous tile's epilogue, which
+    // still uses `ep`), so it is one of the EX_TAIL instructions and has landed long before the epilogue reads it.
+    auto stage_bias = [&](int tn0) {
+        const int l7 = lane_id() & 7;
+        const int col = geglu ? tn0 + (wc >> 1) * 128 + (wc & 1) * 32 + (l7 >> 2) * 64 + (l7 & 3) * 8 : tn0 + wc * 64 + l7 * 8;
+        __builtin_amdgcn_global_load_lds((glb_void*)(p.bias + col), (lds_void*)ep, 16, 0, 0);
+    };
+    auto pad_tail = [&]() {  // EX_TAIL harmless pieces into the idle upper 3 KiB of `ep`
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-        fA[kk] = (wr * 64 + l31) * 128 + (((kk * 2 + lhi) ^ sw) << 4);
-        fB[kk] = 4 * HT + (wc * 32 + l31) * 128 + (((kk * 2 + lhi) ^ sw) << 4);
-        asm volatile("" : "+v"(fA[kk]), "+v"(fB[kk]));  // keep the eight addresses resident: no VALU in the load phases
-    }
+        for (int j = 0; j < EX_TAIL; ++j)
+            __builtin_amdgcn_global_load_lds((glb_void*)(reinterpret_cast<const char*>(gA[0]) + (size_t)oA[0]),
+                                             (lds_void*)(ep + 1024 + (j % 3) * 1024), 16, 0, 0);
+    };
+
+    // ---- fragment addresses: row r of a half-tile at r*128, 16-byte chunk c at ((c ^ ((r>>1)&7)) << 4)
+    unsigned fA[4], fB[4];  // LDS byte offsets, one per k-step: half / buffer / row-block are immediate ds_read offsets
+    auto derive_frag = [&]() {
+        const int ln = lane_id();
+        const int l31 = ln & 31, lhi = ln >> 5;
+        const int sw = (l31 >> 1) & 7;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            fA[kk] = (wr * 64 + l31) * 128 + (((kk * 2 + lhi) ^ sw) << 4);
+            fB[kk] = 4 * HT + (wc * 32 + l31) * 128 + (((kk * 2 + lhi) ^ sw) << 4);
+            asm volatile("" : "+v"(fA[kk]), "+v"(fB[kk]));  // keep the eight addresses resident: no VALU in the load phases
+        }
+    };
     V8 dummy = {};
     if constexpr ((DBG & 4) != 0) asm volatile("" : "+v"(dummy));
     auto readA = [&](int half, int buf, int mi, int kk) -> V8 {
@@ -169,23 +208,21 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     // Each half-tile is staged as soon as its slot is free (2 phases after the slot's read) and waited for one phase
     // before its own read, so 5 half-tiles (80 KiB) are in flight per CU in the steady state: ~10 barrier intervals
     // (~1.5 us) of latency cover.  (One wait per k-tile - vmcnt(6) in P4 - measured the same within noise.)
-    auto wait_newer = [&](int n) {
-        switch (n) {
-            case 5: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-            case 4: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-            case 2: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-            case 1: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        }
+    // EX: further vector-memory instructions this wave has issued AFTER the half-tile waited for and that may stay in
+    // flight as well - the previous output tile's last C stores (EX_TAIL).  vmcnt counts loads and stores alike and they
+    // retire in issue order, so "all but the n newest" is exact whatever the mix.
+    auto wait_newer = [&](auto nc, auto exc) {
+        constexpr int N = 2 * decltype(nc)::value + decltype(exc)::value;
+        static_assert(N <= 63, "vmcnt is a 6-bit field");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
     };
 
     f32x16 acc[4][2];
     constexpr bool mma_on = (DBG & 1) == 0;
     // No branch anywhere in a k-tile (a taken scalar branch costs more than the slack a phase has): past the end of K
     // the stages simply re-fetch the last k-tile into a buffer nobody reads, so the counted waits never change.
-    auto ktile = [&](auto bufc, int kt) {
+    auto ktile = [&](auto bufc, auto exa, auto exb, int kt) {  // exa: EX of the P1 wait, exb: of the P2 / P4 waits
         constexpr int B = decltype(bufc)::value;
-        constexpr bool n1 = true, n2 = true;
         const int kt1 = min(kt + 1, nk - 1), kt2 = min(kt + 2, nk - 1);
         V8 bl[4], br[4], a0[4][2], a1[4][2];
         // ---------------- P1: B0 strip (first: retired before the barrier, see WAR above) + A0 rows
@@ -199,7 +236,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
         }
         __builtin_amdgcn_sched_barrier(0);
         stage(0, 1, B ^ 1, kt1);
-        wait_newer(n1 ? 5 : 1);  // B1(kt), read in P2: newer = A1(kt) [+ B0 A0 B1 A1 of kt+1]
+        wait_newer(IC<5>{}, exa);  // B1(kt), read in P2: newer = A1(kt) + B0 A0 B1 A1 of kt+1
         asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
         PP_BARRIER();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -218,7 +255,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
         for (int kk = 0; kk < 4; ++kk) br[kk] = readB(1, B, kk);
         __builtin_amdgcn_sched_barrier(0);
         stage(1, 0, B, kt2);
-        wait_newer((n1 ? 4 : 0) + (n2 ? 1 : 0));  // A1(kt), read in P3: newer = all of kt+1 [+ B0(kt+2)]
+        wait_newer(IC<5>{}, exb);  // A1(kt), read in P3: newer = all of kt+1 + B0(kt+2)
         PP_BARRIER();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         PP_PRIO(1);
@@ -253,7 +290,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
         PP_BARRIER();
         // ---------------- P4: no reads (B0 strip still in registers); the k-tile's one counted wait
         stage(1, 1, B, kt2);
-        if (n1) wait_newer(n2 ? 5 : 2);  // B0 A0 (kt+1), read in the next P1: newer = B1 A1 (kt+1) [+ B0 A0 B1 (kt+2)]
+        wait_newer(IC<5>{}, exb);  // B0 A0 (kt+1), read in the next P1: newer = B1 A1 (kt+1) + B0 A0 B1 (kt+2)
         PP_BARRIER();
         PP_PRIO(1);
         if constexpr (mma_on) {
@@ -269,7 +306,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 
     T* const Cg = reinterpret_cast<T*>(p.C) + bz * p.sC;
     const T* const Rg = p.residual ? reinterpret_cast<const T*>(p.residual) + bz * p.sR : nullptr;
-    char* const ep = smem + 8 * HT + wave * 4096;  // wave-private transposition tile
+    const bool nt_store = (p.debug & 512) != 0;      // experiment: C tiles leave with the non-temporal hint
 
     int id = tile_local;
     if (id >= ntiles) return;
@@ -280,8 +317,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     }
     int m0, n0;
     set_tile(id, m0, n0);
+    derive_stage();
     stage_prologue();
-    bool first = true;
+    if (p.bias && is_fast(m0, n0)) stage_bias(n0);
+    pad_tail();  // no epilogue yet behind the first prologue
     while (true) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -289,55 +328,68 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        // k-tile 0 must have landed; after the first tile the previous epilogue's stores are in the count too
-        if (first) wait_newer(nk > 1 ? 5 : 2);  // A0 B0 of k-tile 0: newer = B1 A1 [+ B0 A0 B1 of k-tile 1]
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        first = false;
+        derive_frag();
+        // A0 B0 of k-tile 0 must have landed: all but the five newer half-tiles of the prologue - and the EX_TAIL
+        // vector-memory instructions issued behind them (the previous tile's last C stores), which keep draining under
+        // the first k-tiles.  (A vmcnt(0) here parked every wave of the CU until its C stores were acknowledged - and the
+        // whole chip writes its 256 x 256 tiles in the same few microseconds of each round.)  They are older than
+        // A1(k-tile 1), staged in k-tile 0's P1: the waits for it and for everything younger (k-tile 1's P2 on) already
+        // imply them.  gemm_debug bit 8 (256): drain first (A/B).
+        if ((p.debug & 256) != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wait_newer(IC<5>{}, IC<EX_TAIL>{});
         PP_BARRIER();
         if (wr == 1) PP_BARRIER();  // group 1 runs one barrier behind group 0 from here on
-        for (int kt = 0; kt < nk; kt += 2) {  // nk is even
-            ktile(IC<0>{}, kt);
-            ktile(IC<1>{}, kt + 1);
+        ktile(IC<0>{}, IC<EX_TAIL>{}, IC<EX_TAIL>{}, 0);
+        ktile(IC<1>{}, IC<EX_TAIL>{}, IC<0>{}, 1);
+        for (int kt = 2; kt < nk; kt += 2) {  // nk is even
+            ktile(IC<0>{}, IC<0>{}, IC<0>{}, kt);
+            ktile(IC<1>{}, IC<0>{}, IC<0>{}, kt + 1);
         }
         // (the over-fetched stages may still be in flight: a wave only ever writes its own 16 rows of a slot, and its
         // loads return in order, so the next tile's prologue into the same slots lands after them)
         if (wr == 0) PP_BARRIER();  // balance group 1's extra barrier: every ds_read of this tile has retired
 
-        // ---- next tile's pipeline fill goes out before this tile's epilogue
-        const int cm0 = m0, cn0 = n0;
-        id += G;
-        const bool more = id < ntiles;
-        if (more) {
-            set_tile(id, m0, n0);
-            stage_prologue();
-        }
-
         // ---- epilogue.  D layout (operands swapped): lane holds tile row ..+(lane&31); register r of a fragment is
         // column (r&3) + 8*(r>>2) + 4*(lane>>5) of its 32-column strip.
         // (the lane-derived epilogue constants are rebuilt from an opaque copy so they are not kept live - spilled -
         // across the main loop)
-        int lane_e = lane;
-        asm volatile("" : "+v"(lane_e));
+        const int cm0 = __builtin_amdgcn_readfirstlane(m0), cn0 = __builtin_amdgcn_readfirstlane(n0);
+        const int lane_e = lane_id();
         const int l31 = lane_e & 31, lhi = lane_e >> 5;
         // Interior tiles (all of them on the UNet's shapes) take a branch-free epilogue: the generic code below tests
         // bias / row bias / bounds per 4 values, and every test became a branch with an s_waitcnt vmcnt(0) behind each
         // bias or residual load - loads, converts and stores ran strictly one after the other (4-8 us per tile, all of
-        // it with the matrix pipe idle).  Here the bias values are fetched once per tile, and the four residual loads of a
-        // 32-row piece are in flight while the piece is transposed through LDS.
-        const bool fast = cm0 + 256 <= p.M && cn0 + 256 <= p.N && !p.rowbias && (geglu || p.epi == EPI_NONE);
-        if (fast && geglu) {
-            const int nw = cn0 + (wc >> 1) * 128 + (wc & 1) * 32;
-            const int no = (cn0 >> 1) + wc * 32;
-            V4 bh[4], bg[4];  // kept packed: the accumulators still occupy 128 registers here
+        // it with the matrix pipe idle).  Here the bias values are fetched once per tile, and the residual loads of a
+        // 32-row piece are in flight while the previous piece is transposed through LDS and stored.
+        const bool fast = is_fast(cm0, cn0);
+        const int nwg = cn0 + (wc >> 1) * 128 + (wc & 1) * 32;  // GEGLU: the wave's hidden strip; its gates 64 columns further
+        const int nwp = cn0 + wc * 64;                          // plain: the wave's 64 adjacent columns
+        // The bias slice of this tile has been sitting in the first 128 bytes of the wave's transposition tile since the
+        // tile's first k-tiles (`stage_bias`): reading it is an LDS read.  (Loaded from memory here, its wait - vmcnt
+        // retires in issue order - either drained the next tile's prologue or, requested ahead of it, was turned into a
+        // vmcnt(0) by the compiler all the same.)  Kept packed: the accumulators still occupy 128 registers.
+        V4 bq[8];
+        if (fast) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) bh[g] = bg[g] = V4{0, 0, 0, 0};
+            for (int g = 0; g < 8; ++g) bq[g] = V4{0, 0, 0, 0};
             if (p.bias) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    bh[g] = *reinterpret_cast<const V4*>(p.bias + nw + 8 * g + 4 * lhi);
-                    bg[g] = *reinterpret_cast<const V4*>(p.bias + nw + 64 + 8 * g + 4 * lhi);
-                }
+                for (int g = 0; g < 8; ++g) bq[g] = *reinterpret_cast<const V4*>(ep + (g >> 2) * 64 + 2 * (8 * (g & 3) + 4 * lhi));
             }
+        }
+        PP_FENCE();
+
+        // ---- next tile's pipeline fill goes out before this tile's epilogue
+        id += G;
+        const bool more = id < ntiles;
+        if (more) {
+            set_tile(id, m0, n0);
+            derive_stage();
+            stage_prologue();
+        }
+        PP_FENCE();
+        if (fast && geglu) {
+            const int no = (cn0 >> 1) + wc * 32;
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) {
                 const int mb = cm0 + (mi >> 1) * 128 + wr * 64 + (mi & 1) * 32;
@@ -347,8 +399,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
                     V4 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float hq = (float)(T)(acc[mi][0][4 * g + e] + (float)bh[g][e]);
-                        const float gq = (float)(T)(acc[mi][1][4 * g + e] + (float)bg[g][e]);
+                        const float hq = (float)(T)(acc[mi][0][4 * g + e] + (float)bq[g][e]);
+                        const float gq = (float)(T)(acc[mi][1][4 * g + e] + (float)bq[4 + g][e]);
                         o[e] = (T)(hq * (float)(T)ds_gelu_erf(gq));
                     }
                     *reinterpret_cast<V4*>(ep + l31 * 64 + ((((c >> 3) ^ (l31 >> 2)) & 3) << 4) + ((c >> 2) & 1) * 8) = o;
@@ -357,53 +409,63 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
                 for (int i = 0; i < 2; ++i) {
                     const int row = i * 16 + (lane_e >> 2), ch = lane_e & 3;
                     const V8 v = *reinterpret_cast<const V8*>(ep + row * 64 + (((ch ^ (row >> 2)) & 3) << 4));
-                    *reinterpret_cast<V8*>(Cg + (long)(mb + row) * p.ldc + no + ch * 8) = v;
+                    T* dst = Cg + (long)(mb + row) * p.ldc + no + ch * 8;
+                    if (nt_store) __builtin_nontemporal_store(v, reinterpret_cast<V8*>(dst));
+                    else *reinterpret_cast<V8*>(dst) = v;
                 }
             }
         } else if (fast) {
-            const int nw = cn0 + wc * 64;
-            V4 bv[2][4];
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) bv[ni][g] = V4{0, 0, 0, 0};
-            if (p.bias) {
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        bv[ni][g] = *reinterpret_cast<const V4*>(p.bias + nw + ni * 32 + 8 * g + 4 * lhi);
-            }
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-                const int mb = cm0 + (mi >> 1) * 128 + wr * 64 + (mi & 1) * 32;
+            // two straight-line instances (with / without a residual): one body with `if (Rg)` inside carried the
+            // never-written residual registers of the other case around the whole tile loop as spills
+            auto plain = [&](auto resc) {
+                constexpr bool RES = decltype(resc)::value != 0;
                 V8 rv[4];
-                if (Rg) {  // all four 16-byte pieces of the residual rows go out before the transposition
+                auto load_res = [&](int mi) {
+                    const int mb = cm0 + (mi >> 1) * 128 + wr * 64 + (mi & 1) * 32;
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        rv[i] = *reinterpret_cast<const V8*>(Rg + (long)(mb + i * 8 + (lane_e >> 3)) * p.ldr + nw + (lane_e & 7) * 8);
-                }
+                        rv[i] = *reinterpret_cast<const V8*>(Rg + (long)(mb + i * 8 + (lane_e >> 3)) * p.ldr + nwp + (lane_e & 7) * 8);
+                };
+                if constexpr (RES) load_res(0);
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
+                for (int mi = 0; mi < 4; ++mi) {
+                    const int mb = cm0 + (mi >> 1) * 128 + wr * 64 + (mi & 1) * 32;
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int c = ni * 32 + 8 * g + 4 * lhi;
-                        V4 o;
+                    for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = (T)(acc[mi][ni][4 * g + e] + (float)bv[ni][g][e]);
-                        *reinterpret_cast<V4*>(ep + l31 * 128 + ((((c >> 3) ^ (l31 >> 1)) & 7) << 4) + ((c >> 2) & 1) * 8) = o;
+                        for (int g = 0; g < 4; ++g) {
+                            const int c = ni * 32 + 8 * g + 4 * lhi;
+                            V4 o;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = (T)(acc[mi][ni][4 * g + e] + (float)bq[ni * 4 + g][e]);
+                            *reinterpret_cast<V4*>(ep + l31 * 128 + ((((c >> 3) ^ (l31 >> 1)) & 7) << 4) + ((c >> 2) & 1) * 8) = o;
+                        }
+                    V8 v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int row = i * 8 + (lane_e >> 3), ch = lane_e & 7;
+                        v[i] = *reinterpret_cast<const V8*>(ep + row * 128 + (((ch ^ (row >> 1)) & 7) << 4));
+                        if constexpr (RES) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[i][e] = (T)((float)v[i][e] + (float)rv[i][e]);
+                        }
+                    }
+                    // the NEXT piece's residual rows are requested before this piece's stores: the wait for them then
+                    // leaves the stores in flight (requested behind them, it would wait for their acknowledgement)
+                    if constexpr (RES) {
+                        if (mi < 3) load_res(mi + 1);
                     }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int row = i * 8 + (lane_e >> 3), ch = lane_e & 7;
-                    V8 v = *reinterpret_cast<const V8*>(ep + row * 128 + (((ch ^ (row >> 1)) & 7) << 4));
-                    if (Rg) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = (T)((float)v[e] + (float)rv[i][e]);
+                    for (int i = 0; i < 4; ++i) {
+                        const int row = i * 8 + (lane_e >> 3), ch = lane_e & 7;
+                        T* dst = Cg + (long)(mb + row) * p.ldc + nwp + ch * 8;
+                        if (nt_store) __builtin_nontemporal_store(v[i], reinterpret_cast<V8*>(dst));
+                        else *reinterpret_cast<V8*>(dst) = v[i];
                     }
-                    *reinterpret_cast<V8*>(Cg + (long)(mb + row) * p.ldc + nw + ch * 8) = v;
                 }
-            }
+            };
+            if (__builtin_amdgcn_readfirstlane((int)(Rg != nullptr))) plain(IC<1>{});
+            else plain(IC<0>{});
         } else if (geglu) {
             const int nw = cn0 + (wc >> 1) * 128 + (wc & 1) * 32;  // hidden strip; gates 64 columns further
             const int no = (cn0 >> 1) + wc * 32;                   // first output column of the wave
@@ -514,9 +576,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
             }
         }
         if (!more) break;
+        if (p.bias && is_fast(m0, n0)) stage_bias(n0);  // the next tile's (m0, n0 were advanced by set_tile above)
+        if (!fast) pad_tail();                          // generic epilogue: its store count depends on the tile's edges
     }
     if constexpr ((DBG & 16) != 0) {
-        if (blockIdx.x == 0 && blockIdx.z == 0 && tid == 0) {
+        if (blockIdx.x == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
             unsigned long long* o = reinterpret_cast<unsigned long long*>(p.C);
             __builtin_amdgcn_s_waitcnt(0);
             o[0] = __builtin_readcyclecounter() - probe_c0;
