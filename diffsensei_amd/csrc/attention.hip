@@ -318,7 +318,24 @@ __global__ __launch_bounds__(256, 2) void ip_attn_kernel(const IPAttnParams p, i
     }
     __syncthreads();
 
-    const float* bbox_b = p.bbox + (long)b * p.max_ips * 4;
+    // The character boxes of this image, fetched ONCE per block: lane k reads box k and the eight (x1, y1, x2, y2) are
+    // broadcast into scalar registers.  (Read inside the tile loop, the short-circuited test became a chain of two
+    // dependent global loads per box, each behind an s_waitcnt vmcnt(0) that also waited for the next tile's Q rows
+    // requested just before it - every query tile stalled for whole memory round trips.)  Boxes >= max_ips: x1 = 2,
+    // which no grid point (x in [0, 1]) satisfies.
+    float box[8][4];
+    {
+        const float* bbox_b = p.bbox + (long)b * p.max_ips * 4;
+        float bv[4] = {2.f, 2.f, -1.f, -1.f};
+        if (lane < p.max_ips) {
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) bv[c4] = bbox_b[4 * lane + c4];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) box[k][c4] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bv[c4]), k));
+    }
     const float ip_scale = p.ip_scale_ptr ? *p.ip_scale_ptr : p.ip_scale;
     for (int it = 0; it < qt; ++it) {
         const int q0 = (blockIdx.x * qt + it) * 128 + wave * 32;
@@ -328,7 +345,14 @@ __global__ __launch_bounds__(256, 2) void ip_attn_kernel(const IPAttnParams p, i
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) qf[kk] = qn[kk];
         if (it + 1 < qt) load_q(it + 1);  // next tile's Q rows land under this tile's MFMAs / softmax
-        const unsigned inside = region_flags(bbox_b, p.max_ips, qidx, p.mask_h, p.mask_w);
+        unsigned inside = 0;  // bit k set <=> the token lies in box k (region_flags() with the boxes in registers)
+        {
+            const int yi = qidx / p.mask_w, xi = qidx - yi * p.mask_w;
+            const float x = linspace01(xi, p.mask_w), y = linspace01(yi, p.mask_h);
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                inside |= (unsigned)((x >= box[k][0]) & (x <= box[k][2]) & (y >= box[k][1]) & (y <= box[k][3])) << k;
+        }
         // 96-bit "attendable IP key" set of this query row: dummy keys [0, n_dummy) iff the token lies in NO box,
         // character k's keys [n_dummy + k*tpi, +tpi) iff it lies in box k  (reference :155-163)
         unsigned open_ip[3] = {0u, 0u, 0u};

@@ -68,7 +68,7 @@ int ds_set_option(const char* key, int value) {
         return 0;
     }
     if (strcmp(key, "gemm_ring") == 0) {
-        DS_REQUIRE(value >= 0 && value <= 2, "gemm_ring must be 0 (auto), 1 (off) or 2 (every 64-row grid)");
+        DS_REQUIRE(value >= 0 && value <= 1, "gemm_ring must be 0 (auto) or 1 (off)");
         ds_gemm_set_ring(value);
         return 0;
     }

@@ -23,7 +23,7 @@
 
 static int g_gemm_variant = 0;  // 0 auto; A/B: 1 register staging, 2 two-buffer glds, 3 ping-pong 256x256, 7 two-buffer BM 64, 8/9 one-buffer glds (BM 128/64), 10 halo conv
 void ds_gemm_set_variant(int v) { g_gemm_variant = v; }
-static int g_gemm_ring = 0;  // 0 auto, 1 never use the ring-buffered small-grid kernel, 2 use it for every 64-row grid (A/B)
+static int g_gemm_ring = 0;  // 0 auto, 1 never use the ring-buffered small-grid kernel (A/B)
 void ds_gemm_set_ring(int v) { g_gemm_ring = v; }
 static int g_gemm_debug = 0;  // ablation switches, see GemmParams::debug
 void ds_gemm_set_debug(int v) { g_gemm_debug = v; }
@@ -657,7 +657,7 @@ Choice choose(const GemmParams& p, int batch) {
         // grids that leave a CU with at most two 64 x 128 blocks: nothing hides the DMA latency of the one-buffer kernel
         // (33 us per launch at M = 2048, profiles/r02_ring_in_pipeline_ab.txt) -> ring of 4 (one block per CU) or 3 (two) buffers
         const long blocks64 = (long)((p.M + 63) / 64) * ((p.N + 127) / 128) * batch;
-        if (g_gemm_ring != 1 && p.K >= 256 && blocks64 <= (g_gemm_ring == 2 ? 1024 : 512)) {
+        if (g_gemm_ring != 1 && p.K >= 256 && blocks64 <= 512) {  // every 64-row grid (<= 768 blocks): -1 % (profiles/r02_ring_wide_ab.txt)
             c.kind = K_RING;
             c.bm = blocks64 <= 256 ? 4 : 3;   // bm carries the ring depth for this kind
         }

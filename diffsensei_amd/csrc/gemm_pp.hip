@@ -25,8 +25,12 @@
 //          which is legal only because P1 issues the B0 reads first and retires them (lgkmcnt(8)) before P1's
 //          first barrier.
 //   * persistent: a block walks tiles id = round * grid + chunk-of-its-XCD; the operand loads of the NEXT output
-//     tile's first k-tiles are issued before the epilogue of the current one, so the pipeline fill hides under the
-//     C stores.
+//     tile's first k-tiles are issued before the epilogue of the current one, so the pipeline fill hides under it.
+//     For that to be true no wait of the epilogue may cover the prologue (vmcnt retires in issue order): the tile's
+//     bias slice is staged into LDS with the tile's first k-tiles and read from there, the residual rows of a 32-row
+//     piece are requested before the previous piece's stores, and the C stores themselves keep draining under the next
+//     tile's first k-tiles (EX_TAIL).  Measured (profiles/r02_pp_epilogue_ab.txt): M = 32768, N = 2560, K = 1280
+//     222 -> 187 us (967 -> 1146 TFLOP/s, F.linear / hipBLASLt on the same box: 1041-1168); GEGLU 893 -> 772 us.
 //
 // Column ownership is chosen for the epilogue (the B half-tiles are just a permutation of the 256 tile columns):
 //   plain  half h, LDS row r -> tile column (r>>5)*64 + h*32 + (r&31): a wave ends up with 64 adjacent columns, i.e.
@@ -306,7 +310,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 
     T* const Cg = reinterpret_cast<T*>(p.C) + bz * p.sC;
     const T* const Rg = p.residual ? reinterpret_cast<const T*>(p.residual) + bz * p.sR : nullptr;
-    const bool nt_store = (p.debug & 512) != 0;      // experiment: C tiles leave with the non-temporal hint
 
     int id = tile_local;
     if (id >= ntiles) return;
@@ -409,9 +412,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
                 for (int i = 0; i < 2; ++i) {
                     const int row = i * 16 + (lane_e >> 2), ch = lane_e & 3;
                     const V8 v = *reinterpret_cast<const V8*>(ep + row * 64 + (((ch ^ (row >> 2)) & 3) << 4));
-                    T* dst = Cg + (long)(mb + row) * p.ldc + no + ch * 8;
-                    if (nt_store) __builtin_nontemporal_store(v, reinterpret_cast<V8*>(dst));
-                    else *reinterpret_cast<V8*>(dst) = v;
+                    *reinterpret_cast<V8*>(Cg + (long)(mb + row) * p.ldc + no + ch * 8) = v;
                 }
             }
         } else if (fast) {
@@ -458,9 +459,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int row = i * 8 + (lane_e >> 3), ch = lane_e & 7;
-                        T* dst = Cg + (long)(mb + row) * p.ldc + nwp + ch * 8;
-                        if (nt_store) __builtin_nontemporal_store(v[i], reinterpret_cast<V8*>(dst));
-                        else *reinterpret_cast<V8*>(dst) = v[i];
+                        *reinterpret_cast<V8*>(Cg + (long)(mb + row) * p.ldc + nwp + ch * 8) = v[i];
                     }
                 }
             };

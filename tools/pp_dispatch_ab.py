@@ -24,7 +24,8 @@ def timed(fn, reps=20):
 
 for B in (6, 8, 10, 12, 16):
     for name, M, N, K, mode in [("ff2_L2", B * 1024, 1280, 5120, "res"), ("proj_L2", B * 1024, 1280, 1280, "res"),
-                                ("qk_L2", B * 1024, 2560, 1280, None)]:
+                                ("qk_L2", B * 1024, 2560, 1280, None), ("qk_L1", B * 4096, 1280, 640, None),
+                                ("ff2_L1", B * 4096, 640, 2560, "res"), ("proj_L1", B * 4096, 640, 640, "res")]:
         x, w, b = R(M, K), R(N, K) * (K ** -0.5) * 2, R(N)
         res = R(M, N) if mode == "res" else None
         y = ops.gemm(x, w, b, residual=res)
