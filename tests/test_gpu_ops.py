@@ -147,6 +147,60 @@ def test_gemm_pingpong_geglu_and_dispatch(hip_lib):
     _close(auto, x2.float() @ w2.float().t(), what="auto dispatch")
 
 
+@pytest.mark.parametrize("M,N,K,mode", [(32768 - 48, 1280, 1280, "res"), (16384, 2560 - 64, 1280, "bias"),
+                                        (24576, 1280, 256, "inplace"), (16384, 2560, 1280, "none"),
+                                        (8192, 10240, 1280, "geglu"), (20480, 1280, 640, "gelu")])
+def test_gemm_pingpong_tile_handover(hip_lib, M, N, K, mode):
+    """Several output tiles per persistent block (> 256 tiles), so every hand-over path of gemm_pp_kernel runs: the bias
+    slice staged through LDS, residual rows requested a piece ahead (also in place: C == residual), interior tiles next
+    to ragged ones (branch-free and generic epilogues alternate inside one block's walk, `pad_tail`), no bias at all,
+    an activation (generic epilogue everywhere).  The C stores of a tile drain under the next tile's first k-tiles
+    (counted waits): every launch must equal, bit for bit, the variant that drains them first (gemm_debug 256) - an
+    under-counted wait shows up as a rare wrong tile, hence the repetitions - and agree with fp32."""
+    from diffsensei_amd import _lib
+    from diffsensei_amd.engine import pack_geglu
+    ops = _ops(hip_lib)
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M + N + K)
+    x, w = _r((M, K), g).to(DEV), _r((N, K), g, 1 / math.sqrt(K)).to(DEV)
+    b = None if mode == "none" else _r((N,), g).to(DEV)
+    res = _r((M, N), g).to(DEV) if mode in ("res", "inplace") else None
+    kw = {}
+    if mode == "geglu":
+        w, b = pack_geglu(w, b)
+        kw["geglu"] = True
+    if mode == "gelu":
+        kw["act"] = "gelu"
+
+    def run(out=None):
+        if mode == "inplace":
+            buf = res.clone()
+            return ops.gemm(x, w, b, residual=buf, out=buf)
+        return ops.gemm(x, w, b, residual=res, out=out, **kw)
+
+    try:
+        assert lib.ds_set_option(b"gemm_variant", 3) == 0
+        assert lib.ds_set_option(b"gemm_debug", 256) == 0
+        drained = run().clone()
+        assert lib.ds_set_option(b"gemm_debug", 0) == 0
+        for _ in range(10):
+            assert torch.equal(run(), drained)
+    finally:
+        lib.ds_set_option(b"gemm_debug", 0)
+        lib.ds_set_option(b"gemm_variant", 0)
+    y = x.float() @ w.float().t()
+    if b is not None:
+        y = y + b.float()
+    if mode == "geglu":  # packed layout: every 128 columns = 64 hidden | their 64 gates
+        t = y.half().float().view(M, N // 128, 2, 64)
+        ref = (t[:, :, 0] * F.gelu(t[:, :, 1]).half().float()).reshape(M, N // 2)
+    elif mode == "gelu":
+        ref = F.gelu(y)
+    else:
+        ref = y.half().float() + (res.float() if res is not None else 0)
+    _close(drained, ref, what=f"pingpong hand-over {mode}")
+
+
 @pytest.mark.parametrize("M,N,K", [(2048, 1280, 1280), (2048, 2560, 1280), (2048, 1280, 5120), (8192, 640, 640),
                                    (200, 136, 256), (64, 128, 320), (1000, 640, 2560), (4096, 1280, 1280)])
 def test_gemm_ring_buffered_small_grid_kernel(hip_lib, M, N, K):
