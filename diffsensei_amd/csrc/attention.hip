@@ -87,7 +87,15 @@ __global__ __launch_bounds__(256, 2) void self_attn_kernel(const SelfAttnParams 
         for (int j = 0; j < 2; ++j) {
             const int row = r0 + 32 * j;
             *reinterpret_cast<h8*>(&sK[buf][row * 128 + swz(row, c8)]) = rk[j];
-            *reinterpret_cast<h8*>(&sV[buf][row * 128 + swz(row, c8)]) = rv[j];
+            // V^T rows are stored with the four 4-key pieces of every 16-key group in the order 0 2 1 3: the P fragment
+            // leaves the score MFMA holding keys {0-3, 8-11} (lanes 0-31) or {4-7, 12-15} (lanes 32-63) of a group, so
+            // its V^T operand is then ONE 16-byte read (two 8-byte reads + four moves per fragment before)
+            h4 lo, hi;
+            lo[0] = rv[j][0]; lo[1] = rv[j][1]; lo[2] = rv[j][2]; lo[3] = rv[j][3];
+            hi[0] = rv[j][4]; hi[1] = rv[j][5]; hi[2] = rv[j][6]; hi[3] = rv[j][7];
+            const int g2 = c8 & ~1, odd8 = (c8 & 1) * 8;
+            *reinterpret_cast<h4*>(&sV[buf][row * 128 + swz(row, g2) + odd8]) = lo;
+            *reinterpret_cast<h4*>(&sV[buf][row * 128 + swz(row, g2 + 1) + odd8]) = hi;
         }
     };
 
@@ -194,12 +202,7 @@ __global__ __launch_bounds__(256, 2) void self_attn_kernel(const SelfAttnParams 
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
                     const int row = db * 32 + l31;
-                    const int ch = kb * 4 + hb * 2;
-                    const h4 v0 = *reinterpret_cast<const h4*>(&sV[buf][row * 128 + swz(row, ch) + 8 * lhi]);
-                    const h4 v1 = *reinterpret_cast<const h4*>(&sV[buf][row * 128 + swz(row, ch + 1) + 8 * lhi]);
-                    h8 vf;
-                    vf[0] = v0[0]; vf[1] = v0[1]; vf[2] = v0[2]; vf[3] = v0[3];
-                    vf[4] = v1[0]; vf[5] = v1[1]; vf[6] = v1[2]; vf[7] = v1[3];
+                    const h8 vf = *reinterpret_cast<const h8*>(&sV[buf][row * 128 + swz(row, kb * 4 + hb * 2 + lhi)]);
 #pragma unroll
                     for (int qb = 0; qb < QB; ++qb)
                         ot[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[qb], ot[qb][db], 0, 0, 0);
