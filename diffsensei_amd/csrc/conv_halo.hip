@@ -12,9 +12,14 @@
 // the 128 x 128 GEMM relies on (gemm.hip, STAGES = 1 schedule: wait, barrier, all fragments to registers, barrier,
 // refill the single W buffer under the 16 MFMAs).
 //
-// The patch is written by LDS-DMA (lane-linear destination), so it is dense [row][64 ch] with the same XOR swizzle as
-// every other tile (16-byte chunk c of row q at slot c ^ ((q>>1)&7)); because the tap shift changes q per lane, the
-// reader rebuilds its swizzle per tap: base = q*128 + ((lhi ^ (q>>1)&7) << 4), k-step kk at base ^ (kk << 5).
+// The patch is written by LDS-DMA (lane-linear destination), so it is dense [row][64 ch]; 16-byte chunk c of patch pixel
+// q = (qy, qx) sits at slot c ^ ((qx>>1)&7) - swizzled by the patch COLUMN.  A fragment read touches 16 + 16 pixels of two
+// adjacent patch rows (q jumps by 18 between lanes 15 and 16), so the row-index swizzle of the other tiles, (q>>1)&7, put
+// two lanes of every 16-lane ds_read_b128 group on the same banks: 8 LDS cycles per fragment instead of 4, 40 % of the
+// kernel's LDS cycles were conflicts (PMC: profiles/r02_pmc_conv_attn_summary.txt; the bank model in
+// tools/lds_bank_model.py reproduces the 40 % and shows the column swizzle conflict-free for all nine taps).  The tap
+// shift changes qx per lane, so the reader rebuilds it per tap: base = q*128 + ((lhi ^ ((qx0+kx)>>1)&7) << 4), k-step kk
+// at base ^ (kk << 5).
 // Halo pixels outside the image come from a zero page.  With upsample the patch is gathered from input pixel
 // nearest_src(uy), nearest_src(ux) (= uy>>1, ux>>1 for the plain x2 case): the upsampled tensor never exists.
 //
@@ -50,6 +55,7 @@ __global__ __launch_bounds__(256, 3) void conv_halo_kernel(const GemmParams p) {
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, lhi = lane >> 5;
     const int lrow = lane >> 3, slot = lane & 7;
+    const bool rowswz = (p.debug & 1024) != 0;  // A/B only: the row-index patch swizzle (2-way bank conflicts on every A read)
 
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     int tm, tn;
@@ -67,7 +73,7 @@ __global__ __launch_bounds__(256, 3) void conv_halo_kernel(const GemmParams p) {
         const int uy = oy0 - 1 + qy, ux = ox0 - 1 + qx;  // output-resolution pixel
         const bool ok = (q < HROWS) & (uy >= 0) & (uy < p.Hout) & (ux >= 0) & (ux < p.Wout);
         const int iy = p.upsample ? nearest_src(uy, p.up_sy, p.Hin) : uy, ix = p.upsample ? nearest_src(ux, p.up_sx, p.Win) : ux;
-        const int chunk = slot ^ ((q >> 1) & 7);
+        const int chunk = slot ^ (((rowswz ? q : qx) >> 1) & 7);  // swizzle by patch COLUMN (see the header)
         poff[j] = ok ? ((b * p.Hin + iy) * p.Win + ix) * p.Cin + chunk * 8 : -1;
     }
     int woff[4];  // element offset of the lane's chunk in the weight matrix at k = 0 (Cout * 9 * Cin < 2^31)
@@ -121,7 +127,7 @@ __global__ __launch_bounds__(256, 3) void conv_halo_kernel(const GemmParams p) {
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) {
                 const int q = q0[mi] + shift;
-                const int base = q * 128 + ((lhi ^ ((q >> 1) & 7)) << 4);
+                const int base = q * 128 + ((lhi ^ (((rowswz ? q : (l31 & 15) + kx) >> 1) & 7)) << 4);
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) af[kk][mi] = *reinterpret_cast<const V8*>(sP + (base ^ (kk << 5)));
             }
@@ -259,6 +265,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo256_kernel(const GemmParams p
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, lhi = lane >> 5;
     const int lrow = lane >> 3, slot = lane & 7;
+    const bool rowswz = (p.debug & 1024) != 0;  // A/B only: the row-index patch swizzle (2-way bank conflicts on every A read)
 
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     int tm, tn;
@@ -275,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo256_kernel(const GemmParams p
         const int uy = oy0 - 1 + qy, ux = ox0 - 1 + qx;
         const bool ok = (q < HROWS2) & (uy >= 0) & (uy < p.Hout) & (ux >= 0) & (ux < p.Wout);
         const int iy = p.upsample ? nearest_src(uy, p.up_sy, p.Hin) : uy, ix = p.upsample ? nearest_src(ux, p.up_sx, p.Win) : ux;
-        const int chunk = slot ^ ((q >> 1) & 7);
+        const int chunk = slot ^ (((rowswz ? q : qx) >> 1) & 7);  // swizzle by patch COLUMN (see the header)
         poff[j] = ok ? ((b * p.Hin + iy) * p.Win + ix) * p.Cin + chunk * 8 : -1;
     }
     int woff[4];
@@ -339,7 +346,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo256_kernel(const GemmParams p
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
             const int q = q0[mi] + shift;
-            abase[mi] = q * 128 + ((lhi ^ ((q >> 1) & 7)) << 4);
+            abase[mi] = q * 128 + ((lhi ^ (((rowswz ? q : (l31 & 15) + kx) >> 1) & 7)) << 4);
         }
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
