@@ -45,7 +45,8 @@ int ds_device_info(int* cu_count, int* lds_bytes, char* arch_name, int arch_name
  *   "llm_gemv_variant"   0 auto (software-pipelined persistent GEMV) | 1 one column per wavefront | 2 un-pipelined streaming GEMV
  *   "gemm_debug"         bits 0..7: ablation builds of gemm_pp_kernel (only in a library built with -DDS_ABLATION; 0 otherwise) |
  *                        bit 8 (256): gemm_pp_kernel drains a tile's C stores before the next tile's first k-tile instead of
- *                        letting them retire under it - same bits out (tests/test_gpu_ops.py::test_gemm_pingpong_tile_handover)
+ *                        letting them retire under it - same bits out (tests/test_gpu_ops.py::test_gemm_pingpong_tile_handover) |
+ *                        bit 10 (1024): halo-patch convs use the row-index patch swizzle (2-way LDS bank conflicts; A/B only)
  * returns 0, or -1 (ds_last_error()) for an unknown key / out-of-range value */
 int ds_set_option(const char* key, int value);
 
