@@ -33,6 +33,8 @@ PY
 }
 for op in conv attn attn1k; do
   run $op ${op}_sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
-  run $op ${op}_mem FETCH_SIZE WRITE_SIZE GRBM_GUI_ACTIVE
+  run $op ${op}_fetch FETCH_SIZE          # FETCH_SIZE / WRITE_SIZE / GRBM_GUI_ACTIVE in ONE pass hung until the timeout (round 2):
+  run $op ${op}_write WRITE_SIZE          # one derived-size counter per pass, like tools/gpu_pmc_pp.sh
+  run $op ${op}_grbm GRBM_GUI_ACTIVE
   run $op ${op}_valu SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVES
 done
