@@ -1,6 +1,6 @@
 """Build the gfx950 kernel library in-tree: diffsensei_amd/lib/libdiffsensei_hip.so.
 
-    python -m diffsensei_amd.build [--force] [--ablation]
+    python -m diffsensei_amd.build [--force] [--ablation] [--experimental]
 
 hipcc cross-compiles for gfx950 without a GPU, so this runs in the build container; the resulting .so travels
 with the tree to the GPU box.  One hipcc invocation per source (parallel), then one link.
@@ -19,6 +19,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libdiffsensei_hip.so")
 SOURCES = ["gemm.hip", "gemm_pp.hip", "conv_halo.hip", "vae.hip", "norm.hip", "attention.hip", "attention_fp8.hip", "elementwise.hip", "llm.hip", "preprocess.hip",
            "capi.hip"]
+EXPERIMENTAL = [os.path.join("experimental", "gemm_w4.hip")]   # --experimental only: unmeasured kernels behind explicit knobs
 HEADERS = ["ds_common.h", "ds_kernels.h", os.path.join("..", "..", "include", "diffsensei_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffast-math", "-fno-finite-math-only",
          "-Wno-unused-result"]
@@ -31,27 +32,28 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found")
 
 
-def _digest() -> str:
+def _digest(extra=()) -> str:
     h = hashlib.sha256()
-    for f in SOURCES + HEADERS:
+    for f in SOURCES + list(extra) + HEADERS:
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(fh.read())
     h.update(" ".join(FLAGS).encode())
     return h.hexdigest()
 
 
-def build(force: bool = False, verbose: bool = True, ablation: bool = False) -> str:
+def build(force: bool = False, verbose: bool = True, ablation: bool = False, experimental: bool = False) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     stamp = os.path.join(LIBDIR, "build.stamp")
-    flags = FLAGS + (["-DDS_ABLATION"] if ablation else [])
-    dig = _digest() + ("+ablation" if ablation else "")
+    flags = FLAGS + (["-DDS_ABLATION"] if ablation else []) + (["-DDS_EXPERIMENTAL"] if experimental else [])
+    sources = SOURCES + (EXPERIMENTAL if experimental else [])
+    dig = _digest(EXPERIMENTAL if experimental else ()) + ("+ablation" if ablation else "") + ("+experimental" if experimental else "")
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
         return LIB
     hipcc = _hipcc()
     objs = []
 
     def compile_one(src):
-        obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
+        obj = os.path.join(LIBDIR, os.path.basename(src).replace(".hip", ".o"))
         cmd = [hipcc, *flags, "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
@@ -60,8 +62,8 @@ def build(force: bool = False, verbose: bool = True, ablation: bool = False) -> 
             print(r.stderr, file=sys.stderr)
         return obj
 
-    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
-        objs = list(ex.map(compile_one, SOURCES))
+    with ThreadPoolExecutor(max_workers=len(sources)) as ex:
+        objs = list(ex.map(compile_one, sources))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
@@ -74,4 +76,4 @@ def build(force: bool = False, verbose: bool = True, ablation: bool = False) -> 
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, ablation="--ablation" in sys.argv)
+    build(force="--force" in sys.argv, ablation="--ablation" in sys.argv, experimental="--experimental" in sys.argv)

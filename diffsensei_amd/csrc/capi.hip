@@ -44,7 +44,11 @@ int ds_device_info(int* cu_count, int* lds_bytes, char* arch_name, int arch_name
 int ds_set_option(const char* key, int value) {
     DS_REQUIRE(key != nullptr, "ds_set_option: null key");
     if (strcmp(key, "gemm_variant") == 0) {
+#ifdef DS_EXPERIMENTAL
+        DS_REQUIRE((value >= 0 && value <= 10) || value == 12, "gemm_variant must be 0..10 or 12 (experimental build)");
+#else
         DS_REQUIRE(value >= 0 && value <= 10, "gemm_variant must be 0..10");
+#endif
         ds_gemm_set_variant(value);
         return 0;
     }
@@ -613,7 +617,7 @@ int ds_plan_capture(ds_plan* plan, void* stream) {
     hipGraph_t g = nullptr;
     hipError_t e = hipStreamEndCapture(st, &g);
     if (rc != 0) {
-        if (g) hipGraphDestroy(g);
+        if (g) (void)hipGraphDestroy(g);
         return rc;
     }
     if (e != hipSuccess) {
@@ -633,8 +637,8 @@ int ds_plan_replay(ds_plan* plan, void* stream) {
 
 int ds_plan_destroy(ds_plan* plan) {
     if (!plan) return 0;
-    if (plan->exec) hipGraphExecDestroy(plan->exec);
-    if (plan->graph) hipGraphDestroy(plan->graph);
+    if (plan->exec) (void)hipGraphExecDestroy(plan->exec);
+    if (plan->graph) (void)hipGraphDestroy(plan->graph);
     delete plan;
     return 0;
 }
