@@ -128,6 +128,29 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmParams p) {
                 acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[ni], a[mi], acc[mi][ni], 0, 0, 0);
     };
 
+    // one k-step: the 16 MFMAs of (ac, bc) with, in issue order, the 8 fragment reads of k-step `kk` of stage `rs` into
+    // (an, bn) and NW / 2 staging pieces (first J0): written to stage `ws`, then re-requested from the stream
+    auto step = [&](int rs, int kk, h8 (&an)[4], h8 (&bn)[4], h8 (&ac)[4], h8 (&bc)[4], int ws, auto j0c, auto nwc) {
+        constexpr int J0 = decltype(j0c)::value, NW = decltype(nwc)::value;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            if (g < 4) an[g] = *reinterpret_cast<const h8*>(smem + rs * W4_STAGE + fa[kk] + g * 4096);
+            else bn[g - 4] = *reinterpret_cast<const h8*>(smem + rs * W4_STAGE + fb[kk] + (g - 4) * 4096);
+            if (g < NW) {
+                const int j = J0 + g / 2;
+                if ((g & 1) == 0) {
+                    *reinterpret_cast<h8*>(smem + ws * W4_STAGE + j * 4096 + w0) = sa[j];
+                    sa[j] = *reinterpret_cast<const h8*>(ld_a + (long)j * 32 * p.lda + ld_kt * 64);
+                } else {
+                    *reinterpret_cast<h8*>(smem + ws * W4_STAGE + W4_B + j * 4096 + w0) = sb[j];
+                    sb[j] = *reinterpret_cast<const h8*>(ld_b + (long)j * 32 * p.ldw + ld_kt * 64);
+                }
+            }
+        }
+        mma(ac, bc);
+        interleave(nwc);
+    };
+
     // ---- stream prologue: k-tile 0 into stage 0, k-tile 1 into the staging registers
 #pragma unroll
     for (int j = 0; j < 8; ++j) gload(j);
@@ -155,36 +178,19 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmParams p) {
                 for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
         for (int kt = 0; kt < nk; ++kt) {
             const int other = stage ^ 1;
-            // step 0
-            fread(stage, 1, a1, b1);
-#pragma unroll
-            for (int j = 0; j < 3; ++j) lwrite(other, j);
-#pragma unroll
-            for (int j = 0; j < 3; ++j) gload(j);
-            mma(a0, b0);
-            interleave(IC<6>{});
-            // step 1
-            fread(stage, 2, a0, b0);
-#pragma unroll
-            for (int j = 3; j < 6; ++j) lwrite(other, j);
-#pragma unroll
-            for (int j = 3; j < 6; ++j) gload(j);
-            mma(a1, b1);
-            interleave(IC<6>{});
-            // step 2
-            fread(stage, 3, a1, b1);
-#pragma unroll
-            for (int j = 6; j < 8; ++j) lwrite(other, j);
-#pragma unroll
-            for (int j = 6; j < 8; ++j) gload(j);
-            advance();
-            mma(a0, b0);
-            interleave(IC<4>{});
+            // (reads, writes and loads are written in the order they should issue: the compiler cannot tell the two stages
+            // apart, so it keeps LDS reads and writes in program order - eight reads followed by six writes would reach
+            // the matrix pipe as one block of fourteen memory instructions)
+            step(stage, 1, a1, b1, a0, b0, other, IC<0>{}, IC<6>{});
+            step(stage, 2, a0, b0, a1, b1, other, IC<3>{}, IC<6>{});
+            step(stage, 3, a1, b1, a0, b0, other, IC<6>{}, IC<4>{});
             __syncthreads();  // stage `other` complete everywhere; nobody reads `stage` any more
-            // step 3
-            fread(other, 0, a0, b0);
-            mma(a1, b1);
-            interleave(IC<0>{});
+            step(other, 0, a0, b0, a1, b1, other, IC<0>{}, IC<0>{});
+            // pin the fragments just read in front of the branch below (the compiler otherwise sinks the eight reads past
+            // it, behind this step's MFMAs: the next k-tile then starts by waiting for them)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(a0[i]), "+v"(b0[i]));
+            advance();        // (a branch: kept out of the scheduled regions) the next k-tile of the stream
             stage = other;
         }
 
