@@ -1,6 +1,8 @@
 // EXPERIMENTAL - not part of the production library, never dispatched by ds_launch_gemm.  Written at the end of round 2
 // (no GPU minutes left): it compiles for gfx950 and its register / instruction budget has been read off the assembly, but
-// it has NOT run yet.  `python -m diffsensei_amd.build --experimental` adds it behind gemm_variant 12.
+// it has NOT run yet (its address arithmetic has: tools/w4_index_model.py replays staging, fragment reads, the MFMA
+// layout and the epilogue per thread in numpy).  `python -m diffsensei_amd.build --experimental` adds it behind
+// gemm_variant 12; tests/test_gpu_ops.py::test_gemm_w4_experimental and tools/w4_check.py are the first contact.
 //
 // fp16 MFMA GEMM, 256 x 256 x 64 block tile, FOUR waves (2 x 2), wave tile 128 x 128, one wave per SIMD, persistent.
 // Same GemmParams / epilogue semantics as gemm.hip and gemm_pp.hip for the shapes it takes (M, N multiples of 256,
