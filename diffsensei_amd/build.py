@@ -75,5 +75,28 @@ def build(force: bool = False, verbose: bool = True, ablation: bool = False, exp
     return LIB
 
 
+def check_experimental(verbose: bool = True) -> None:
+    """Compile-only check (hipcc -c, nothing linked) of the sources that are NOT part of the production library, so that
+    they cannot rot unnoticed; cached by content digest."""
+    os.makedirs(os.path.join(LIBDIR, "experimental"), exist_ok=True)
+    flags = FLAGS + ["-DDS_EXPERIMENTAL"]
+    for src in EXPERIMENTAL:
+        h = hashlib.sha256()
+        for f in [src] + HEADERS[:2]:
+            with open(os.path.join(CSRC, f), "rb") as fh:
+                h.update(fh.read())
+        obj = os.path.join(LIBDIR, "experimental", os.path.basename(src).replace(".hip", ".o"))
+        stamp = obj + ".stamp"
+        if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read().strip() == h.hexdigest():
+            continue
+        r = subprocess.run([_hipcc(), *flags, "-c", os.path.join(CSRC, src), "-o", obj], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
+        with open(stamp, "w") as fh:
+            fh.write(h.hexdigest())
+        if verbose:
+            print(f"compiled (not linked) {src}")
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv, ablation="--ablation" in sys.argv, experimental="--experimental" in sys.argv)
