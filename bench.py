@@ -21,9 +21,12 @@ each rank serves its own requests with no data-path collective -> "scaling": "we
 synchronize on both sides, MAX over ranks; value = N * K * num_samples / t.
 
 Extra objects on the JSON line: `roofline` (dominant kernel of the UNet forward, algorithmic flops / HIP-event time
-vs the 2.5 PFLOP/s dense fp16 MFMA peak), `cpu_baseline` (the fp32 CPU oracle on a bounded sample of BASELINE.json
-configs[0], rank 0 at N=1 only) and `parity` (the SAME configs[0] steps run on the GPU with the same weights, latents and
-conditioning as the oracle just timed: relative L2 of the latents; the bench FAILS above 3e-2).
+vs the 2.5 PFLOP/s dense fp16 MFMA peak), `cpu_baseline` (the whole `__call__` of BASELINE.json configs[0] on the fp32 CPU
+oracle, the Euler loop interrupted after 2 of 20 steps and only the loop extrapolated; rank 0 at N=1 only) and `parity`
+(`path: "__call__"`: the SAME call - prompt, negative prompt, noise, weights, interrupt point - through `pipe(...)` on the
+GPU: relative L2 of the latents, and the uint8 image bytes compared.  The bench FAILS when the latents differ by more than
+3e-2 (bounded 2-step sample) / 6e-2 (`--cpu-full`, all 20 steps: fp16 storage vs fp32 compounds through CFG 7.5) or the
+image by more than 5e-2).
 """
 from __future__ import annotations
 
@@ -49,7 +52,7 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def build_pipeline(device, num_gpus, rank, seed=0, with_vae=True, agent=None):
+def build_pipeline(device, num_gpus, rank, seed=0, with_vae=True, agent=None, keep_oracle=False):
     """Reference construction recipe (scripts/demo/gradio_wo_mllm.py:161-200) with synthetic weights."""
     from transformers import CLIPVisionConfig, CLIPVisionModel, ViTMAEConfig, ViTMAEModel
     from diffsensei_amd.distributed import broadcast_pipeline
@@ -68,9 +71,20 @@ def build_pipeline(device, num_gpus, rank, seed=0, with_vae=True, agent=None):
                                 image_size=224, patch_size=14, hidden_act="gelu", projection_dim=1024)   # ViT-H/14
     mae_cfg = ViTMAEConfig(hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
                            image_size=224, patch_size=16, mask_ratio=0.0)                                  # Magi crop encoder
+    keep = {}                    # fp32 CPU modules holding exactly the engines' fp16 weights: the oracle chain of `parity`
+
+    def cpu_module(name, m):
+        m = m.eval()
+        with torch.no_grad():
+            for prm in m.parameters():
+                prm.copy_(prm.half().float())
+        if keep_oracle:
+            keep[name] = m
+        return m
+
     with torch.device("cpu"):
-        clip = ClipVisionEngine.from_transformers(CLIPVisionModel(clip_cfg).eval(), device)
-        magi = ViTMAEEngine.from_transformers(ViTMAEModel(mae_cfg).eval(), device)
+        clip = ClipVisionEngine.from_transformers(cpu_module("image_encoder", CLIPVisionModel(clip_cfg)), device)
+        magi = ViTMAEEngine.from_transformers(cpu_module("magi", ViTMAEModel(mae_cfg)), device)
     resampler = Resampler(dim=1280, depth=4, dim_head=64, heads=20, num_queries=16, num_dummy_tokens=16,
                           embedding_dim=1280, magi_embedding_dim=768, output_dim=cfg.cross_attention_dim, ff_mult=4,
                           device=device).init_random(seed + 1)
@@ -82,8 +96,8 @@ def build_pipeline(device, num_gpus, rank, seed=0, with_vae=True, agent=None):
     t2 = CLIPTextConfig(vocab_size=49408, hidden_size=1280, intermediate_size=5120, num_hidden_layers=32,
                         num_attention_heads=20, max_position_embeddings=77, hidden_act="gelu", projection_dim=1280)
     with torch.device("cpu"):
-        te1 = ClipTextEngine.from_transformers(CLIPTextModel(t1).eval(), device)
-        te2 = ClipTextEngine.from_transformers(CLIPTextModelWithProjection(t2).eval(), device)
+        te1 = ClipTextEngine.from_transformers(cpu_module("text_encoder", CLIPTextModel(t1)), device)
+        te2 = ClipTextEngine.from_transformers(cpu_module("text_encoder_2", CLIPTextModelWithProjection(t2)), device)
     # SDXL VAE decoder (49.5 M parameters) at its true shapes, random init, bf16 HIP engine
     from diffsensei_amd.vae import VaeConfig, VaeDecoderEngine
     vae = VaeDecoderEngine.init_random(VaeConfig(), seed + 2, device) if with_vae else None
@@ -92,6 +106,9 @@ def build_pipeline(device, num_gpus, rank, seed=0, with_vae=True, agent=None):
     pipe = DiffSenseiPipeline(vae=vae, text_encoder=te1, text_encoder_2=te2, tokenizer=tok, tokenizer_2=tok,
                               scheduler=EulerDiscreteScheduler(), unet=unet, image_encoder=clip)
     pipe.register_manga_modules(magi_image_encoder=magi, image_proj_model=resampler)
+    if keep_oracle:
+        keep.update(tokenizer=tok, tokenizer_2=tok, resampler_heads=20, resampler_dim_head=64, vae_seed=seed + 2)
+        pipe._oracle_modules = keep
     # N > 1: every engine's frozen weights (pipe.tensors() [+ the MLLM agent]) go out from rank 0 in 512 MiB buckets,
     # then an all-reduced checksum proves the replicas are bit-identical (ranks != 0 were seeded differently on purpose)
     bstats = {"bytes": 0, "seconds": 0.0, "buckets": 0, "verify_ms": 0.0, "tensors": 0}
@@ -156,39 +173,80 @@ def build_mllm_agent(device, seed=7):
     return ContinuousLVLM(llm, res_in, res_out), mllm_synthetic_inputs(seed)
 
 
-def gpu_parity_on_oracle_state(pipe, st, ref_image=None):
-    """BASELINE configs[0] (512x512, 20-step Euler, text-only, batch 1) on the HIP engine with the weights, initial latents
-    and conditioning the CPU oracle has just been timed on (`north_star`: "outputs match the reference CPU path on identical
-    seeds/latents within stated fp16 tolerance").  Compares the latents after the oracle's measured steps; the tolerance,
-    3e-2 relative L2, is fp16 storage vs the oracle's pure fp32 through `steps_done` UNet forwards + CFG at 7.5."""
-    from diffsensei_amd.schedulers import EulerDiscreteScheduler
-    H, W = st["height"] // 8, st["width"] // 8
-    sch = EulerDiscreteScheduler()
-    sch.set_timesteps(st["steps"])
-    eng = pipe.unet.engine(2, H, W, H / W)
-    eng.build_sampler(1, sch.kind, True)
-    eng.set_request(st["enc"], st["text_embeds"], st["time_ids"], st["bbox"], None, st["ip_scale"])
-    eng.load_schedule(torch.from_numpy(sch.coef_table(st["guidance_scale"])))
-    eng.latents.copy_(st["latents0"].to(eng.latents.device, torch.float16))
-    eng.prep_plan.run()
-    for _ in range(st["steps_done"]):
-        eng.step_plan.run()
-    torch.cuda.synchronize()
-    got, ref = eng.latents.float().cpu(), st["latents"].float()
-    assert torch.isfinite(got).all()
-    rel = ((got - ref).norm() / ref.norm()).item()
-    moved = ((ref - st["latents0"].float()).norm() / ref.norm()).item()
-    out = {"config": "C1: 512x512, 20-step Euler, text-only, batch 1 (BASELINE.json configs[0])", "steps": st["steps_done"],
-           "rel_l2": round(rel, 6), "max_abs": round((got - ref).abs().max().item(), 5),
-           "tolerance": 3e-2 if st["steps_done"] <= 4 else 6e-2,      # fp16 storage vs pure fp32 compounds over 20 CFG steps
-           "latents_moved_rel": round(moved, 4),
-           "vs": "oracle/pipeline_ref (fp32 torch, CPU) on the same weights / latents / conditioning"}
-    if ref_image is not None:      # the decoded image too: bf16 HIP decoder on the GPU's latents vs the fp32 oracle decode
-        img = pipe.vae.decode(eng.latents, return_dict=False, scaling_factor=pipe.vae.config.scaling_factor)[0].float().cpu()
-        out["image_rel_l2"] = round(((img - ref_image).norm() / ref_image.norm()).item(), 6)
-        out["image_tolerance"] = 5e-2
-        assert out["image_rel_l2"] <= out["image_tolerance"], out
-    return out
+def cpu_call_and_gpu_parity(pipe, req, cpu_full=False, parity=True, budget_steps=2):
+    """BASELINE configs[0] - 512x512, 20-step Euler, text-only (`ip_images=[]`), batch 1 - as ONE whole call of the
+    reference function (pipeline_diffsensei.py:180-372) on both sides:
+
+    * `cpu_baseline`: `oracle.pipeline_ref.call_oracle` on the host cores in fp32 - tokenise, both SDXL text encoders,
+      prepare_ip_image_embeds (4 black references through the HF processors, CLIP-H, ViT-MAE, zeroed, Resampler), the Euler
+      loop, the fp32 VAE decode, postprocess to uint8.  Bounded sample: the loop is interrupted after `budget_steps` of the 20
+      steps (the reference's own `interrupt` flag: the remaining iterations `continue`) and ONLY the loop time is
+      extrapolated to 20 steps; encoders, VAE decode and postprocess are measured whole.  `--cpu-full`: all 20 steps.
+    * `parity` (`path: "__call__"`): the SAME call - same prompt, negative prompt, initial noise, weights (the oracle's
+      modules hold the engines' fp16-rounded weights), same interrupt point - through `pipe(...)` on the GPU, compared on
+      the latents (relative L2, tolerance 3e-2 for <= 4 steps / 6e-2 for the 20-step run: fp16 storage vs pure fp32
+      compounding through CFG 7.5) and on the uint8 image bytes the call returns (`image_rel_l2` on pixels / 255, the
+      fraction of bytes that differ at all and by more than 1 LSB, the largest difference)."""
+    import numpy as np
+    from diffsensei_amd.unet_config import sdxl_config
+    from diffsensei_amd.vae import VaeConfig, random_state_dict as vae_random_sd
+    from oracle.pipeline_ref import call_oracle
+    from oracle.unet_ref import UNetOracle
+    mods = dict(pipe._oracle_modules)
+    vcfg = VaeConfig()
+    mods["vae_sd"] = {k: v.to(torch.bfloat16).float() for k, v in vae_random_sd(vcfg, mods["vae_seed"]).items()}
+    mods["vae_cfg"] = {"layers_per_block": vcfg.layers_per_block, "norm_num_groups": vcfg.norm_num_groups, "eps": vcfg.eps,
+                       "scaling_factor": vcfg.scaling_factor}
+    mods["resampler_sd"] = {k: v.float().cpu() for k, v in pipe.image_proj_model.state_dict().items()}
+    unet_o = UNetOracle(sdxl_config(), {k: v.float().cpu() for k, v in pipe.unet._sd.items()})
+    size, steps, gs, ip_scale = 512, 20, 7.5, 0.6
+    lat0 = torch.randn(1, 4, size // 8, size // 8, generator=torch.Generator().manual_seed(0))
+    n_run = steps if cpu_full else budget_steps
+    tm = {}
+    t0 = time.perf_counter()
+    ref = call_oracle(mods, unet_o, req["prompt"], req["negative_prompt"], size, size, steps, gs, lat0, ip_images=[],
+                      ip_bbox=[], ip_scale=ip_scale, dialog_bbox=[], num_samples=1, max_steps=n_run, timings=tm)
+    wall = time.perf_counter() - t0
+    fixed = tm["text_encoders_s"] + tm["character_encoders_s"] + tm["vae_postprocess_s"]
+    panel_s = fixed + tm["denoise_s"] * steps / n_run
+    cpu = {"value": round(1.0 / panel_s, 6), "unit": "panels/s", "cores": torch.get_num_threads(), "kind": "port",
+           "s_per_panel": round(panel_s, 1),
+           "sample": (f"the whole __call__ of BASELINE configs[0] (512x512, 20-step Euler, text-only, batch 1) on the fp32 torch "
+                      f"oracle, {wall:.1f} s measured: text encoders {tm['text_encoders_s']:.1f} s + character encoders / "
+                      f"Resampler {tm['character_encoders_s']:.1f} s + {n_run} of {steps} Euler steps (CFG batch 2) "
+                      f"{tm['denoise_s']:.1f} s + fp32 VAE decode / uint8 {tm['vae_postprocess_s']:.1f} s; " +
+                      ("nothing extrapolated" if n_run == steps else f"only the loop is extrapolated to {steps} steps")),
+           "spread_note": "box-to-box spread of this figure is up to 2x (host cores shared; BASELINE.md section 5)"}
+    del unet_o
+    if not parity:
+        return cpu, None
+
+    def stop(p, i, t, kw):
+        if i + 1 >= n_run:
+            p._interrupt = True
+        return kw
+
+    kw = dict(prompt=req["prompt"], negative_prompt=req["negative_prompt"], height=size, width=size, num_inference_steps=steps,
+              guidance_scale=gs, num_samples=1, ip_images=[], ip_bbox=[], ip_scale=ip_scale, dialog_bbox=[],
+              callback_on_step_end=stop)
+    got_lat = pipe(latents=lat0.clone(), output_type="latent", **kw).images.float().cpu()
+    pil = pipe(latents=lat0.clone(), output_type="pil", **kw).images
+    got_u8 = np.asarray(pil[0])
+    assert torch.isfinite(got_lat).all() and got_u8.shape == ref["u8"][0].shape == (size, size, 3)
+    rl = ref["latents"].float()
+    d = got_u8.astype(np.int16) - ref["u8"][0].astype(np.int16)
+    a, b = got_u8.astype(np.float64) / 255.0, ref["u8"][0].astype(np.float64) / 255.0
+    par = {"path": "__call__",
+           "config": "C1: 512x512, 20-step Euler, text-only, batch 1 (BASELINE.json configs[0]), prompt + negative prompt -> PIL",
+           "steps": n_run, "interrupted_after": None if n_run == steps else n_run,
+           "rel_l2": round(((got_lat - rl).norm() / rl.norm()).item(), 6),
+           "max_abs": round((got_lat - rl).abs().max().item(), 5),
+           "tolerance": 3e-2 if n_run <= 4 else 6e-2,
+           "image_rel_l2": round(float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-12)), 6), "image_tolerance": 5e-2,
+           "u8_frac_differ": round(float((d != 0).mean()), 6), "u8_frac_gt_1lsb": round(float((np.abs(d) > 1).mean()), 6),
+           "u8_max_diff": int(np.abs(d).max()), "u8_std_ref": round(float(ref["u8"][0].std()), 2),
+           "vs": "oracle/pipeline_ref.call_oracle (fp32 torch + transformers modules, CPU) on the same weights / prompt / noise"}
+    return cpu, par
 
 
 def profile_forward_ops(pipe, reps=3):
@@ -271,7 +329,8 @@ def main():
     agent = mllm_in = None
     if args.mllm:
         agent, mllm_in = build_mllm_agent(device, seed=7 if rank == 0 else 70 + rank)
-    pipe, setup = build_pipeline(device, world, rank, with_vae=not args.no_vae, agent=agent)
+    pipe, setup = build_pipeline(device, world, rank, with_vae=not args.no_vae, agent=agent,
+                                 keep_oracle=(rank == 0 and world == 1 and not args.no_cpu_baseline))
     ns = args.num_samples
     out_type = "latent" if args.no_vae else args.output
     req = synthetic_request(device, args.size, seed=1234 + rank, output_type=out_type, refs=args.refs)
@@ -355,35 +414,14 @@ def main():
 
     cpu_baseline = parity = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from diffsensei_amd.unet_config import sdxl_config
-        from oracle.pipeline_ref import time_cpu_baseline
-        sd_cpu = {k: v.float().cpu() for k, v in pipe.unet._sd.items()}
-        cpu_baseline = time_cpu_baseline(sdxl_config(), sd_cpu, 512, 512, 20, budget_s=1e9 if args.cpu_full else 25.0,
-                                         keep_state=True, min_steps=20 if args.cpu_full else 2)
-        state = cpu_baseline.pop("_state")
-        del sd_cpu
-        ref_image = None
-        if args.cpu_full and pipe.vae is not None:      # + the VAE decode, fp32 on the host (the reference upcasts it to fp32)
-            from diffsensei_amd.vae import VaeConfig, random_state_dict as vae_random_sd
-            from oracle.vae_ref import vae_decode
-            vcfg = VaeConfig()
-            vsd = {k: v.to(torch.bfloat16).float() for k, v in vae_random_sd(vcfg, 2).items()}   # build_pipeline: seed + 2
-            t0 = time.perf_counter()
-            with torch.no_grad():
-                ref_image = vae_decode(vsd, state["latents"].float() / vcfg.scaling_factor, vcfg.layers_per_block,
-                                       vcfg.norm_num_groups, vcfg.eps)
-            t_vae = time.perf_counter() - t0
-            t_unet = 1.0 / cpu_baseline["value"]
-            cpu_baseline["value"] = 1.0 / (t_unet + t_vae)
-            cpu_baseline["sample"] = (f"ALL 20 Euler steps of a 512x512 text-only panel (CFG batch 2; {t_unet:.1f} s) + the VAE "
-                                      f"decode ({t_vae:.1f} s), fp32 torch oracle, nothing extrapolated; prompt embeddings given "
-                                      f"(text encoders not timed)")
-        cpu_baseline["value"] = round(cpu_baseline["value"], 6)
-        if not args.no_parity:
-            parity = gpu_parity_on_oracle_state(pipe, state, ref_image)
+        cpu_baseline, parity = cpu_call_and_gpu_parity(pipe, req, cpu_full=args.cpu_full,
+                                                         parity=not (args.no_parity or args.no_vae))
+        if parity is not None:
             log("parity:", json.dumps(parity))
             assert parity["rel_l2"] <= parity["tolerance"], \
                 f"GPU latents differ from the CPU oracle on BASELINE configs[0]: {parity}"
+            assert parity["image_rel_l2"] <= parity["image_tolerance"], \
+                f"GPU image differs from the CPU oracle on BASELINE configs[0]: {parity}"
 
     if rank == 0:
         line = {

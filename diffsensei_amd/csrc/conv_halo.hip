@@ -475,13 +475,12 @@ int ds_launch_conv_halo(const GemmParams& p0, hipStream_t stream) {
     if (big) {
         p.tiles_m = batch * ty16 * txs;
         const size_t lds2 = PBYTES2 + 2 * BN * 128;  // 76 KiB; the 256 x 272 B epilogue tile fits inside
-        static bool attr_set = false;
-        if (!attr_set) {
+        static unsigned long long attr_devs = 0;
+        if (ds_first_on_device(attr_devs)) {
             DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo256_kernel<half_t>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
             DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo256_kernel<bf16_t>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-            attr_set = true;
         }
         dim3 grid2(p.tiles_m * p.tiles_n);
         if (p.dtype == DS_DTYPE_BF16) hipLaunchKernelGGL(conv_halo256_kernel<bf16_t>, grid2, dim3(256), lds2, stream, p);

@@ -65,6 +65,18 @@ void ds_set_error(const char* fmt, ...);
         }                                                                   \
     } while (0)
 
+// One-off per-DEVICE set-up at a launch site (hipFuncSetAttribute for > 64 KiB of dynamic LDS): function attributes
+// are per device, and ops.bind_device can move a process to another device, so a process-wide `static bool` is not
+// enough.  `seen` is the call site's own static bit mask (devices 0..63).
+inline bool ds_first_on_device(unsigned long long& seen) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;   // unknown: redo the set-up, it is idempotent
+    const unsigned long long bit = 1ull << dev;
+    if (seen & bit) return false;
+    seen |= bit;
+    return true;
+}
+
 // ---- device helpers ------------------------------------------------------------------------------
 __device__ __forceinline__ float ds_silu(float x) { return x / (1.0f + __expf(-x)); }
 // Exact (erf) GELU, branch-free: gelu(x) = x * Phi(x) with Phi(-|x|) = erfc(z)/2, z = |x|/sqrt(2), and

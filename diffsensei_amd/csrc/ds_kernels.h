@@ -164,8 +164,7 @@ struct LlmGemvParams {
     float eps = 1e-6f;
 };
 int ds_launch_llm_gemv(const LlmGemvParams& p, hipStream_t stream);
-void ds_llm_gemv_set_variant(int v);
-void ds_llm_gemv_set_min_cols(int v);  // 0 auto (pipelined), 1 one column per wavefront, 2 streaming without pipelining
+void ds_llm_gemv_set_variant(int v);   // 0 auto (pipelined), 1 one column per wavefront, 2 streaming without pipelining
 
 struct LlmAttnParams {
     const half_t* qkv = nullptr;       // [M, (heads + 2 kv_heads) * D] rows (ldqkv): q | k | v, not yet rotated

@@ -560,11 +560,10 @@ int launch(const GemmParams& p0, int batch, hipStream_t stream) {
     p.tiles_n = (p.N + BN - 1) / BN;
     const size_t lds = 2 * BM * 128 + 2 * BN * 128;
     auto kern = GLDS ? gemm_glds_kernel<BM, CONV> : gemm_f16_kernel<(BM > 128 ? 128 : BM), CONV>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_devs = 0;
+    if (ds_first_on_device(attr_devs)) {
         DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)lds));
-        attr_set = true;
     }
     dim3 grid(p.tiles_m * p.tiles_n, 1, batch);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p);
@@ -594,11 +593,10 @@ int launch_ring(const GemmParams& p0, int batch, hipStream_t stream) {
     p.tiles_n = (p.N + BN - 1) / BN;
     const size_t lds = (size_t)STAGES * (BM + BN) * 128;
     auto kern = gemm_glds_kernel<BM, false, STAGES>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_devs = 0;
+    if (ds_first_on_device(attr_devs)) {
         DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)lds));
-        attr_set = true;
     }
     dim3 grid(p.tiles_m * p.tiles_n, 1, batch);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p);

@@ -626,7 +626,8 @@ int ds_launch_gemm_pp(const GemmParams& p0, int batch, hipStream_t stream) {
         {24, gemm_pp_kernel<half_t, 24>}, {48, gemm_pp_kernel<half_t, 48>}, {49, gemm_pp_kernel<half_t, 49>}, {64, gemm_pp_kernel<half_t, 64>}, {128, gemm_pp_kernel<half_t, 128>},
 #endif
         {-1, gemm_pp_kernel<bf16_t, 0>}};  // -1: the bf16 build (VAE decoder), no ablation variants
-    if (g_pp_blocks == 0) {
+    static unsigned long long attr_devs = 0;
+    if (ds_first_on_device(attr_devs)) {
         for (const auto& e : table)
             DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(e.k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int dev = 0, cus = 0;

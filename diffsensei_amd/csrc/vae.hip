@@ -303,13 +303,12 @@ int ds_launch_wide_attn(const void* q, const void* k, const void* vt, void* o, i
     if (n_valid <= 0) n_valid = N;
     DS_REQUIRE(n_valid <= N, "wide_attn: n_valid (%d) exceeds the row count (%d)", n_valid, N);
     const size_t lds = 2 * KT * KROW + 2 * DS * VSTR;  // 64 KiB + 18 KiB
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_devs = 0;
+    if (ds_first_on_device(attr_devs)) {
         DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wide_attn_kernel<bf16_t>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wide_attn_kernel<half_t>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
     }
     dim3 grid((N + 127) / 128, DH / DS, B);
     if (dtype == DS_DTYPE_BF16)
@@ -328,13 +327,12 @@ int ds_launch_vae_conv_in(const float* lat, const float* wpq, const float* bpq, 
                "vae_conv_in: C (%d) must be 8 x a divisor of 256", C);
     const size_t lds = (size_t)(C * 36 + C) * sizeof(float);
     DS_REQUIRE(lds <= 160 * 1024, "vae_conv_in: weights (%zu B) exceed LDS", lds);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_devs = 0;
+    if (ds_first_on_device(attr_devs)) {
         DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vae_conv_in_kernel<bf16_t>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vae_conv_in_kernel<half_t>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
     }
     const int ppb = 256 / (C / 8);
     const int px_per_block = ppb * 16;  // the weight stage-in is amortised over 16 passes

@@ -19,7 +19,9 @@ Tensor = torch.Tensor
 def bind_device(dev: torch.device) -> None:
     """One process drives one GPU.  The library launches on "the current stream", which HIP resolves per
     CURRENT device, so before a launch the tensors' device is made the current one (a no-op in the normal case where
-    `init_from_env` / the caller already selected it)."""
+    `init_from_env` / the caller already selected it).  NOTE: this changes process-global state (torch's current device) and
+    does not restore it - deliberate under the one-process-one-GPU design; the library's per-device one-off set-up
+    (`ds_first_on_device`, csrc/ds_common.h) is keyed by device, so a process that does touch a second GPU stays correct."""
     if dev.type == "cuda" and dev.index is not None and dev.index != torch.cuda.current_device():
         torch.cuda.set_device(dev)
 

@@ -60,10 +60,12 @@ class DiffSenseiPipeline:
         # character references are resized / cropped / normalised by csrc/preprocess.hip (bytes identical to Pillow; e2e
         # character tokens vs the host processors rel-L2 6.9e-4, profiles/r02_device_preprocess_e2e.log).  False, or a
         # reference that is not a PIL image, goes through the transformers processors on the host like the reference.
-        self.device_preprocess = True
+        # DIFFSENSEI_DEVICE_PREPROCESS=0 restores the reference's host path process-wide.
+        self.device_preprocess = os.environ.get("DIFFSENSEI_DEVICE_PREPROCESS", "1") != "0"
         self._device_pre = None
         self._magi_proc = None
         self._guidance_scale = 1.0
+        self._interrupt = False
         self._stream = None
         self.use_graph = os.environ.get("DIFFSENSEI_GRAPH", "1") != "0"
         self.last_run_info = {}
@@ -111,6 +113,10 @@ class DiffSenseiPipeline:
     @property
     def guidance_scale(self):
         return self._guidance_scale
+
+    @property
+    def interrupt(self):
+        return self._interrupt
 
     @property
     def do_classifier_free_guidance(self):
@@ -305,13 +311,18 @@ class DiffSenseiPipeline:
                  # ---- trailing extensions (not in the reference signature)
                  latents: Optional[Tensor] = None, prompt_embeds: Optional[Tensor] = None,
                  negative_prompt_embeds: Optional[Tensor] = None, pooled_prompt_embeds: Optional[Tensor] = None,
-                 negative_pooled_prompt_embeds: Optional[Tensor] = None, output_type: str = "pil"):
+                 negative_pooled_prompt_embeds: Optional[Tensor] = None, output_type: str = "pil",
+                 callback_on_step_end=None):
+        """`callback_on_step_end(pipe, step_index, timestep, {"latents": device tensor}) -> dict | None` is diffusers'
+        SDXL-pipeline hook [3P]; together with `pipe._interrupt = True` it is the reference's early exit: the loop
+        `continue`s over the remaining steps (reference :314-315) and the call still decodes and post-processes."""
+        self._interrupt = False                                   # reference :226
         cond = self._conditioning(prompt, prompt_2, height, width, num_inference_steps, guidance_scale, negative_prompt,
                                   negative_prompt_2, num_samples, generator, original_size, crops_coords_top_left,
                                   target_size, ip_images, ip_image_embeds, ip_bbox, ip_scale, dialog_bbox, latents,
                                   prompt_embeds, negative_prompt_embeds, pooled_prompt_embeds,
                                   negative_pooled_prompt_embeds)
-        out_latents = self._denoise([cond], num_inference_steps, guidance_scale, ip_scale)
+        out_latents = self._denoise([cond], num_inference_steps, guidance_scale, ip_scale, callback_on_step_end)
         return StableDiffusionXLPipelineOutput(images=self._postprocess(out_latents, output_type))
 
     # ---- one request's conditioning tensors (reference :205-309), `num_samples` rows each, conditional and negative
@@ -361,7 +372,7 @@ class DiffSenseiPipeline:
                         to(neg_dialog))}
 
     # ---- the denoising loop over one UNet batch assembled from >= 1 requests of the same shape (reference :310-337)
-    def _denoise(self, conds, num_inference_steps, guidance_scale, ip_scale) -> Tensor:
+    def _denoise(self, conds, num_inference_steps, guidance_scale, ip_scale, callback_on_step_end=None) -> Tensor:
         device = self._execution_device
         self._guidance_scale = guidance_scale
         do_cfg = self.do_classifier_free_guidance
@@ -409,11 +420,18 @@ class DiffSenseiPipeline:
                     n0 = 1
                     eng.step_plan.capture(st.cuda_stream)
                 graph = True
-            for _ in range(n0, num_inference_steps):
+            timesteps = self.scheduler.timesteps
+            if n0 and callback_on_step_end is not None:
+                callback_on_step_end(self, 0, timesteps[0], {"latents": eng.latents})
+            for i in range(n0, num_inference_steps):
+                if self._interrupt:                               # reference :314-315 `if self.interrupt: continue`
+                    continue
                 if graph:
                     eng.step_plan.replay(st.cuda_stream)
                 else:
                     eng.step_plan.run(st.cuda_stream)
+                if callback_on_step_end is not None:              # launched, not synchronised: the hook sees device tensors
+                    callback_on_step_end(self, i, timesteps[i], {"latents": eng.latents})
         torch.cuda.current_stream(device).wait_stream(st)
         self.last_run_info = {"graph": graph, "ops_per_step": eng.step_plan.n, "batch": B, "latent_hw": (H, W)}
         return eng.latents.clone()

@@ -27,11 +27,22 @@ def _alphas_cumprod(T: int, beta_start: float, beta_end: float) -> torch.Tensor:
 class _SchedulerBase:
     kind = -1
     order = 1
+    _FIXED = {"trained_betas": (None,), "rescale_betas_zero_snr": (False,), "use_karras_sigmas": (False,),
+              "use_exponential_sigmas": (False,), "use_beta_sigmas": (False,), "interpolation_type": ("linear",),
+              "final_sigmas_type": ("zero",), "timestep_type": ("discrete",), "sigma_min": (None,), "sigma_max": (None,),
+              "clip_sample": (False,), "set_alpha_to_one": (False,), "thresholding": (False,)}
 
     def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
                  steps_offset=1, timestep_spacing="leading", prediction_type="epsilon", **unused):
         if beta_schedule != "scaled_linear" or timestep_spacing != "leading" or prediction_type != "epsilon":
             raise NotImplementedError("only the SDXL scheduler configuration (scaled_linear / leading / epsilon)")
+        # scheduler_config.json keys of diffusers' Euler / DDIM classes [3P] that CHANGE the sigma schedule or the update
+        # rule: only the value the device kernel implements is accepted - anything else would sample on a different
+        # schedule than the reference's scheduler without a word.  Keys that do not touch the arithmetic are ignored.
+        for key, ok in self._FIXED.items():
+            if key in unused and unused[key] not in ok:
+                raise NotImplementedError(f"scheduler config {key}={unused[key]!r}: the MI355X sampler kernel implements "
+                                          f"{key} in {ok} only")
         self.T = num_train_timesteps
         self.steps_offset = steps_offset
         self.alphas_cumprod = _alphas_cumprod(num_train_timesteps, beta_start, beta_end)

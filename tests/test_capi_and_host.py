@@ -119,6 +119,29 @@ def test_scheduler_tables_match_oracle():
         assert np.allclose(tab[:, 2], np.sqrt(a[do.timesteps]), rtol=1e-6)
 
 
+def test_scheduler_config_keys_that_change_the_schedule_are_refused():
+    """scheduler_config.json keys the local Euler / DDIM classes do not implement must not be swallowed - a
+    checkpoint with karras sigmas, zero-SNR rescaling, trained betas, ... would silently sample on another schedule than
+    the reference's diffusers scheduler (reference src/pipelines/pipeline_diffsensei.py:248-249 uses whatever the
+    checkpoint's scheduler_config.json builds)."""
+    from diffsensei_amd.schedulers import DDIMScheduler, EulerDiscreteScheduler
+    ok = dict(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", steps_offset=1,
+              timestep_spacing="leading", prediction_type="epsilon", interpolation_type="linear", use_karras_sigmas=False,
+              trained_betas=None, clip_sample=False, set_alpha_to_one=False, skip_prk_steps=True, sample_max_value=1.0,
+              rescale_betas_zero_snr=False, final_sigmas_type="zero", timestep_type="discrete")
+    EulerDiscreteScheduler(**ok).set_timesteps(20)
+    DDIMScheduler(**ok).set_timesteps(20)
+    for key, bad in (("use_karras_sigmas", True), ("rescale_betas_zero_snr", True), ("trained_betas", [0.1, 0.2]),
+                     ("interpolation_type", "log_linear"), ("final_sigmas_type", "sigma_min"), ("clip_sample", True),
+                     ("set_alpha_to_one", True), ("timestep_type", "continuous"), ("use_exponential_sigmas", True),
+                     ("thresholding", True)):
+        for cls in (EulerDiscreteScheduler, DDIMScheduler):
+            with pytest.raises(NotImplementedError):
+                cls(**dict(ok, **{key: bad}))
+    with pytest.raises(NotImplementedError):
+        EulerDiscreteScheduler(timestep_spacing="trailing")
+
+
 def test_pipeline_check_inputs_errors():
     from diffsensei_amd.pipeline import DiffSenseiPipeline
     p = DiffSenseiPipeline.__new__(DiffSenseiPipeline)

@@ -58,3 +58,46 @@ def test_product_tables_equal_the_oracle_tables(filt):
         assert np.array_equal(first, o_first) and np.array_equal(count, o_count) and np.array_equal(taps, o_taps)
         assert taps.dtype == np.int32 and int(np.abs(taps.astype(np.int64)).sum(1).max()) * 255 < 2 ** 31   # int32 accumulate is safe
     assert shortest_edge_size(97, 333, 224) == P.shortest_edge_size(97, 333, 224)
+
+
+@pytest.mark.parametrize("mode", ["RGBA", "P", "L", "LA", "CMYK", "RGB"])
+@pytest.mark.parametrize("hw", [(225, 223), (97, 333), (224, 224), (641, 479)])
+def test_non_rgb_modes_and_odd_sizes_match_the_hf_processors(mode, hw):
+    """the pipeline's default is the device pre-processing (`pipeline.device_preprocess`), whose host part is
+    `image.convert("RGB")` -> bytes (diffsensei_amd/preprocess.py `_one`); everything after is the byte-exact resize pinned
+    above.  The reference hands the PIL images to CLIPImageProcessor() / ViTImageProcessor() (reference
+    src/pipelines/pipeline_diffsensei.py:125-126).  For every PIL mode a reference image can arrive in, and odd sizes, the
+    chain convert("RGB") -> oracle resize/crop/normalise must equal the HF processors on the ORIGINAL image wherever they
+    accept it (CLIP: do_convert_rgb; ViT: accepts 3-channel input only - for other modes the reference itself fails or
+    mis-normalises, and the comparison is made on the RGB-converted image)."""
+    from transformers import CLIPImageProcessor, ViTImageProcessor
+    rng = np.random.RandomState(hw[0] * 7 + hw[1] + len(mode))
+    base = Image.fromarray(rng.randint(0, 256, hw + (3,), dtype=np.uint8))
+    if mode == "RGBA":
+        im = base.copy()
+        im.putalpha(Image.fromarray(rng.randint(0, 256, hw, dtype=np.uint8)))
+    elif mode == "LA":
+        im = base.convert("L")
+        im.putalpha(Image.fromarray(rng.randint(0, 256, hw, dtype=np.uint8)))
+    else:
+        im = base.convert(mode)
+    assert im.mode == mode
+    rgb = np.array(im.convert("RGB"), dtype=np.uint8)
+    got_c, got_v = P.clip_preprocess(rgb), P.vit_preprocess(rgb)
+    ref_c = CLIPImageProcessor()(images=[im], return_tensors="np").pixel_values[0]          # the ORIGINAL image
+    assert ref_c.shape == (3, 224, 224) and np.abs(got_c - ref_c).max() <= 1e-6, mode
+    ref_v = ViTImageProcessor()(images=[im.convert("RGB")], return_tensors="np").pixel_values[0]
+    assert np.abs(got_v - ref_v).max() <= 1e-6, mode
+    if mode == "RGB":
+        assert np.array_equal(ref_v, ViTImageProcessor()(images=[im], return_tensors="np").pixel_values[0])
+
+
+def test_device_preprocess_env_switch(monkeypatch):
+    """DIFFSENSEI_DEVICE_PREPROCESS=0 restores the reference's host processors without touching code."""
+    from diffsensei_amd.pipeline import DiffSenseiPipeline
+    from diffsensei_amd.schedulers import EulerDiscreteScheduler
+    unet = type("U", (), {"config": type("C", (), {"sample_size": 128})(), "device": "cpu"})()
+    monkeypatch.setenv("DIFFSENSEI_DEVICE_PREPROCESS", "0")
+    assert DiffSenseiPipeline(None, None, None, None, None, EulerDiscreteScheduler(), unet, None).device_preprocess is False
+    monkeypatch.delenv("DIFFSENSEI_DEVICE_PREPROCESS")
+    assert DiffSenseiPipeline(None, None, None, None, None, EulerDiscreteScheduler(), unet, None).device_preprocess is True
