@@ -43,6 +43,10 @@ SIGNATURES = {
     "ds_wide_attn_bf16": (i32, [vp, vp, vp, vp, i32, i32, i32, f32, vp]),
     "ds_vae_conv_in_bf16": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp]),
     "ds_vae_conv_out_bf16": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "ds_groupnorm_scaled_f16": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, f32, vp]),
+    "ds_wide_attn_f16": (i32, [vp, vp, vp, vp, i32, i32, i32, f32, vp]),
+    "ds_vae_conv_in_f16": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp]),
+    "ds_vae_conv_out_f16": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "ds_groupnorm_workspace_bytes": (sz, [i32, i32]),
     "ds_groupnorm_f16": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp]),
     "ds_layernorm_f16": (i32, [vp, vp, vp, vp, i32, i32, f32, vp]),

@@ -44,6 +44,8 @@ def _digest(extra=()) -> str:
 def build(force: bool = False, verbose: bool = True, ablation: bool = False, experimental: bool = False) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     stamp = os.path.join(LIBDIR, "build.stamp")
+    # A/B sessions: every build() call of the process tree (tests' hip_lib fixture, bench.py) keeps the experimental kernels
+    experimental = experimental or os.environ.get("DIFFSENSEI_BUILD_EXPERIMENTAL") == "1"
     flags = FLAGS + (["-DDS_ABLATION"] if ablation else []) + (["-DDS_EXPERIMENTAL"] if experimental else [])
     sources = SOURCES + (EXPERIMENTAL if experimental else [])
     dig = _digest(EXPERIMENTAL if experimental else ()) + ("+ablation" if ablation else "") + ("+experimental" if experimental else "")

@@ -189,6 +189,31 @@ int ds_vae_conv_out_bf16(const void* x, const void* w, const void* bias, float* 
     return ds_launch_vae_conv_out(x, w, bias, image, B, H_, W_, C, denormalize, DS_DTYPE_BF16, S(stream));
 }
 
+// ---- f16 twins of the decoder entry points (the scaled-fp16 "upcast" mode of diffsensei_amd/vae.py)
+int ds_groupnorm_scaled_f16(const void* x, void* y, const void* gamma, const void* beta, void* ws, int B, int HW, int C,
+                            int groups, float eps, int silu, float out_scale, void* stream) {
+    GroupNormParams p;
+    p.x1 = H(x); p.y = HM(y); p.gamma = H(gamma); p.beta = H(beta); p.ws = reinterpret_cast<float*>(ws);
+    p.B = B; p.HW = HW; p.C1 = C; p.C2 = 0; p.groups = groups; p.eps = eps; p.silu = silu; p.out_scale = out_scale;
+    return ds_launch_groupnorm(p, S(stream));
+}
+
+int ds_wide_attn_f16(const void* q, const void* k, const void* vt, void* o, int B, int N, int n_valid, float scale,
+                     void* stream) {
+    return ds_launch_wide_attn(q, k, vt, o, B, N, n_valid, DS_DTYPE_F16, scale, S(stream));
+}
+
+int ds_vae_conv_in_f16(const float* latents, const float* post_quant_w, const float* post_quant_b, const void* w,
+                       const void* bias, void* y, int B, int H_, int W_, int C, float scaling_factor, void* stream) {
+    return ds_launch_vae_conv_in(latents, post_quant_w, post_quant_b, w, bias, y, B, H_, W_, C, scaling_factor,
+                                 DS_DTYPE_F16, S(stream));
+}
+
+int ds_vae_conv_out_f16(const void* x, const void* w, const void* bias, float* image, int B, int H_, int W_, int C,
+                        int denormalize, void* stream) {
+    return ds_launch_vae_conv_out(x, w, bias, image, B, H_, W_, C, denormalize, DS_DTYPE_F16, S(stream));
+}
+
 size_t ds_groupnorm_workspace_bytes(int B, int C) { return ds_groupnorm_ws_floats(B, C) * sizeof(float); }
 
 int ds_groupnorm_f16(const void* x1, const void* x2, void* y, const void* gamma, const void* beta, void* ws, int B,

@@ -60,6 +60,7 @@ struct GroupNormParams {
     float eps = 1e-5f;
     int silu = 0;
     int dtype = DS_DTYPE_F16;  // bf16: VAE decoder path (x, y, gamma, beta are 2-byte opaque pointers)
+    float out_scale = 1.0f;    // y = act(norm(x)) * out_scale (the VAE decoder's scaled-fp16 mode; exact for powers of two)
 };
 size_t ds_groupnorm_ws_floats(int B, int C);
 int ds_launch_groupnorm(const GroupNormParams& p, hipStream_t stream);

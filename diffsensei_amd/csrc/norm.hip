@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GroupNormParams p, int nc
         for (int e = 0; e < 8; ++e) {
             float f = fmaf(a[e], (float)v[e], s[e]);
             if (p.silu) f = ds_silu(f);
-            o[e] = (T)f;
+            o[e] = (T)(f * p.out_scale);
         }
         return o;
     };

@@ -369,23 +369,48 @@ def wide_attention_bf16(q: Tensor, k: Tensor, vt: Tensor, scale: float, n_valid:
 def vae_conv_in(latents: Tensor, pq_w: Tensor, pq_b: Tensor, w: Tensor, bias: Tensor, scaling_factor: float) -> Tensor:
     """latents fp32 NCHW [B,4,H,W]; pq_w [4,4], pq_b [4] fp32; w [C,3,3,4], bias [C] bf16 -> [B,H,W,C] bf16."""
     _chk(latents, pq_w, pq_b, dtype=torch.float32)
-    _chk(w, bias, dtype=_BF)
+    _chk(w, bias, dtype=w.dtype)
     B, _, H, W = latents.shape
     C = w.shape[0]
-    y = torch.empty((B, H, W, C), dtype=_BF, device=latents.device)
-    check(_lib.load().ds_vae_conv_in_bf16(_p(latents), _p(pq_w), _p(pq_b), _p(w), _p(bias), _p(y), B, H, W, C,
-                                          scaling_factor, _stream()), "ds_vae_conv_in_bf16")
+    y = torch.empty((B, H, W, C), dtype=w.dtype, device=latents.device)
+    L = _lib.load()
+    fn, name = (L.ds_vae_conv_in_bf16, "ds_vae_conv_in_bf16") if w.dtype == _BF else (L.ds_vae_conv_in_f16, "ds_vae_conv_in_f16")
+    check(fn(_p(latents), _p(pq_w), _p(pq_b), _p(w), _p(bias), _p(y), B, H, W, C, scaling_factor, _stream()), name)
     return y
 
 
 def vae_conv_out(x: Tensor, w: Tensor, bias: Tensor, denormalize: bool = False) -> Tensor:
-    """x [B,H,W,C] bf16, w [3,3,3,C], bias [3] bf16 -> image fp32 NCHW [B,3,H,W] (denormalize: (y/2+0.5).clamp(0,1))."""
-    _chk(x, w, bias, dtype=_BF)
+    """x [B,H,W,C] bf16 (or f16), w [3,3,3,C], bias [3] same dtype -> image fp32 NCHW [B,3,H,W] (denormalize: (y/2+0.5).clamp(0,1))."""
+    _chk(x, w, bias, dtype=x.dtype)
     B, H, W, C = x.shape
     img = torch.empty((B, 3, H, W), dtype=torch.float32, device=x.device)
-    check(_lib.load().ds_vae_conv_out_bf16(_p(x), _p(w), _p(bias), _p(img), B, H, W, C, int(denormalize), _stream()),
-          "ds_vae_conv_out_bf16")
+    L = _lib.load()
+    fn, name = (L.ds_vae_conv_out_bf16, "ds_vae_conv_out_bf16") if x.dtype == _BF else (L.ds_vae_conv_out_f16, "ds_vae_conv_out_f16")
+    check(fn(_p(x), _p(w), _p(bias), _p(img), B, H, W, C, int(denormalize), _stream()), name)
     return img
+
+
+# ---- f16 twins used by the decoder's scaled-fp16 mode (vae.py)
+def groupnorm_scaled(x: Tensor, gamma: Tensor, beta: Tensor, groups: int, eps: float, silu: bool, out_scale: float) -> Tensor:
+    """x: [B,HW,C] f16 -> act(GroupNorm(x)) * out_scale."""
+    _chk(x, gamma, beta)
+    B, HW, C = x.shape
+    L = _lib.load()
+    ws = torch.empty(L.ds_groupnorm_workspace_bytes(B, C), dtype=torch.uint8, device=x.device)
+    y = torch.empty_like(x)
+    check(L.ds_groupnorm_scaled_f16(_p(x), _p(y), _p(gamma), _p(beta), _p(ws), B, HW, C, groups, eps, int(silu),
+                                    float(out_scale), _stream()), "ds_groupnorm_scaled_f16")
+    return y
+
+
+def wide_attention_f16(q: Tensor, k: Tensor, vt: Tensor, scale: float, n_valid: int = 0) -> Tensor:
+    """`wide_attention_bf16` on f16 tensors."""
+    _chk(q, k, vt)
+    B, N, D = q.shape
+    assert D == 512 and vt.shape == (B, 512, N)
+    o = torch.empty_like(q)
+    check(_lib.load().ds_wide_attn_f16(_p(q), _p(k), _p(vt), _p(o), B, N, int(n_valid), scale, _stream()), "ds_wide_attn_f16")
+    return o
 
 
 # ---- MLLM pre-pass: LLaMA greedy decoding (csrc/llm.hip) ----------------------------------------------------

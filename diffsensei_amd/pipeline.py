@@ -444,9 +444,18 @@ class DiffSenseiPipeline:
             return out_latents
         scaling = getattr(getattr(self.vae, "config", None), "scaling_factor", 0.13025)
         if isinstance(self.vae, VaeDecoderEngine):  # incl. postprocess' denormalize, all on the HIP kernels
-            image = self.vae.decode(out_latents, return_dict=False, scaling_factor=scaling, denormalize=True)[0]
+            image = self.vae.decode(out_latents, return_dict=False, scaling_factor=scaling, denormalize=True,
+                                    latents_affine=True)[0]      # latents_mean / latents_std (:348-357) folded at load time
         else:
-            image = self.vae.decode(out_latents.float() / scaling, return_dict=False)[0]
+            vc = getattr(self.vae, "config", None)
+            lm, ls = getattr(vc, "latents_mean", None), getattr(vc, "latents_std", None)
+            z = out_latents.float()
+            if lm is not None and ls is not None:                # reference :348-357, a user-supplied decoder object
+                view = lambda v: torch.tensor(list(v), dtype=z.dtype, device=z.device).view(1, -1, 1, 1)
+                z = z * view(ls) / scaling + view(lm)
+            else:
+                z = z / scaling
+            image = self.vae.decode(z, return_dict=False)[0]
             image = (image / 2 + 0.5).clamp(0, 1)
         if output_type == "pt":
             return image

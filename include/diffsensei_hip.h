@@ -97,6 +97,23 @@ int ds_vae_conv_in_bf16(const float* latents, const float* post_quant_w, const f
 int ds_vae_conv_out_bf16(const void* x, const void* w, const void* bias, float* image, int B, int H, int W, int C,
                          int denormalize, void* stream);
 
+/* ---- the same decoder in scaled fp16 (diffsensei_amd/vae.py, precision "fp16-scaled": what runs when the VAE config has
+ * force_upcast, i.e. where the reference upcasts the VAE to fp32 "as it overflows in float16", pipeline_diffsensei.py:339-344).
+ * All tensors f16.  Conv outputs and the residual stream are stored multiplied by S = 2^-6 (range 4.2e6, fp16's 11-bit
+ * mantissa instead of bf16's 8), conv INPUTS are O(1): GroupNorm+SiLU outputs, pre-multiplied by S through `out_scale` so
+ * that every accumulator already carries the factor; biases are pre-scaled on the host; GroupNorm of a scaled tensor is
+ * exact with eps * S^2.  The 3x3 convs and linears go through ds_conv3x3_f16 / ds_gemm_f16 / ds_gemm_f16_batched. */
+/* GroupNorm (+SiLU) over x[B,HW,C], y = act(norm(x)) * out_scale; ws: ds_groupnorm_workspace_bytes(B, C) */
+int ds_groupnorm_scaled_f16(const void* x, void* y, const void* gamma, const void* beta, void* ws, int B, int HW, int C,
+                            int groups, float eps, int silu, float out_scale, void* stream);
+/* ds_wide_attn_bf16 / ds_vae_conv_in_bf16 / ds_vae_conv_out_bf16 with f16 tensors (same arguments) */
+int ds_wide_attn_f16(const void* q, const void* k, const void* vt, void* o, int B, int N, int n_valid, float scale,
+                     void* stream);
+int ds_vae_conv_in_f16(const float* latents, const float* post_quant_w, const float* post_quant_b, const void* w,
+                       const void* bias, void* y, int B, int H, int W, int C, float scaling_factor, void* stream);
+int ds_vae_conv_out_f16(const void* x, const void* w, const void* bias, float* image, int B, int H, int W, int C,
+                        int denormalize, void* stream);
+
 /* 3x3 convolution, pad 1, NHWC: y[B,Ho,Wo,Cout] = conv(x[B,H,W,Cin], w[Cout,3,3,Cin]) + bias
  * (+ rowbias[b, :] per image — the resnet time_emb_proj term) (+ residual).  stride in {1,2};
  * upsample != 0 fuses a nearest x2 upsample in front (diffusers Upsample2D).  Cin % 64 == 0.

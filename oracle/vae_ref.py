@@ -21,7 +21,7 @@ State-dict keys are diffusers' (`decoder.up_blocks.0.resnets.1.conv1.weight`, `p
 from __future__ import annotations
 
 import math
-from typing import Dict
+from typing import Dict, Optional
 
 import torch
 import torch.nn.functional as F
@@ -52,14 +52,18 @@ def _attention(sd, p, x, groups, eps):
 
 
 def vae_decode(sd: Dict[str, Tensor], z: Tensor, layers_per_block: int = 2, groups: int = 32, eps: float = 1e-6,
-               n_up: int = 4) -> Tensor:
-    """`vae.decode(z)[0]`: z [B,4,h,w] (already divided by scaling_factor) -> image [B,3,8h,8w], fp32."""
+               n_up: int = 4, taps: Optional[dict] = None) -> Tensor:
+    """`vae.decode(z)[0]`: z [B,4,h,w] (already divided by scaling_factor) -> image [B,3,8h,8w], fp32.
+    `taps`: filled with max |activation| of the residual stream after each block (tests that push the decoder into the
+    magnitude range where the real SDXL VAE overflows fp16)."""
     sd = {k: v.float() for k, v in sd.items()}
+    tap = (lambda name, t: taps.__setitem__(name, float(t.abs().max()))) if taps is not None else (lambda name, t: None)
     x = F.conv2d(z.float(), sd["post_quant_conv.weight"], sd["post_quant_conv.bias"])
     x = F.conv2d(x, sd["decoder.conv_in.weight"], sd["decoder.conv_in.bias"], padding=1)
     x = _resnet(sd, "decoder.mid_block.resnets.0", x, groups, eps)
     x = _attention(sd, "decoder.mid_block.attentions.0", x, groups, eps)
     x = _resnet(sd, "decoder.mid_block.resnets.1", x, groups, eps)
+    tap("mid_block", x)
     for i in range(n_up):
         for j in range(layers_per_block + 1):
             x = _resnet(sd, f"decoder.up_blocks.{i}.resnets.{j}", x, groups, eps)
@@ -67,5 +71,6 @@ def vae_decode(sd: Dict[str, Tensor], z: Tensor, layers_per_block: int = 2, grou
             x = F.interpolate(x, scale_factor=2.0, mode="nearest")
             x = F.conv2d(x, sd[f"decoder.up_blocks.{i}.upsamplers.0.conv.weight"],
                          sd[f"decoder.up_blocks.{i}.upsamplers.0.conv.bias"], padding=1)
+        tap(f"up_blocks.{i}", x)
     x = F.silu(F.group_norm(x, groups, sd["decoder.conv_norm_out.weight"], sd["decoder.conv_norm_out.bias"], eps))
     return F.conv2d(x, sd["decoder.conv_out.weight"], sd["decoder.conv_out.bias"], padding=1)

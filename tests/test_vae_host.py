@@ -31,3 +31,25 @@ def test_oracle_decode_structure():
     sd2 = dict(sd)
     sd2["decoder.conv_out.bias"] = sd["decoder.conv_out.bias"] + torch.tensor([1.0, -2.0, 0.5])
     assert torch.allclose(vae_decode(sd2, z, 1, 8, cfg.eps) - img, torch.tensor([1.0, -2.0, 0.5]).view(1, 3, 1, 1).expand_as(img), atol=1e-5)
+
+
+def test_latents_mean_std_fold_equals_the_reference_formula():
+    """reference src/pipelines/pipeline_diffsensei.py:348-357: `latents * latents_std / scaling_factor + latents_mean`, then
+    decode.  The product folds that per-channel affine map into post_quant_conv (`vae.fold_latents_affine`); on the oracle
+    decoder the folded weights applied to `latents / scaling_factor` must give the reference formula's image."""
+    from diffsensei_amd.vae import fold_latents_affine
+    from oracle.vae_ref import vae_decode
+    cfg = VaeConfig(block_out_channels=(32, 32, 64, 64), layers_per_block=1, norm_num_groups=8)
+    sd = random_state_dict(cfg, 3)
+    mean, std, sf = [0.3, -0.2, 0.05, 1.1], [1.2, 0.7, 2.0, 0.9], 0.13025
+    lat = torch.randn(2, 4, 5, 7, generator=torch.Generator().manual_seed(2))
+    ref = vae_decode(sd, lat * torch.tensor(std).view(1, 4, 1, 1) / sf + torch.tensor(mean).view(1, 4, 1, 1), 1, 8, cfg.eps)
+    w2, b2 = fold_latents_affine(sd["post_quant_conv.weight"], sd["post_quant_conv.bias"], mean, std)
+    sd2 = dict(sd)
+    sd2["post_quant_conv.weight"], sd2["post_quant_conv.bias"] = w2.view(4, 4, 1, 1), b2
+    got = vae_decode(sd2, lat / sf, 1, 8, cfg.eps)
+    assert torch.allclose(got, ref, atol=2e-5, rtol=1e-5), (got - ref).abs().max()
+    import pytest
+    with pytest.raises(ValueError):          # the pair comes together
+        from diffsensei_amd.vae import VaeDecoderEngine
+        VaeDecoderEngine(VaeConfig(latents_mean=mean), {}, device="cpu")
