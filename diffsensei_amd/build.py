@@ -1,6 +1,6 @@
 """Build the gfx950 kernel library in-tree: diffsensei_amd/lib/libdiffsensei_hip.so.
 
-    python -m diffsensei_amd.build [--force] [--ablation] [--experimental]
+    python -m diffsensei_amd.build [--force] [--ablation]
 
 hipcc cross-compiles for gfx950 without a GPU, so this runs in the build container; the resulting .so travels
 with the tree to the GPU box.  One hipcc invocation per source (parallel), then one link.
@@ -19,7 +19,6 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libdiffsensei_hip.so")
 SOURCES = ["gemm.hip", "gemm_pp.hip", "conv_halo.hip", "vae.hip", "norm.hip", "attention.hip", "attention_fp8.hip", "elementwise.hip", "llm.hip", "preprocess.hip",
            "capi.hip"]
-EXPERIMENTAL = [os.path.join("experimental", "gemm_w4.hip")]   # --experimental only: unmeasured kernels behind explicit knobs
 HEADERS = ["ds_common.h", "ds_kernels.h", os.path.join("..", "..", "include", "diffsensei_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffast-math", "-fno-finite-math-only",
          "-Wno-unused-result"]
@@ -41,14 +40,12 @@ def _digest(extra=()) -> str:
     return h.hexdigest()
 
 
-def build(force: bool = False, verbose: bool = True, ablation: bool = False, experimental: bool = False) -> str:
+def build(force: bool = False, verbose: bool = True, ablation: bool = False) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     stamp = os.path.join(LIBDIR, "build.stamp")
-    # A/B sessions: every build() call of the process tree (tests' hip_lib fixture, bench.py) keeps the experimental kernels
-    experimental = experimental or os.environ.get("DIFFSENSEI_BUILD_EXPERIMENTAL") == "1"
-    flags = FLAGS + (["-DDS_ABLATION"] if ablation else []) + (["-DDS_EXPERIMENTAL"] if experimental else [])
-    sources = SOURCES + (EXPERIMENTAL if experimental else [])
-    dig = _digest(EXPERIMENTAL if experimental else ()) + ("+ablation" if ablation else "") + ("+experimental" if experimental else "")
+    flags = FLAGS + (["-DDS_ABLATION"] if ablation else [])
+    sources = SOURCES
+    dig = _digest() + ("+ablation" if ablation else "")
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
         return LIB
     hipcc = _hipcc()
@@ -77,28 +74,5 @@ def build(force: bool = False, verbose: bool = True, ablation: bool = False, exp
     return LIB
 
 
-def check_experimental(verbose: bool = True) -> None:
-    """Compile-only check (hipcc -c, nothing linked) of the sources that are NOT part of the production library, so that
-    they cannot rot unnoticed; cached by content digest."""
-    os.makedirs(os.path.join(LIBDIR, "experimental"), exist_ok=True)
-    flags = FLAGS + ["-DDS_EXPERIMENTAL"]
-    for src in EXPERIMENTAL:
-        h = hashlib.sha256()
-        for f in [src] + HEADERS[:2]:
-            with open(os.path.join(CSRC, f), "rb") as fh:
-                h.update(fh.read())
-        obj = os.path.join(LIBDIR, "experimental", os.path.basename(src).replace(".hip", ".o"))
-        stamp = obj + ".stamp"
-        if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read().strip() == h.hexdigest():
-            continue
-        r = subprocess.run([_hipcc(), *flags, "-c", os.path.join(CSRC, src), "-o", obj], capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
-        with open(stamp, "w") as fh:
-            fh.write(h.hexdigest())
-        if verbose:
-            print(f"compiled (not linked) {src}")
-
-
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, ablation="--ablation" in sys.argv, experimental="--experimental" in sys.argv)
+    build(force="--force" in sys.argv, ablation="--ablation" in sys.argv)

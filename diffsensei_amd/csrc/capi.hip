@@ -44,11 +44,7 @@ int ds_device_info(int* cu_count, int* lds_bytes, char* arch_name, int arch_name
 int ds_set_option(const char* key, int value) {
     DS_REQUIRE(key != nullptr, "ds_set_option: null key");
     if (strcmp(key, "gemm_variant") == 0) {
-#ifdef DS_EXPERIMENTAL
-        DS_REQUIRE((value >= 0 && value <= 10) || value == 12, "gemm_variant must be 0..10 or 12 (experimental build)");
-#else
         DS_REQUIRE(value >= 0 && value <= 10, "gemm_variant must be 0..10");
-#endif
         ds_gemm_set_variant(value);
         return 0;
     }

@@ -27,10 +27,6 @@ struct GemmParams {
 int ds_launch_gemm(const GemmParams& p, int batch, hipStream_t stream);
 bool ds_gemm_pp_applicable(const GemmParams& p);  // gemm_pp.hip: 256 x 256 ping-pong kernel takes this shape
 int ds_launch_gemm_pp(const GemmParams& p, int batch, hipStream_t stream);
-#ifdef DS_EXPERIMENTAL
-bool ds_gemm_w4_applicable(const GemmParams& p);  // experimental/gemm_w4.hip: 4-wave 256 x 256 kernel (unmeasured)
-int ds_launch_gemm_w4(const GemmParams& p, int batch, hipStream_t stream);
-#endif
 bool ds_conv_halo_applicable(const GemmParams& p);  // conv_halo.hip: halo-patch 3x3 convolution takes this shape
 int ds_launch_conv_halo(const GemmParams& p, hipStream_t stream);
 void ds_conv_halo_set_variant(int v);  // 0 auto, 1 8x16-pixel blocks, 2 16x16-pixel blocks

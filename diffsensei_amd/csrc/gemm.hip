@@ -721,9 +721,6 @@ int ds_launch_gemm(const GemmParams& p_in, int batch, hipStream_t stream) {
         DS_REQUIRE(p.A2 == nullptr || (p.K1 % 64 == 0 && p.lda2 % 8 == 0), "gemm: split-A needs K1 %% 64 == 0");
     }
     if (p.epi == EPI_GEGLU) DS_REQUIRE(p.N % 128 == 0, "geglu: packed N (%d) must be a multiple of 128", p.N);
-#ifdef DS_EXPERIMENTAL  // python -m diffsensei_amd.build --experimental: csrc/experimental/gemm_w4.hip behind gemm_variant 12
-    if (g_gemm_variant == 12 && ds_gemm_w4_applicable(p)) return ds_launch_gemm_w4(p, batch, stream);
-#endif
     Choice c = choose(p, batch);
     if (p.dtype != DS_DTYPE_F16) {  // bf16 (VAE decoder): only the two kernels that are templated on the element type
         if (conv) {

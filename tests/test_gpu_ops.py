@@ -201,43 +201,6 @@ def test_gemm_pingpong_tile_handover(hip_lib, M, N, K, mode):
     _close(drained, ref, what=f"pingpong hand-over {mode}")
 
 
-@pytest.mark.parametrize("M,N,K,mode", [(512, 512, 128, "res"), (4096, 12288, 256, "bias"), (8192, 2560, 1280, "none"),
-                                        (16384, 1280, 640, "inplace"), (8192, 10240, 1280, "geglu")])
-def test_gemm_w4_experimental(hip_lib, M, N, K, mode):
-    """csrc/experimental/gemm_w4.hip (four waves, 128 x 128 per wave; only in a library built with
-    `python -m diffsensei_amd.build --experimental`, where gemm_variant 12 selects it; skipped on the production build):
-    the same MFMA order per output as every other GEMM kernel, so bit-identical to the register-staged one."""
-    from diffsensei_amd import _lib
-    from diffsensei_amd.engine import pack_geglu
-    ops = _ops(hip_lib)
-    lib = _lib.load()
-    if lib.ds_set_option(b"gemm_variant", 12) != 0:
-        pytest.skip("production build: the experimental kernels are not compiled in")
-    try:
-        g = torch.Generator().manual_seed(M + N + K)
-        x, w = _r((M, K), g).to(DEV), _r((N, K), g, 1 / math.sqrt(K)).to(DEV)
-        b = None if mode == "none" else _r((N,), g).to(DEV)
-        res = _r((M, N), g).to(DEV) if mode in ("res", "inplace") else None
-        kw = {}
-        if mode == "geglu":
-            w, b = pack_geglu(w, b)
-            kw["geglu"] = True
-
-        def run():
-            if mode == "inplace":
-                buf = res.clone()
-                return ops.gemm(x, w, b, residual=buf, out=buf)
-            return ops.gemm(x, w, b, residual=res, **kw)
-
-        lib.ds_set_option(b"gemm_variant", 1)
-        base = run().clone()
-        lib.ds_set_option(b"gemm_variant", 12)
-        for _ in range(5):
-            assert torch.equal(run(), base)
-    finally:
-        lib.ds_set_option(b"gemm_variant", 0)
-
-
 @pytest.mark.parametrize("M,N,K", [(2048, 1280, 1280), (2048, 2560, 1280), (2048, 1280, 5120), (8192, 640, 640),
                                    (200, 136, 256), (64, 128, 320), (1000, 640, 2560), (4096, 1280, 1280)])
 def test_gemm_ring_buffered_small_grid_kernel(hip_lib, M, N, K):
