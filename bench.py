@@ -109,14 +109,16 @@ def build_pipeline(device, num_gpus, rank, seed=0, with_vae=True, agent=None, ke
     if keep_oracle:
         keep.update(tokenizer=tok, tokenizer_2=tok, resampler_heads=20, resampler_dim_head=64, vae_seed=seed + 2)
         pipe._oracle_modules = keep
-    # N > 1: every engine's frozen weights (pipe.tensors() [+ the MLLM agent]) go out from rank 0 in 512 MiB buckets,
-    # then an all-reduced checksum proves the replicas are bit-identical (ranks != 0 were seeded differently on purpose)
-    bstats = {"bytes": 0, "seconds": 0.0, "buckets": 0, "verify_ms": 0.0, "tensors": 0}
+    # N > 1: every engine's frozen weights (pipe.tensors() [+ the MLLM agent]) are re-homed into one flat arena per dtype and
+    # the arena goes out from rank 0 in asynchronous 512 MiB slices (no staging copies), then an all-reduced checksum proves
+    # the replicas are bit-identical (ranks != 0 were seeded differently on purpose)
+    bstats = {"bytes": 0, "seconds": 0.0, "buckets": 0, "verify_ms": 0.0, "tensors": 0, "consolidate_s": 0.0}
     if num_gpus > 1:
         dist.barrier()
         bstats = broadcast_pipeline(pipe, extra=[agent] if agent is not None else [])
     return pipe, {"init_s": round(t_init, 2), "broadcast_bytes": bstats["bytes"],
                   "broadcast_ms": round(bstats["seconds"] * 1e3, 2), "broadcast_buckets": bstats["buckets"],
+                  "broadcast_rehome_ms": round(bstats.get("consolidate_s", 0.0) * 1e3, 2),
                   "broadcast_verify_ms": round(bstats["verify_ms"], 2), "broadcast_tensors": bstats["tensors"]}
 
 

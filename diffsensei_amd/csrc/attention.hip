@@ -584,6 +584,11 @@ int ds_launch_self_attn(const SelfAttnParams& p, hipStream_t stream) {
     // 64 query rows per wave when that still leaves >= 2 blocks per CU; 32 rows per wave otherwise
     const long blocks2 = (long)((p.Nq + 255) / 256) * p.B * p.heads;
     // (measured on MI355X: 64-row waves win from N = 4096 up, lose at N = 1024 — profiles/r01_attn_variants.txt)
+    // Large grids: the software-pipelined kernel (attention_sp.hip; 256 query rows per block).  Measured on MI355X, interleaved
+    // rounds, profiles/r03_self_attn_sp.txt: B = 32, N = 1024 250 vs 276 us; B = 32, N = 4096 1581 vs 1679 us; B = 8, N = 4096 398 vs
+    // 422 us; below ~1000 blocks (B = 8, N = 1024: 640 blocks; B = 2) the plain kernels are 2-8 % faster.
+    const long blocks_sp = (long)((p.Nq + 255) / 256) * p.B * p.heads;
+    if (g_attn_variant == 3 || (g_attn_variant == 0 && blocks_sp >= 1024)) return ds_launch_self_attn_sp(p, stream);
     if (g_attn_variant == 2 || (blocks2 >= 512 && p.Nk >= 2048 && g_attn_variant != 1)) {
         hipLaunchKernelGGL(self_attn_kernel<2>, dim3((p.Nq + 255) / 256, p.B * p.heads), dim3(256), 0, stream, p);
     } else {

@@ -53,7 +53,7 @@ int ds_set_option(const char* key, int value) {
         return 0;
     }
     if (strcmp(key, "attn_variant") == 0) {
-        DS_REQUIRE(value >= 0 && value <= 2, "attn_variant must be 0..2");
+        DS_REQUIRE(value >= 0 && value <= 3, "attn_variant must be 0..3");
         ds_attn_set_variant(value);
         return 0;
     }

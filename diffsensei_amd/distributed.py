@@ -6,8 +6,9 @@ The reference itself has no inference parallelism (demos pin 'cuda:0'); the only
 the start-up weight broadcast, plus an optional gather of results to rank 0.  `torch.distributed` backend "nccl"
 IS RCCL on ROCm; the same code runs on gloo for the CPU tests.
 
-xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring broadcast is per-link bound, so the arena is sent in
-a few LARGE buckets (default 512 MiB) rather than per-tensor messages — ~7 GB of fp16 weights ~= 50-60 ms.
+xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring broadcast is per-link bound, so the weights are re-homed
+into one flat arena per dtype (`WeightArena`) and the arena itself is sent in a few LARGE slices (default 512 MiB),
+issued asynchronously with one final wait — no per-tensor messages, no staging copies; ~9 GB of weights ~= 60-70 ms.
 """
 from __future__ import annotations
 
@@ -43,47 +44,96 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     return rank, world, local
 
 
-def broadcast_tensors(tensors: Sequence[Tensor], src: int = 0, bucket_bytes: int = 512 << 20,
-                      force: bool = False) -> Dict[str, float]:
-    """In-place broadcast of same-device tensors from `src`, coalesced into large flat buckets per dtype.
-    `force`: issue the collectives even in a 1-rank group (the RCCL bring-up test on a single GPU)."""
+class WeightArena:
+    """Every frozen weight of a serving process in ONE flat buffer per (device, dtype).
+
+    `WeightArena(tensors)` re-homes the given tensors: each keeps its Python identity, shape and values, but its storage
+    becomes a 256-byte-aligned slice of the arena (`Tensor.set_`), after ONE device-to-device copy per tensor at start-up.
+    The weight broadcast then runs on slices of the arena itself - no `torch.cat` staging buffer, no copy-back (the
+    round-2 path moved every byte three times and held an extra 512 MiB), and the slices are issued as asynchronous
+    collectives with a single wait at the end, so RCCL pipelines them over the xGMI ring.
+    Data pointers change: callers must drop launch plans / packed copies derived from the old storage
+    (`weights_changed()` of the engines - `broadcast_pipeline` does it)."""
+    ALIGN = 256
+
+    def __init__(self, tensors: Sequence[Tensor]):
+        self.buffers: Dict[Tuple[torch.device, torch.dtype], Tensor] = {}
+        self.loose: List[Tensor] = []          # not contiguous: left where they are, broadcast one by one
+        groups: Dict[Tuple[torch.device, torch.dtype], List[Tensor]] = {}
+        seen: Dict[Tuple[int, int, Tuple[int, ...]], Tensor] = {}
+        self._alias: List[Tuple[Tensor, Tensor]] = []
+        for t in tensors:
+            if not t.is_contiguous():
+                self.loose.append(t)
+                continue
+            key = (t.data_ptr(), t.numel() * t.element_size(), tuple(t.shape))
+            if t.numel() and key in seen:       # the same memory listed twice (shared weights): one slot, both re-homed to it
+                if seen[key] is not t:
+                    self._alias.append((t, seen[key]))
+                continue
+            seen[key] = t
+            groups.setdefault((t.device, t.dtype), []).append(t)
+        self.bytes = 0                          # arena size (with alignment padding)
+        self.payload_bytes = sum(t.numel() * t.element_size() for t in tensors)
+        for (dev, dtype), lst in groups.items():
+            esz = lst[0].element_size()
+            step = max(1, self.ALIGN // esz)
+            offs, n = [], 0
+            for t in lst:
+                offs.append(n)
+                n += (t.numel() + step - 1) // step * step
+            flat = torch.zeros(n, dtype=dtype, device=dev)
+            for t, off in zip(lst, offs):
+                view = flat[off:off + t.numel()].view(t.shape)
+                view.copy_(t)
+                t.set_(view)
+            self.buffers[(dev, dtype)] = flat
+            self.bytes += n * esz
+        for t, first in self._alias:
+            t.set_(first)
+
+    def slices(self, bucket_bytes: int) -> List[Tensor]:
+        out = []
+        for flat in self.buffers.values():
+            m = max(1, bucket_bytes // flat.element_size())
+            out += [flat[o:o + m] for o in range(0, flat.numel(), m)]
+        return out + list(self.loose)
+
+
+def broadcast_arena(arena: WeightArena, src: int = 0, bucket_bytes: int = 512 << 20, force: bool = False) -> Dict[str, float]:
+    """Broadcast the arena's buffers from `src` in `bucket_bytes` slices: all collectives issued asynchronously, one wait."""
     stats = {"bytes": 0, "buckets": 0, "seconds": 0.0}
     if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return stats
     t0 = time.perf_counter()
-    by_dtype: Dict[torch.dtype, List[Tensor]] = {}
-    for t in tensors:
-        by_dtype.setdefault(t.dtype, []).append(t)
-    for dtype, lst in by_dtype.items():
-        esz = lst[0].element_size()
-        bucket: List[Tensor] = []
-        size = 0
-
-        def flush():
-            nonlocal bucket, size
-            if not bucket:
-                return
-            flat = torch.cat([b.reshape(-1) for b in bucket])
-            dist.broadcast(flat, src=src)
-            off = 0
-            for b in bucket:
-                n = b.numel()
-                b.copy_(flat[off:off + n].view_as(b))
-                off += n
-            stats["bytes"] += flat.numel() * esz
-            stats["buckets"] += 1
-            bucket, size = [], 0
-
-        for t in lst:
-            nb = t.numel() * esz
-            if size and size + nb > bucket_bytes:
-                flush()
-            bucket.append(t)
-            size += nb
-        flush()
-    if tensors and tensors[0].is_cuda:
+    work = []
+    for sl in arena.slices(bucket_bytes):
+        work.append(dist.broadcast(sl, src=src, async_op=True))
+        stats["bytes"] += sl.numel() * sl.element_size()
+        stats["buckets"] += 1
+    for w in work:
+        w.wait()
+    if any(dev.type == "cuda" for dev, _ in arena.buffers):
         torch.cuda.synchronize()
     stats["seconds"] = time.perf_counter() - t0
+    return stats
+
+
+def broadcast_tensors(tensors: Sequence[Tensor], src: int = 0, bucket_bytes: int = 512 << 20,
+                      force: bool = False) -> Dict[str, float]:
+    """In-place broadcast of tensors from `src`: they are re-homed into a `WeightArena` (their data pointers change!) and
+    the arena is broadcast in large asynchronous slices.  `force`: issue the collectives even in a 1-rank group (the RCCL
+    bring-up test on a single GPU).  Returns {"bytes", "buckets", "seconds", "consolidate_s"}."""
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
+        return {"bytes": 0, "buckets": 0, "seconds": 0.0, "consolidate_s": 0.0}
+    t0 = time.perf_counter()
+    arena = WeightArena(tensors)
+    if any(dev.type == "cuda" for dev, _ in arena.buffers):
+        torch.cuda.synchronize()
+    t_cons = time.perf_counter() - t0
+    stats = broadcast_arena(arena, src=src, bucket_bytes=bucket_bytes, force=force)
+    stats["arena_bytes"], stats["bytes"] = stats["bytes"], arena.payload_bytes   # "bytes": the tensors' own; arena: + padding
+    stats["consolidate_s"] = t_cons
     return stats
 
 
@@ -134,7 +184,12 @@ def broadcast_pipeline(pipe, extra: Sequence = (), src: int = 0, bucket_bytes: i
         if m is not None:
             tensors += list(m.tensors())
     stats = broadcast_tensors(tensors, src=src, bucket_bytes=bucket_bytes, force=force)
-    pipe.unet.weights_changed()
+    # the tensors now live in the weight arena (new data pointers) and, on ranks != src, hold new values: every engine
+    # drops what it derived from the old storage (packed copies, launch plans with raw pointers)
+    names = ("unet", "text_encoder", "text_encoder_2", "image_encoder", "magi_image_encoder", "image_proj_model", "vae")
+    for m in [getattr(pipe, n, None) for n in names] + list(extra):
+        if m is not None and hasattr(m, "weights_changed"):
+            m.weights_changed()
     t0 = time.perf_counter()
     ver = verify_replicas(tensors) if (dist.is_initialized() and (dist.get_world_size() > 1 or force)) else \
         {"checksum": None, "elements": sum(t.numel() for t in tensors)}

@@ -198,6 +198,11 @@ class LlamaDecodeEngine:
                             p=(self.logits, self.chain if self.n_chain else None, self.state, self.out_ids)))
         return ops_
 
+    def weights_changed(self) -> None:
+        """The weight tensors moved or changed (multi-GPU broadcast into the weight arena): cached launch plans hold raw
+        pointers and are rebuilt on next use."""
+        self._plans.clear()
+
     def _plan(self, M: int, kind: str) -> Plan:
         key = (M, kind, self.n_chain, self.chain.data_ptr())
         pl = self._plans.get(key)
@@ -426,6 +431,11 @@ class ContinuousLVLM:
     def tensors(self) -> List[Tensor]:
         """Frozen weights of the whole agent: LLaMA decode engine + both QwenResamplers (multi-GPU broadcast list)."""
         return self.llm.tensors() + self.input_resampler.tensors() + self.output_resampler.tensors()
+
+    def weights_changed(self) -> None:
+        self.llm.weights_changed()
+        self.input_resampler._add.clear()
+        self.output_resampler._add.clear()
 
     @torch.no_grad()
     def generate(self, tokenizer=None, prompt=None, input_ids=None, image_embeds=None, ids_cmp_mask=None,

@@ -232,3 +232,31 @@ def test_broadcast_pipeline_and_replica_check_world2():
     (_, b0, a0, ok0, r0), (_, b1, a1, ok1, r1) = res
     assert b0 != b1 and a0 == a1 == b0 and ok0 and ok1
     assert r0 and r1, "a perturbed replica must be detected on both ranks"
+
+
+def test_weight_arena_rehomes_tensors_in_place():
+    """`WeightArena` (the no-staging weight broadcast): every tensor keeps its identity, shape and values but ends up as a
+    256-byte-aligned slice of ONE flat buffer per dtype; memory listed twice is re-homed once; a non-contiguous tensor is
+    left alone and broadcast on its own."""
+    from diffsensei_amd.distributed import WeightArena
+    g = torch.Generator().manual_seed(0)
+    ts = [torch.randn(s, generator=g).half() for s in [(7, 3), (640, 640), (5,), (33, 2, 2)]]
+    ts += [torch.arange(6, dtype=torch.float32), torch.randn(3, 3, generator=g)]
+    shared = ts[1]
+    odd = torch.randn(8, 6, generator=g).half().t()               # not contiguous
+    lst = ts + [shared, odd]
+    before = [t.clone() for t in lst]
+    ids = [id(t) for t in lst]
+    arena = WeightArena(lst)
+    assert [id(t) for t in lst] == ids and all(torch.equal(a, b) for a, b in zip(lst, before))
+    assert set(k[1] for k in arena.buffers) == {torch.float16, torch.float32} and arena.loose == [odd]
+    f16 = next(v for k, v in arena.buffers.items() if k[1] == torch.float16)
+    lo, hi = f16.data_ptr(), f16.data_ptr() + f16.numel() * 2
+    for t in ts[:4]:
+        assert lo <= t.data_ptr() < hi and (t.data_ptr() - lo) % 256 == 0 and t.is_contiguous()
+    assert arena.payload_bytes == sum(t.numel() * t.element_size() for t in lst) and arena.bytes >= sum(t.numel() * t.element_size() for t in ts)
+    # writing through the arena IS writing the tensors (what the in-place broadcast relies on)
+    f16.zero_()
+    assert all(float(t.abs().sum()) == 0 for t in ts[:4]) and float(ts[4].sum()) == 15.0
+    sl = arena.slices(1 << 10)
+    assert sum(x.numel() * x.element_size() for x in sl if x is not odd) == arena.bytes and sl[-1] is odd

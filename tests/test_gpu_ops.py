@@ -571,6 +571,95 @@ def test_self_attention_forced_rescale(hip_lib):
     _close(ops.self_attention(q.to(DEV), k.to(DEV), vt.to(DEV), 1), ref, tol=3e-3, what="rescale")
 
 
+def _with_attn_variant(lib, var, fn):
+    assert lib.ds_set_option(b"attn_variant", var) == 0
+    try:
+        return fn()
+    finally:
+        lib.ds_set_option(b"attn_variant", 0)
+
+
+@pytest.mark.parametrize("B,heads,N", [(1, 2, 256), (2, 10, 1024), (1, 4, 960), (1, 2, 72), (1, 3, 4096), (2, 5, 2312),
+                                       (1, 1, 64), (1, 2, 128), (1, 1, 40), (2, 2, 1000)])
+def test_self_attention_software_pipelined_variant(hip_lib, B, heads, N):
+    """`self_attn_sp_kernel` (attention_sp.hip, attn_variant 3: scores of pair k+1 and P V of pair k-1 on the matrix pipe while
+    the VALU exponentiates pair k; deferred rescale; LDS-DMA ring) vs fp32 SDPA at the tolerance of the other flash kernels,
+    incl. one-tile problems, ragged query / key counts, and agreement with `self_attn_kernel<1>` to fp16 rounding."""
+    from diffsensei_amd import _lib
+    ops = _ops(hip_lib)
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(B + heads + N)
+    q, k, vt, ref = _sdpa_case(g, B, heads, N)
+    got = _with_attn_variant(lib, 3, lambda: ops.self_attention(q, k, vt, heads))
+    base = _with_attn_variant(lib, 1, lambda: ops.self_attention(q, k, vt, heads))
+    _close(got, ref, tol=3e-3, what="self-attn sp")
+    _close(got, base.float().cpu(), tol=2e-3, what="self-attn sp vs <1>")
+    # determinism: the ring / skew bookkeeping has no launch-to-launch freedom
+    again = _with_attn_variant(lib, 3, lambda: ops.self_attention(q, k, vt, heads))
+    assert torch.equal(got, again)
+
+
+@pytest.mark.parametrize("B,heads,N", [(2, 2, 63), (1, 4, 99), (1, 2, 1001), (2, 1, 20), (1, 3, 2317)])
+def test_self_attention_sp_any_token_count(hip_lib, B, heads, N):
+    """Token counts that are not multiples of 8: V^T rows padded to 8 keys with LARGE finite content that must not leak
+    (the kernel clamps its LDS-DMA chunks to the last one holding a real key and masks scores of keys >= Nk)."""
+    from diffsensei_amd import _lib
+    ops = _ops(hip_lib)
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(B + heads + N)
+    C = heads * 64
+    q, k, v = _r((B, N, C), g), _r((B, N, C), g), _r((B, N, C), g)
+    hs = lambda t: t.float().view(B, N, heads, 64).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(hs(q), hs(k), hs(v)).transpose(1, 2).reshape(B, N, C)
+    Np = (N + 7) // 8 * 8
+    vt = torch.full((B, heads, 64, Np), 100.0, dtype=torch.float16)
+    vt[..., :N] = v.view(B, N, heads, 64).permute(0, 2, 3, 1)
+    got = _with_attn_variant(lib, 3, lambda: ops.self_attention(q.to(DEV), k.to(DEV), vt.to(DEV), heads))
+    _close(got, ref, tol=3e-3, what="ragged self-attn sp")
+
+
+@pytest.mark.parametrize("spike_at,gain", [(300, 6.0), (70, 10.0), (5, 8.0), (1000, 4.0)])
+def test_self_attention_sp_deferred_rescale(hip_lib, spike_at, gain):
+    """The deferred rescale (threshold 8 in base-2 logits) is a rare data-dependent branch: force it.  One key aligned with
+    one query row makes that row's maximum jump by far more than the threshold at a chosen tile (first, second, late);
+    a second case scales ALL scores so that many rows cross the threshold at different tiles, and a third keeps every score
+    far BELOW the initial reference (the first tile must re-centre, or the f16 probabilities would underflow)."""
+    from diffsensei_amd import _lib
+    ops = _ops(hip_lib)
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(3 + spike_at)
+    B, heads, N = 1, 2, 1088
+    C = heads * 64
+    q, k, v = _r((B, N, C), g), _r((B, N, C), g), _r((B, N, C), g)
+    k[0, spike_at, :64] = q[0, 17, :64] * gain
+    k[0, min(spike_at + 400, N - 1), 64:] = q[0, 700, 64:] * gain
+    hs = lambda t: t.float().view(B, N, heads, 64).transpose(1, 2)
+    vt = v.view(B, N, heads, 64).permute(0, 2, 3, 1).contiguous()
+    for name, qq in (("spike", q), ("hot", q * 5.0), ("cold", q)):
+        kk = k if name != "cold" else -(q.abs() + 1.0) * torch.sign(q) * 3.0   # q . k = -3 sum(q^2 + |q|): every score << 0
+        ref = F.scaled_dot_product_attention(hs(qq), hs(kk), hs(v)).transpose(1, 2).reshape(B, N, C)
+        got = _with_attn_variant(lib, 3, lambda: ops.self_attention(qq.to(DEV), kk.to(DEV), vt.to(DEV), heads))
+        assert torch.isfinite(got).all(), name
+        # "hot": logits of +-40; Q is pre-multiplied by scale * log2(e) and rounded to f16 once, so the logit error grows with
+        # |logit| (2^-11 relative) - 8e-3 there, the flash kernels' usual 4e-3 otherwise
+        _close(got, ref, tol=8e-3 if name == "hot" else 4e-3, what=f"deferred rescale [{name}]")
+
+
+def test_self_attention_sp_matches_reference_fixture(hip_lib, golden_dir):
+    """tests/golden/self_attn.npz is the output of the reference's own AttnProcessor2_0 (oracle/make_golden.py imports
+    src/models/attention_processor.py unmodified): the product's processor with the software-pipelined kernel forced."""
+    from diffsensei_amd import _lib
+    from diffsensei_amd.attention_processor import AttentionWeights, AttnProcessor2_0
+    lib = _lib.load()
+    g2 = np.load(os.path.join(golden_dir, "self_attn.npz"))
+    T2 = lambda k: torch.tensor(g2[k]).half().to(DEV)
+    a1 = AttentionWeights(128, None, int(g2["heads"]), DEV)
+    a1.to_q.weight, a1.to_k.weight, a1.to_v.weight = T2("wq"), T2("wk"), T2("wv")
+    a1.to_out[0].weight, a1.to_out[0].bias = T2("wo"), T2("bo")
+    y1 = _with_attn_variant(lib, 3, lambda: AttnProcessor2_0()(a1, T2("x")))
+    _close(y1, torch.tensor(g2["y"]), tol=1e-2, what="AttnProcessor2_0 (sp kernel) vs reference")
+
+
 def test_region_flags_bit_exact_vs_reference_fixture(hip_lib, golden_dir):
     ops = _ops(hip_lib)
     gfile = np.load(os.path.join(golden_dir, "ip_region_masks.npz"))

@@ -37,6 +37,7 @@ def test_rccl_broadcast_and_checksum_world1(hip_lib):
         cs0 = tensors_checksum(ws)
         stats = broadcast_tensors(ws, src=0, bucket_bytes=8 << 20, force=True)      # several buckets, two dtypes
         assert stats["buckets"] >= 3 and stats["bytes"] == sum(t.numel() * t.element_size() for t in ws)
+        assert stats["arena_bytes"] >= stats["bytes"]               # one flat arena per dtype, 256-byte aligned slots
         assert all(torch.equal(a, b) for a, b in zip(ws, before))
         ver = verify_replicas(ws)                                                     # all_reduce MIN / MAX over RCCL
         assert ver["checksum"] == int(cs0[0].item()) and ver["elements"] == sum(t.numel() for t in ws)
@@ -89,6 +90,12 @@ def test_broadcast_pipeline_covers_every_engine(hip_lib):
     try:
         stats = broadcast_pipeline(p, force=True)
         assert stats["tensors"] == len(ts) and stats["bytes"] == sum(t.numel() * t.element_size() for t in ts)
+        # no staging copies - the broadcast itself (asynchronous slices of the arena, one wait) stays
+        # far below 250 ms per 9 GB in a 1-rank RCCL group; the one-off re-homing copy is reported separately
+        gb = stats["bytes"] / 1e9
+        print(f"broadcast_pipeline world 1: {gb:.3f} GB in {stats['seconds'] * 1e3:.1f} ms ({stats['buckets']} slices), "
+              f"re-homing {stats['consolidate_s'] * 1e3:.1f} ms")
+        assert stats["seconds"] * 1e3 <= 250.0 * max(gb / 9.0, 0.05), stats
         assert stats["checksum"] is not None and stats["elements"] == sum(t.numel() for t in ts)
     finally:
         dist.destroy_process_group()

@@ -1,51 +1,33 @@
 #!/usr/bin/env python
-import os, sys
+"""Self-attention kernels at the UNet's shapes: interleaved rounds of the software-pipelined kernel (attn_variant 3) and the
+automatic choice among self_attn_kernel<1|2> (0); min and median of ROUNDS x 10 launches, HIP events."""
+import os, sys, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from diffsensei_amd import _lib, ops
 lib = _lib.load()
+ROUNDS = int(os.environ.get("ROUNDS", "5"))
+VARS = [int(v) for v in os.environ.get("VARS", "3,0").split(",")]
 g = torch.Generator(device="cuda").manual_seed(0)
 R = lambda *s: torch.randn(*s, generator=g, device="cuda").half()
-for (B, h, N) in [(8, 20, 1024), (8, 10, 4096), (2, 20, 1024), (2, 10, 4096)]:
+for (B, h, N) in [(32, 20, 1024), (32, 10, 4096), (8, 20, 1024), (8, 10, 4096), (2, 20, 1024), (2, 10, 4096), (2, 10, 16384)]:
     C = h * 64
     q, k, vt = R(B, N, C), R(B, N, C), R(B, h, 64, N)
-    outs, row = {}, []
-    for rnd in range(2):
-        for var in (1, 0):
+    outs, t = {}, {v: [] for v in VARS}
+    for rnd in range(ROUNDS):
+        for var in VARS:
             lib.ds_set_option(b"attn_variant", var)
-            o = ops.self_attention(q, k, vt, h)
+            outs[var] = ops.self_attention(q, k, vt, h)
             torch.cuda.synchronize()
-            outs[var] = o
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
             ev[0].record()
             for _ in range(10):
                 ops.self_attention(q, k, vt, h)
             ev[1].record()
             torch.cuda.synchronize()
-            us = ev[0].elapsed_time(ev[1]) * 100
-            row.append(f"var{var}: {us:7.1f} us ({4.0 * B * h * N * N * 64 / us / 1e6:6.1f} TF)")
-    d = (outs[0].float() - outs[1].float()).abs().max().item()
-    print(f"B={B} h={h} N={N}  " + "  ".join(row) + f"  maxdiff {d:.3g}", flush=True)
-lib.ds_set_option(b"attn_variant", 0)
-# 64-row GEMM tiles on the N=1280 shapes
-for (M, N, K) in [(8192, 1280, 1280), (8192, 1280, 5120), (8192, 2560, 1280), (32768, 640, 640), (32768, 640, 2560)]:
-    x = (torch.randn(M, K, generator=g, device="cuda") * 0.5).half()
-    w = (torch.randn(N, K, generator=g, device="cuda") * K ** -0.5).half()
-    b = R(N); r = R(M, N)
-    y = torch.empty(M, N, dtype=torch.float16, device="cuda")
-    row = []
-    for rnd in range(2):
-        for var in (2, 7):
-            lib.ds_set_option(b"gemm_variant", var)
-            ops.gemm(x, w, b, residual=r, out=y)
-            torch.cuda.synchronize()
-            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-            ev[0].record()
-            for _ in range(10):
-                ops.gemm(x, w, b, residual=r, out=y)
-            ev[1].record()
-            torch.cuda.synchronize()
-            us = ev[0].elapsed_time(ev[1]) * 100
-            row.append(f"v{var}: {us:6.1f} us ({2.0 * M * N * K / us / 1e6:6.1f} TF)")
-    print(f"M={M} N={N} K={K}  " + "  ".join(row), flush=True)
-lib.ds_set_option(b"gemm_variant", 0)
+            t[var].append(ev[0].elapsed_time(ev[1]) * 100)
+    lib.ds_set_option(b"attn_variant", 0)
+    fl = 4.0 * B * h * N * N * 64
+    row = "  ".join(f"var{v}: min {min(t[v]):7.1f} us ({fl / min(t[v]) / 1e6:6.1f} TF) med {statistics.median(t[v]):7.1f}" for v in VARS)
+    d = (outs[VARS[0]].float() - outs[VARS[-1]].float()).abs().max().item()
+    print(f"B={B:2d} h={h:2d} N={N:5d}  {row}  maxdiff {d:.3g}", flush=True)
