@@ -575,24 +575,33 @@ __global__ __launch_bounds__(256) void small_attn_kernel(const half_t* __restric
 
 }  // namespace
 
+// 0: self_attn_kernel<1>, 1: self_attn_kernel<2>, 2: self_attn_sp_kernel (see the measurements in ds_launch_self_attn)
+static int self_attn_choice(int B, int heads, int Nq, int Nk) {
+    const long blocks_sp = (long)((Nq + 255) / 256) * B * heads;
+    if (g_attn_variant == 3 || (g_attn_variant == 0 && blocks_sp >= 1024)) return 2;
+    if (g_attn_variant == 2 || (blocks_sp >= 512 && Nk >= 2048 && g_attn_variant != 1)) return 1;
+    return 0;
+}
+const char* ds_self_attn_kernel_name(int B, int heads, int Nq, int Nk) {
+    static const char* names[] = {"self_attn_kernel<1>", "self_attn_kernel<2>", "self_attn_sp_kernel"};
+    return names[self_attn_choice(B, heads, Nq, Nk)];
+}
+
 int ds_launch_self_attn(const SelfAttnParams& p, hipStream_t stream) {
     DS_REQUIRE(p.B > 0 && p.heads > 0 && p.Nq > 0 && p.Nk > 0, "self_attn: empty problem");
     // any Nk: V^T rows are read 8 keys at a time, so their stride must cover Nk rounded up to 8 (the pad columns may hold
     // anything finite: keys >= Nk are masked to probability 0 on the last tile)
     DS_REQUIRE(p.ldv % 8 == 0 && p.ldv >= (p.Nk + 7) / 8 * 8 && p.ldq % 8 == 0 && p.ldk % 8 == 0 && p.ldo % 4 == 0,
                "self_attn: ld* alignment (Nk=%d ldv=%ld)", p.Nk, p.ldv);
-    // 64 query rows per wave when that still leaves >= 2 blocks per CU; 32 rows per wave otherwise
-    const long blocks2 = (long)((p.Nq + 255) / 256) * p.B * p.heads;
-    // (measured on MI355X: 64-row waves win from N = 4096 up, lose at N = 1024 — profiles/r01_attn_variants.txt)
     // Large grids: the software-pipelined kernel (attention_sp.hip; 256 query rows per block).  Measured on MI355X, interleaved
     // rounds, profiles/r03_self_attn_sp.txt: B = 32, N = 1024 250 vs 276 us; B = 32, N = 4096 1581 vs 1679 us; B = 8, N = 4096 398 vs
     // 422 us; below ~1000 blocks (B = 8, N = 1024: 640 blocks; B = 2) the plain kernels are 2-8 % faster.
-    const long blocks_sp = (long)((p.Nq + 255) / 256) * p.B * p.heads;
-    if (g_attn_variant == 3 || (g_attn_variant == 0 && blocks_sp >= 1024)) return ds_launch_self_attn_sp(p, stream);
-    if (g_attn_variant == 2 || (blocks2 >= 512 && p.Nk >= 2048 && g_attn_variant != 1)) {
-        hipLaunchKernelGGL(self_attn_kernel<2>, dim3((p.Nq + 255) / 256, p.B * p.heads), dim3(256), 0, stream, p);
-    } else {
-        hipLaunchKernelGGL(self_attn_kernel<1>, dim3((p.Nq + 127) / 128, p.B * p.heads), dim3(256), 0, stream, p);
+    // Else 64 query rows per wave when that still leaves >= 2 blocks per CU (wins from N = 4096 up, loses at N = 1024 -
+    // profiles/r01_attn_variants.txt), 32 rows per wave otherwise.
+    switch (self_attn_choice(p.B, p.heads, p.Nq, p.Nk)) {
+        case 2: return ds_launch_self_attn_sp(p, stream);
+        case 1: hipLaunchKernelGGL(self_attn_kernel<2>, dim3((p.Nq + 255) / 256, p.B * p.heads), dim3(256), 0, stream, p); break;
+        default: hipLaunchKernelGGL(self_attn_kernel<1>, dim3((p.Nq + 127) / 128, p.B * p.heads), dim3(256), 0, stream, p); break;
     }
     DS_LAUNCH_CHECK();
     return 0;

@@ -554,7 +554,7 @@ int ds_op_describe(const ds_op* op, char* name, int name_len, double* flops, dou
         case DS_OP_GROUPNORM: nm = "groupnorm(3 kernels)"; by = 2.0 * 2.0 * i[0] * (double)i[1] * (i[2] + i[3]); break;
         case DS_OP_LAYERNORM: nm = "layernorm_kernel"; by = 2.0 * 2.0 * i[0] * (double)i[1]; break;
         case DS_OP_SELF_ATTN:
-            nm = "self_attn_kernel";
+            nm = ds_self_attn_kernel_name(i[0], i[1], i[2], i[3]);
             fl = 4.0 * i[0] * (double)i[1] * i[2] * (double)i[3] * 64;
             by = 2.0 * i[0] * (double)i[1] * 64 * (2.0 * i[2] + 2.0 * i[3]);
             break;

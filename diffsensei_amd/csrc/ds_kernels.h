@@ -21,6 +21,7 @@ struct GemmParams {
     int Hin = 0, Win = 0, Cin = 0, Hout = 0, Wout = 0, cstride = 1, upsample = 0;
     float up_sy = 0.5f, up_sx = 0.5f;  // upsample: nearest-resize scales float(Hin)/Hout, float(Win)/Wout (ATen's definition)
     int tiles_m = 0, tiles_n = 0;
+    int nbatch = 1;  // gemm_pp_kernel only: batch items folded into the persistent tile walk (id -> item, tile); others use grid.z
     int dtype = DS_DTYPE_F16;  // element type of A / W / C / bias / residual (the pointers are 2-byte opaque): bf16 = VAE path
     int debug = 0;  // ablation only (ds_set_option "gemm_debug"): 1 skip MFMA, 2 skip tile loads — results are garbage
 };
@@ -75,7 +76,8 @@ struct SelfAttnParams {
     float scale = 0.125f;
 };
 int ds_launch_self_attn(const SelfAttnParams& p, hipStream_t stream);
-int ds_launch_self_attn_sp(const SelfAttnParams& p, hipStream_t stream);  // attention_sp.hip: software-pipelined variant
+int ds_launch_self_attn_sp(const SelfAttnParams& p, hipStream_t stream);
+const char* ds_self_attn_kernel_name(int B, int heads, int Nq, int Nk);  // which kernel ds_launch_self_attn picks for this shape  // attention_sp.hip: software-pipelined variant
 // attention_fp8.hip: e4m3 variant (k / vt of the params are unused; the quantized operands are passed separately)
 int ds_launch_quantize_fp8(const half_t* x, long ldx, long sx, unsigned char* out, int batch, int rows, int cols,
                            float scale, int permute64, hipStream_t stream);

@@ -669,10 +669,12 @@ Choice choose(const GemmParams& p, int batch) {
         //   * a single partial round: >= 144 tiles with K, N >= 1280 (num_samples 4: 160 tiles, 111 us vs 145 us; 120 tiles
         //     lose: 115 us vs 90 us);
         //   * never the short-K, narrow-N projection (N, K <= 640: +6..20 % for the 128 x 128 kernels).
-        if (batch == 1 && ds_gemm_pp_applicable(p)) {
-            const long t = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
+        // Batched problems (the V^T projections, one GEMM per image with a shared A = Wv): their items are folded into the
+        // kernel's tile walk, so the rules apply to the whole batch (round 3: 20 tiles x 32 images = 2.5 rounds run as 3).
+        if (ds_gemm_pp_applicable(p)) {
+            const long t = (long)((p.M + 255) / 256) * ((p.N + 255) / 256) * batch;
             const long rounds = (t + 255) / 256;
-            const double useful = (double)p.M * p.N / ((double)rounds * 256 * 65536);
+            const double useful = (double)p.M * p.N * batch / ((double)rounds * 256 * 65536);
             const bool multi = t > 256 && (useful >= 0.75 || (p.K >= 4096 && useful >= 0.6));
             const bool single = t >= 144 && t <= 256 && p.K >= 1280 && p.N >= 1280;
             if ((multi || single) && !(p.N <= 640 && p.K <= 640)) {

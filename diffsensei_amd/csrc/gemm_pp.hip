@@ -83,10 +83,13 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int wr = wave >> 2, wc = wave & 3;
-    const long bz = blockIdx.z;
     const int nk = p.K / 64;
     const bool geglu = p.epi == EPI_GEGLU;
-    const int ntiles = p.tiles_m * p.tiles_n;
+    // batched problems (the V^T projections: one GEMM per image, shared A) are folded into the tile walk: logical id ->
+    // (batch item, tile of that item), items outermost - an XCD's chunk of consecutive ids stays inside one or two items and
+    // shares their operand panels; every item's tile order is the plain one
+    const int per_item = p.tiles_m * p.tiles_n;
+    const int ntiles = per_item * p.nbatch;
 
     // ---- persistent tile walk: round-major, then one contiguous chunk of the logical order per XCD (block b runs on
     // XCD b % 8), so the tiles an XCD has in flight share A / W panels in its L2
@@ -121,10 +124,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     const half_t* gA[2];
     const half_t* gB[2];
     int krot = 0;
-    auto set_tile = [&](int id, int& m0, int& n0) {
+    auto set_tile = [&](int id, int& m0, int& n0, int& bz) {
         krot = (id & 31) % nk;
         int tm, tn;
-        tile_coords(id, p.tiles_m, p.tiles_n, tm, tn);
+        bz = p.nbatch > 1 ? id / per_item : 0;
+        tile_coords(id - bz * per_item, p.tiles_m, p.tiles_n, tm, tn);
         if constexpr ((DBG & 32) != 0) tm = tn = 0;  // ablation: every block works on tile (0,0): all operand loads hit L2
         m0 = tm * 256;
         n0 = tn * 256;
@@ -134,8 +138,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
             // re-read the tile's first row - their products are never stored
             const int ra = m0 + h * 128 + wave * 16;
             const int rb = n0 + cb0 + h * cbh;
-            gA[h] = p.A + bz * p.sA + (long)(ra < p.M ? ra : m0) * p.lda;
-            gB[h] = p.W + bz * p.sW + (long)(rb < p.N ? rb : n0) * p.ldw;
+            gA[h] = p.A + (long)bz * p.sA + (long)(ra < p.M ? ra : m0) * p.lda;
+            gB[h] = p.W + (long)bz * p.sW + (long)(rb < p.N ? rb : n0) * p.ldw;
         }
     };
     char* const sdst = smem + wave * 2048;
@@ -308,9 +312,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
         PP_BARRIER();
     };
 
-    T* const Cg = reinterpret_cast<T*>(p.C) + bz * p.sC;
-    const T* const Rg = p.residual ? reinterpret_cast<const T*>(p.residual) + bz * p.sR : nullptr;
-
     int id = tile_local;
     if (id >= ntiles) return;
     unsigned long long probe_c0 = 0, probe_r0 = 0;
@@ -318,8 +319,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
         probe_c0 = __builtin_readcyclecounter();
         probe_r0 = __builtin_amdgcn_s_memrealtime();
     }
-    int m0, n0;
-    set_tile(id, m0, n0);
+    int m0, n0, bz;
+    set_tile(id, m0, n0, bz);
     derive_stage();
     stage_prologue();
     if (p.bias && is_fast(m0, n0)) stage_bias(n0);
@@ -357,6 +358,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
         // (the lane-derived epilogue constants are rebuilt from an opaque copy so they are not kept live - spilled -
         // across the main loop)
         const int cm0 = __builtin_amdgcn_readfirstlane(m0), cn0 = __builtin_amdgcn_readfirstlane(n0);
+        const int cbz = __builtin_amdgcn_readfirstlane(bz);   // this tile's batch item (set_tile below moves on to the next tile's)
+        T* const Cg = reinterpret_cast<T*>(p.C) + (long)cbz * p.sC;
+        const T* const Rg = p.residual ? reinterpret_cast<const T*>(p.residual) + (long)cbz * p.sR : nullptr;
         const int lane_e = lane_id();
         const int l31 = lane_e & 31, lhi = lane_e >> 5;
         // Interior tiles (all of them on the UNet's shapes) take a branch-free epilogue: the generic code below tests
@@ -386,7 +390,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
         id += G;
         const bool more = id < ntiles;
         if (more) {
-            set_tile(id, m0, n0);
+            set_tile(id, m0, n0, bz);
             derive_stage();
             stage_prologue();
         }
@@ -635,7 +639,8 @@ int ds_launch_gemm_pp(const GemmParams& p0, int batch, hipStream_t stream) {
         DS_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         g_pp_blocks = cus > 0 ? cus : 256;
     }
-    const int tiles = p.tiles_m * p.tiles_n;
+    p.nbatch = batch;
+    const int tiles = p.tiles_m * p.tiles_n * batch;
     int nblk = tiles < g_pp_blocks ? tiles : g_pp_blocks;
     if (g_pp_even && tiles > g_pp_blocks) {  // same number of rounds, all of them full, on fewer CUs
         const int rounds = (tiles + g_pp_blocks - 1) / g_pp_blocks;
@@ -643,7 +648,7 @@ int ds_launch_gemm_pp(const GemmParams& p0, int batch, hipStream_t stream) {
         nblk = (nblk + 7) / 8 * 8;           // keep the XCD-chunked tile walk (grid % 8 == 0)
         if (nblk > g_pp_blocks) nblk = g_pp_blocks;
     }
-    dim3 grid(nblk, 1, batch);
+    dim3 grid(nblk, 1, 1);
     kern_t kern = nullptr;
     for (const auto& e : table)
         if (e.dbg == (p.dtype == DS_DTYPE_BF16 ? -1 : (p.debug & 255))) kern = e.k;

@@ -255,6 +255,36 @@ def test_gemm_batched_vt(hip_lib):
     _close(ops.gemm_batched_nt(wv.to(DEV), x.to(DEV)), ref, what="V^T")
 
 
+@pytest.mark.parametrize("B,N,C", [(32, 1024, 1280), (8, 4096, 640), (16, 1024, 1280), (5, 1000, 1280), (3, 272, 384)])
+def test_gemm_batched_vt_pingpong_folded_batch(hip_lib, B, N, C):
+    """Round 3: batched problems (V^T[b] = Wv X_b^T, A shared) are folded into gemm_pp_kernel's persistent tile walk
+    (id -> image, tile).  The UNet's level-2 / level-1 shapes by natural dispatch and forced (gemm_variant 3), incl. a batch
+    whose tiles are not a multiple of the grid and ragged M / N: vs fp32, and bit-identical to the register-staged kernel."""
+    from diffsensei_amd import _lib
+    ops = _ops(hip_lib)
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(B + N + C)
+    x, wv = _r((B, N, C), g).to(DEV), _r((C, C), g, 1 / math.sqrt(C)).to(DEV)
+    ref = torch.einsum("ck,bnk->bcn", wv.float().cpu(), x.float().cpu())
+    out = {}
+    try:
+        for var in (1, 3, 0):
+            assert lib.ds_set_option(b"gemm_variant", var) == 0
+            out[var] = ops.gemm_batched_nt(wv, x).clone()
+    finally:
+        lib.ds_set_option(b"gemm_variant", 0)
+    _close(out[3], ref, what="batched V^T ping-pong")
+    assert torch.equal(out[3], out[1]) and torch.equal(out[0], out[1])
+    # poisoned output buffer: every element of every image is written exactly by its own tile
+    buf = torch.full((B, C, N), float("nan"), dtype=torch.float16, device=DEV)
+    lib.ds_set_option(b"gemm_variant", 3)
+    try:
+        ops.gemm_batched_nt(wv, x, out=buf)
+    finally:
+        lib.ds_set_option(b"gemm_variant", 0)
+    assert torch.equal(buf, out[1])
+
+
 # ------------------------------------------------------------------------------------------------ conv
 @pytest.mark.parametrize("B,H,W,Cin,Cout,stride,up", [(2, 16, 16, 64, 128, 1, False), (1, 32, 24, 128, 64, 1, False),
                                                        (2, 16, 16, 64, 64, 2, False), (2, 8, 12, 128, 128, 1, True),
