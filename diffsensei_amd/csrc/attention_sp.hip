@@ -229,11 +229,12 @@ __global__ __launch_bounds__(256, 2) void self_attn_sp_kernel(const SelfAttnPara
         mx_next = tile_max(Sn);
         // pin this step's results HERE: the packed probabilities are only consumed by the next step's MFMAs, and the
         // compiler otherwise sinks the whole softmax below the branch between the steps - out of this scheduling region
+        // (inputs only: a tied in/out operand made the register allocator copy every packed pair into place - 16 v_mov per step)
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int hb = 0; hb < 2; ++hb) asm volatile("" : "+v"(Pc[kb][hb]));
-        asm volatile("" : "+v"(lsum[qbc]), "+v"(mx_next));
+            for (int hb = 0; hb < 2; ++hb) asm volatile("" ::"v"(Pc[kb][hb]));
+        asm volatile("" ::"v"(lsum[qbc]), "v"(mx_next));
         // issue order: the bias block and two fragments first (the first MFMA needs them), then 16 x {1 MFMA, 1 fragment
         // read, 2 exponentials, 5 other VALU}: the matrix pipe never waits for a block of VALU work
         __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);      // VALU: the 16 bias registers
