@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdiffsensei_hip.so")
+# DIFFSENSEI_LIB: load another build of the SAME library (A/B of compiler flags, tools/gpu_*): never a fallback - it must exist
+LIB_PATH = os.environ.get("DIFFSENSEI_LIB") or os.path.join(_HERE, "lib", "libdiffsensei_hip.so")
 
 vp, i32, i64, f32, sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 

@@ -6,7 +6,7 @@ The reference serves one panel request at a time from a Gradio callback (scripts
 Here the same idea is applied to inference, because one UNet launch plan / hipGraph exists per
 (batch, height, width) and the kernels only reach their throughput on large batches:
 
-    batcher = BucketBatcher(pipe, max_panels=16)
+    batcher = BucketBatcher(pipe)                              # up to 32 panels per UNet batch at 1024 x 1024
     tickets = [batcher.submit(**request_kwargs) for ...]      # the keyword arguments of DiffSenseiPipeline.__call__
     results = batcher.run(output_type="pil")                   # results[ticket] = that request's images
 
@@ -59,7 +59,10 @@ def plan_batches(requests: List[dict], max_panels: int, max_pixels: Optional[int
 class BucketBatcher:
     """Collects requests, then runs them bucket by bucket through `pipe.generate_batch`."""
 
-    def __init__(self, pipe, max_panels: int = 16, max_pixels: Optional[int] = None):
+    def __init__(self, pipe, max_panels: int = 32, max_pixels: Optional[int] = 32 * 1024 * 1024):
+        # defaults = the benchmark's operating point (bench.py: 32 panels of 1024 x 1024 per call = UNet batch 64, where every
+        # projection of the level-2 transformers is a whole number of 256-tile rounds); the pixel cap scales the panel count
+        # down for larger images and lets smaller ones use the full 32
         self.pipe = pipe
         self.max_panels = max_panels
         self.max_pixels = max_pixels
