@@ -72,11 +72,6 @@ int ds_set_option(const char* key, int value) {
         ds_gemm_set_ring(value);
         return 0;
     }
-    if (strcmp(key, "gemm_pp_skew") == 0) {
-        DS_REQUIRE(value >= 0 && value <= 2000, "gemm_pp_skew: 0..2000 (1/1000 of an estimated tile time)");
-        ds_gemm_pp_set_skew(value);
-        return 0;
-    }
     if (strcmp(key, "gemm_pp_even") == 0) {
         ds_gemm_pp_set_even(value);
         return 0;

@@ -21,7 +21,6 @@ struct GemmParams {
     int Hin = 0, Win = 0, Cin = 0, Hout = 0, Wout = 0, cstride = 1, upsample = 0;
     float up_sy = 0.5f, up_sx = 0.5f;  // upsample: nearest-resize scales float(Hin)/Hout, float(Win)/Wout (ATen's definition)
     int tiles_m = 0, tiles_n = 0;
-    int skew_ticks = 0;  // gemm_pp_kernel experiment: blocks on XCDs 4..7 start this many 100-MHz ticks late (de-phases the epilogues)
     int nbatch = 1;  // gemm_pp_kernel only: batch items folded into the persistent tile walk (id -> item, tile); others use grid.z
     int dtype = DS_DTYPE_F16;  // element type of A / W / C / bias / residual (the pointers are 2-byte opaque): bf16 = VAE path
     int debug = 0;  // ablation only (ds_set_option "gemm_debug"): 1 skip MFMA, 2 skip tile loads — results are garbage
@@ -35,7 +34,6 @@ void ds_conv_halo_set_variant(int v);  // 0 auto, 1 8x16-pixel blocks, 2 16x16-p
 const char* ds_gemm_kernel_name(const GemmParams& p, int batch);  // the instantiation ds_launch_gemm dispatches to
 void ds_gemm_set_debug(int v);
 void ds_gemm_set_ring(int v);     // 0 auto (ring-buffered kernel for small grids), 1 never
-void ds_gemm_pp_set_skew(int permille);  // experiment: start skew of XCDs 4..7 in 1/1000 of an estimated tile time (0 = off)
 void ds_gemm_pp_set_even(int v);  // experiment: 1 = persistent grid shrunk so that every round of tiles is full
 void ds_gemm_set_variant(int v);  // 0 auto, 1 register staging only, 2 glds (BM <= 128), 3 glds, BM = 256 when large
 

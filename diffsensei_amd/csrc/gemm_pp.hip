@@ -319,13 +319,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
         probe_c0 = __builtin_readcyclecounter();
         probe_r0 = __builtin_amdgcn_s_memrealtime();
     }
-    if (p.skew_ticks > 0 && (blockIdx.x & 4) != 0) {
-        // experiment (knob "gemm_pp_skew"): every block walks the same number of equally long tiles, so all 256 CUs reach
-        // their epilogues - 128 KiB of C each - within the same few microseconds, round after round.  Half of the XCDs
-        // start late by about half a tile: their store bursts then fall into the other half's main loops.
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)p.skew_ticks) __builtin_amdgcn_s_sleep(16);
-    }
     int m0, n0, bz;
     set_tile(id, m0, n0, bz);
     derive_stage();
@@ -607,12 +600,10 @@ int g_pp_blocks = 0;  // persistent grid size: one block per CU
 // leaves the stragglers' operand panels without the sharers the XCD-chunked walk counts on, and on this power-limited
 // part the idle CUs buy nothing.  Knob "gemm_pp_even" 0 restores one block per CU (A/B).
 int g_pp_even = 1;
-int g_pp_skew = 0;  // 1/1000 of an estimated tile time
 
 }  // namespace
 
 void ds_gemm_pp_set_even(int v) { g_pp_even = v; }
-void ds_gemm_pp_set_skew(int v) { g_pp_skew = v; }
 
 // Shapes the kernel takes: K a multiple of 128 (an even number of k-tiles), a single A source, M and N multiples of 16 (a wave's 16
 // staged rows are then wholly inside or outside the problem).  ds_launch_gemm decides when it is also the faster choice.
@@ -649,9 +640,6 @@ int ds_launch_gemm_pp(const GemmParams& p0, int batch, hipStream_t stream) {
         g_pp_blocks = cus > 0 ? cus : 256;
     }
     p.nbatch = batch;
-    // estimated tile time: 1.2 us per k-tile + 10 us of hand-over (fit of the K = 640 / 1280 shapes, profiles/r03_*), in
-    // 100-MHz ticks, scaled by the knob
-    p.skew_ticks = g_pp_skew > 0 ? (int)((1.2 * (p.K / 64) + 10.0) * 100.0 * g_pp_skew / 1000.0) : 0;
     const int tiles = p.tiles_m * p.tiles_n * batch;
     int nblk = tiles < g_pp_blocks ? tiles : g_pp_blocks;
     if (g_pp_even && tiles > g_pp_blocks) {  // same number of rounds, all of them full, on fewer CUs

@@ -33,8 +33,6 @@ int ds_device_info(int* cu_count, int* lds_bytes, char* arch_name, int arch_name
  * large problem sizes; every variant of an operator computes the same result (the tests assert torch.equal between them).
  *   "gemm_variant"       0 auto | 1 register-staged only | 2, 7 two-buffer LDS-DMA | 8, 9 one-buffer LDS-DMA |
  *                        3 256x256 ping-pong (gemm_pp_kernel) | 10 halo-patch conv
- *   "gemm_pp_skew"       experiment, 0 (default, off) .. 2000: gemm_pp_kernel blocks on XCDs 4..7 start late by this many 1/1000 of an
- *                        estimated tile time, so the two halves of the chip reach their C-store bursts at different times
  *   "gemm_pp_even"       1 (default) gemm_pp_kernel's persistent grid = ceil(tiles / rounds) blocks, every round full |
  *                        0 one block per CU with a partial last round
  *   "gemm_ring"          0 (default) grids of <= 512 64x128 blocks (num_samples 1) use the ring-buffered
