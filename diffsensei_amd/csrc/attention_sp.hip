@@ -143,8 +143,12 @@ __global__ __launch_bounds__(256, 2) void self_attn_sp_kernel(const SelfAttnPara
     // S^T block of one pair: S[kb] = K(kb) Q'^T - m_ref
     auto qk = [&](f32x16 (&S)[2], int qb, unsigned kb_base) {
         f32x16 negm;  // the accumulator input: -m_ref of the lane's query row in all 16 registers (one block, rebuilt per step)
+        const f32x2 nm2 = {-mref[qb], -mref[qb]};
 #pragma unroll
-        for (int r = 0; r < 16; ++r) negm[r] = -mref[qb];
+        for (int r = 0; r < 16; r += 2) {   // pairs: v_pk_mov_b32 moves two registers per instruction
+            negm[r] = nm2[0];
+            negm[r + 1] = nm2[1];
+        }
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -209,23 +213,24 @@ __global__ __launch_bounds__(256, 2) void self_attn_sp_kernel(const SelfAttnPara
         const int qbn = qbc ^ 1;
         qk(Sn, qbn, kb_base);
         pv(Pp, qbn, vb_base);
-        float s0 = 0.f, s1 = 0.f;
+        // row sum, two scores per v_pk_add_f32: 17 fewer VALU per step and the same kernel time as scalar adds (239.6 vs
+        // 239.3 us at B = 32, N = 1024, profiles/r03_self_attn_sp.txt) - the step is not VALU-issue bound any more
+        f32x2 s2 = {0.f, 0.f};
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                const float e0 = fexp2(Sc[kb][r]), e1 = fexp2(Sc[kb][r + 1]);
-                s0 += e0;
-                s1 += e1;
-                Sc[kb][r] = e0;
-                Sc[kb][r + 1] = e1;
+                const f32x2 e = {fexp2(Sc[kb][r]), fexp2(Sc[kb][r + 1])};
+                s2 += e;
+                Sc[kb][r] = e[0];
+                Sc[kb][r + 1] = e[1];
             }
 #pragma unroll
             for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) Pc[kb][hb][e] = (half_t)Sc[kb][hb * 8 + e];
         }
-        lsum[qbc] += s0 + s1;
+        lsum[qbc] += s2[0] + s2[1];
         mx_next = tile_max(Sn);
         // pin this step's results HERE: the packed probabilities are only consumed by the next step's MFMAs, and the
         // compiler otherwise sinks the whole softmax below the branch between the steps - out of this scheduling region
