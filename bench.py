@@ -396,7 +396,7 @@ def main():
                     "algorithmic_tflop_per_forward": round(d["flops"] / 1e12, 3)}
         # HBM-side traffic comes from separate rocprofv3 --pmc passes (tools/gpu_pmc_pp.sh), committed under profiles/:
         # it cannot be collected inside this process.  Attached only when it was measured for this very kernel.
-        for pmc_name in ("r02_pmc_gemm_pp.json", "r01_pmc_gemm_pp.json"):      # newest committed pass for this kernel
+        for pmc_name in ("r03_pmc_gemm_pp.json", "r02_pmc_gemm_pp.json", "r01_pmc_gemm_pp.json"):      # newest committed pass for this kernel
             pmc_path = os.path.join(ROOT, "profiles", pmc_name)
             if not os.path.exists(pmc_path):
                 continue
