@@ -578,7 +578,7 @@ __global__ __launch_bounds__(256) void small_attn_kernel(const half_t* __restric
 // 0: self_attn_kernel<1>, 1: self_attn_kernel<2>, 2: self_attn_sp_kernel (see the measurements in ds_launch_self_attn)
 static int self_attn_choice(int B, int heads, int Nq, int Nk) {
     const long blocks_sp = (long)((Nq + 255) / 256) * B * heads;
-    if (g_attn_variant == 3 || (g_attn_variant == 0 && blocks_sp >= 1024)) return 2;
+    if (g_attn_variant >= 3 || (g_attn_variant == 0 && blocks_sp >= 1024)) return 2;
     if (g_attn_variant == 2 || (blocks_sp >= 512 && Nk >= 2048 && g_attn_variant != 1)) return 1;
     return 0;
 }
@@ -599,7 +599,11 @@ int ds_launch_self_attn(const SelfAttnParams& p, hipStream_t stream) {
     // Else 64 query rows per wave when that still leaves >= 2 blocks per CU (wins from N = 4096 up, loses at N = 1024 -
     // profiles/r01_attn_variants.txt), 32 rows per wave otherwise.
     switch (self_attn_choice(p.B, p.heads, p.Nq, p.Nk)) {
-        case 2: return ds_launch_self_attn_sp(p, stream);
+        case 2: {
+            SelfAttnParams q = p;
+            q.xcd_map = g_attn_variant == 4 ? 0 : 1;   // 4: A/B only - the plain block order
+            return ds_launch_self_attn_sp(q, stream);
+        }
         case 1: hipLaunchKernelGGL(self_attn_kernel<2>, dim3((p.Nq + 255) / 256, p.B * p.heads), dim3(256), 0, stream, p); break;
         default: hipLaunchKernelGGL(self_attn_kernel<1>, dim3((p.Nq + 127) / 128, p.B * p.heads), dim3(256), 0, stream, p); break;
     }

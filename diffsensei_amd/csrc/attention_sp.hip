@@ -68,8 +68,15 @@ __global__ __launch_bounds__(256, 2) void self_attn_sp_kernel(const SelfAttnPara
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lhi = lane >> 5;
-    const int b = blockIdx.y / p.heads, h = blockIdx.y % p.heads;
-    const int q0 = blockIdx.x * 256 + wave * 64;
+    // Block -> (head, query block): the dispatcher places block i on XCD i % 8.  With the plain (query block, head) grid the 16
+    // query blocks of one head were spread over all eight XCDs and every one of them pulled that head's K / V^T through its own
+    // L2: 2.85 GB of fabric reads per launch for 0.17 GB of K + V (PMC, profiles/r03_pmc_conv_attn_ip_summary.txt).  The 1-D
+    // grid is remapped so that an XCD owns a contiguous run of work items = all query blocks of a few heads, back to back.
+    const int nqb = (p.Nq + 255) / 256;
+    const int item = p.xcd_map ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+    const int bh = item / nqb, qblk = item - bh * nqb;
+    const int b = bh / p.heads, h = bh % p.heads;
+    const int q0 = qblk * 256 + wave * 64;
     const int nt = (p.Nk + 63) / 64;
     const bool ragged = (p.Nk & 63) != 0;
 
@@ -309,7 +316,7 @@ __global__ __launch_bounds__(256, 2) void self_attn_sp_kernel(const SelfAttnPara
 }  // namespace
 
 int ds_launch_self_attn_sp(const SelfAttnParams& p, hipStream_t stream) {
-    hipLaunchKernelGGL(self_attn_sp_kernel, dim3((p.Nq + 255) / 256, p.B * p.heads), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(self_attn_sp_kernel, dim3(((p.Nq + 255) / 256) * p.B * p.heads), dim3(256), 0, stream, p);
     DS_LAUNCH_CHECK();
     return 0;
 }

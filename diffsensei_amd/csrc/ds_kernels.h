@@ -74,6 +74,7 @@ struct SelfAttnParams {
     long sq = 0, sk = 0, so = 0;  // per-batch strides (elements)
     int B = 0, heads = 0, Nq = 0, Nk = 0;
     float scale = 0.125f;
+    int xcd_map = 1;  // self_attn_sp_kernel: 1 = all query blocks of a head on one XCD (0: plain order, A/B via attn_variant 4)
 };
 int ds_launch_self_attn(const SelfAttnParams& p, hipStream_t stream);
 int ds_launch_self_attn_sp(const SelfAttnParams& p, hipStream_t stream);

@@ -41,7 +41,8 @@ int ds_device_info(int* cu_count, int* lds_bytes, char* arch_name, int arch_name
  *                        2 force conv_halo256_kernel (16x16 pixels)
  *   "attn_variant"       0 auto (>= 1024 blocks of 256 query rows: the software-pipelined self_attn_sp_kernel; else 64 query
  *                        rows per wave from Nk >= 2048 and >= 512 blocks on) | 1 force self_attn_kernel<1> (32 rows per wave) |
- *                        2 force self_attn_kernel<2> (64 rows per wave) | 3 force self_attn_sp_kernel
+ *                        2 force self_attn_kernel<2> (64 rows per wave) | 3 force self_attn_sp_kernel | 4 the same with the
+ *                        plain block order instead of the per-XCD head grouping (A/B: profiles/r03_self_attn_sp.txt)
  *   "ip_attn_min_blocks" grid size below which ip_attn_kernel stops doubling its query tiles per block (default 1024)
  *   "llm_gemv_variant"   0 auto (software-pipelined persistent GEMV) | 1 one column per wavefront | 2 un-pipelined streaming GEMV
  *   "gemm_debug"         bits 0..7: ablation builds of gemm_pp_kernel (only in a library built with -DDS_ABLATION; 0 otherwise) |
