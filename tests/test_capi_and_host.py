@@ -193,13 +193,14 @@ def test_committed_bench_line_follows_the_contract():
     """The round-end bench line kept under profiles/ carries every key the driver's contract names."""
     import json
     import os
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r02_bench_default_ns16_final.json")
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r03_bench_default_ns32_final.json")
     line = json.loads(open(path).read().strip().splitlines()[-1])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "parity"):
         assert k in line, k
-    par = line["parity"]            # the GPU repeated the CPU oracle's configs[0] steps from the same weights / latents
-    assert par["rel_l2"] <= par["tolerance"] <= 3e-2 and par["steps"] >= 2 and "512x512" in par["config"]
+    par = line["parity"]            # the SAME whole call (prompt strings -> uint8 image) on the GPU and on the fp32 CPU oracle
+    assert par["path"] == "__call__" and par["rel_l2"] <= par["tolerance"] <= 3e-2 and par["steps"] >= 2 and "512x512" in par["config"]
+    assert par["image_rel_l2"] <= par["image_tolerance"] <= 5e-2 and 0 <= par["u8_frac_gt_1lsb"] <= 0.05 and par["u8_max_diff"] <= 8
     assert line["config"]["output"] == "pil"
     assert line["unit"] == "panels/s" and line["higher_is_better"] is True and line["scaling"] == "weak"
     assert "workload" in line["config"] and "model" not in line["config"]
