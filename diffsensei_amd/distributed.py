@@ -58,12 +58,15 @@ class WeightArena:
 
     def __init__(self, tensors: Sequence[Tensor]):
         self.buffers: Dict[Tuple[torch.device, torch.dtype], Tensor] = {}
-        self.loose: List[Tensor] = []          # not contiguous: left where they are, broadcast one by one
+        self.loose: List[Tensor] = []          # not contiguous, or views of a larger storage: left where they are, broadcast one by one
         groups: Dict[Tuple[torch.device, torch.dtype], List[Tensor]] = {}
         seen: Dict[Tuple[int, int, Tuple[int, ...]], Tensor] = {}
         self._alias: List[Tuple[Tensor, Tensor]] = []
         for t in tensors:
-            if not t.is_contiguous():
+            # only tensors that OWN their storage move: a view into a larger tensor (a slice of a packed weight) must keep
+            # aliasing its base - the in-place broadcast into it updates the base as before
+            owns = t.storage_offset() == 0 and t.untyped_storage().nbytes() == t.numel() * t.element_size()
+            if not t.is_contiguous() or not owns:
                 self.loose.append(t)
                 continue
             key = (t.data_ptr(), t.numel() * t.element_size(), tuple(t.shape))

@@ -244,12 +244,17 @@ def test_weight_arena_rehomes_tensors_in_place():
     ts += [torch.arange(6, dtype=torch.float32), torch.randn(3, 3, generator=g)]
     shared = ts[1]
     odd = torch.randn(8, 6, generator=g).half().t()               # not contiguous
-    lst = ts + [shared, odd]
+    base = torch.randn(3, 16, 16, generator=g).half()             # a packed weight ...
+    view = base[1]                                                # ... and a slice of it that an engine lists: must keep aliasing
+    lst = ts + [shared, odd, view]
     before = [t.clone() for t in lst]
     ids = [id(t) for t in lst]
     arena = WeightArena(lst)
     assert [id(t) for t in lst] == ids and all(torch.equal(a, b) for a, b in zip(lst, before))
-    assert set(k[1] for k in arena.buffers) == {torch.float16, torch.float32} and arena.loose == [odd]
+    assert set(k[1] for k in arena.buffers) == {torch.float16, torch.float32} and len(arena.loose) == 2
+    assert arena.loose[0] is odd and arena.loose[1] is view and view.data_ptr() == base[1].data_ptr()
+    view.fill_(7.0)
+    assert float(base[1].float().mean()) == 7.0                   # still a window onto the packed weight
     f16 = next(v for k, v in arena.buffers.items() if k[1] == torch.float16)
     lo, hi = f16.data_ptr(), f16.data_ptr() + f16.numel() * 2
     for t in ts[:4]:
@@ -259,4 +264,4 @@ def test_weight_arena_rehomes_tensors_in_place():
     f16.zero_()
     assert all(float(t.abs().sum()) == 0 for t in ts[:4]) and float(ts[4].sum()) == 15.0
     sl = arena.slices(1 << 10)
-    assert sum(x.numel() * x.element_size() for x in sl if x is not odd) == arena.bytes and sl[-1] is odd
+    assert sum(x.numel() * x.element_size() for x in sl[:-2]) == arena.bytes and sl[-2] is odd and sl[-1] is view
