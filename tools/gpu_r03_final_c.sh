@@ -1,0 +1,14 @@
+#!/usr/bin/env bash
+# Round 3 evidence run, part C (final tree): build, whole GPU suite, smoke, the default bench line once more.
+set -u
+out=gpurun_out
+mkdir -p "$out"
+export TMPDIR=/tmp
+python -c "import __graft_entry__ as g; g.build()" 2>&1 | tail -1
+timeout 1500 python -m pytest tests -m gpu -q 2>&1 | grep -v "^\[transformers\]" > "$out/r03_final_pytest_gpu.log"
+echo "pytest rc=$? $(grep -a 'passed\|failed' $out/r03_final_pytest_gpu.log | tail -1)"
+grep -a "FAILED\|ERROR" "$out/r03_final_pytest_gpu.log" | head -20
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v "^\[transformers\]" | tail -1
+timeout 1200 python bench.py > "$out/r03_bench_default_ns32_final2.json" 2> "$out/r03_bench_default_ns32_final2.err"
+echo "bench default rc=$?"; tail -1 "$out/r03_bench_default_ns32_final2.json" | cut -c1-200
+grep -a "^parity" "$out/r03_bench_default_ns32_final2.err" | cut -c1-500
