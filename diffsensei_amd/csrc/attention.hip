@@ -340,18 +340,6 @@ __global__ __launch_bounds__(256, 2) void ip_attn_kernel(const IPAttnParams p, i
             for (int c4 = 0; c4 < 4; ++c4) box[k][c4] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bv[c4]), k));
     }
     const float ip_scale = p.ip_scale_ptr ? *p.ip_scale_ptr : p.ip_scale;
-    // The model's token layout (16 dummy + 4 x 16 character tokens) makes a 16-key group of the IP panel open or closed as a
-    // whole for a query row: group g belongs to the dummy tokens (gk = -1), to character gk[g], or to nobody (padding, 99).
-    // Six scalars, computed once - the per-tile work is then six selects instead of building a 96-bit key set per row
-    // (five ranges x three words of shifts and masks: ~120 of the kernel's ~850 VALU instructions per query tile, PMC round 3).
-    const bool fastg = (p.n_dummy % 16 == 0) && (p.tok_per_ip % 16 == 0) && p.Li > 64;   // wave-uniform
-    int gk[6];
-#pragma unroll
-    for (int g = 0; g < 6; ++g) {
-        const int a = p.n_dummy >> 4, per = max(p.tok_per_ip >> 4, 1);
-        const int k = g < a ? -1 : (g - a) / per;
-        gk[g] = __builtin_amdgcn_readfirstlane(k < p.max_ips ? k : 99);
-    }
     for (int it = 0; it < qt; ++it) {
         const int q0 = (blockIdx.x * qt + it) * 128 + wave * 32;
         if (q0 >= p.N) break;  // wave-uniform
@@ -371,14 +359,7 @@ __global__ __launch_bounds__(256, 2) void ip_attn_kernel(const IPAttnParams p, i
         // 96-bit "attendable IP key" set of this query row: dummy keys [0, n_dummy) iff the token lies in NO box,
         // character k's keys [n_dummy + k*tpi, +tpi) iff it lies in box k  (reference :155-163)
         unsigned open_ip[3] = {0u, 0u, 0u};
-        unsigned gopen = 0u;  // fastg: bit g set <=> 16-key group g of the IP panel is attendable for this row
-        if (fastg) {
-#pragma unroll
-            for (int g = 0; g < 6; ++g) {
-                const bool o = gk[g] < 0 ? inside == 0u : (gk[g] < 8 && ((inside >> gk[g]) & 1u) != 0u);
-                gopen |= (unsigned)o << g;
-            }
-        } else {
+        {
             auto set_range = [&](int lo, int hi) {  // bits [lo, hi) of the 96-bit set
 #pragma unroll
                 for (int w = 0; w < 3; ++w) {
@@ -405,8 +386,7 @@ __global__ __launch_bounds__(256, 2) void ip_attn_kernel(const IPAttnParams p, i
         bool act_ip[3];
 #pragma unroll
         for (int kb = 0; kb < 3; ++kb)
-            act_ip[kb] = p.n_dummy == 0 ||
-                         __builtin_amdgcn_ballot_w64(fastg ? ((gopen >> (2 * kb)) & 3u) != 0u : open_ip[kb] != 0u) != 0;
+            act_ip[kb] = p.n_dummy == 0 || __builtin_amdgcn_ballot_w64(open_ip[kb] != 0u) != 0;
 #pragma unroll
         for (int part = 0; part < 2; ++part) {  // 0: text keys, 1: IP keys
             const char* sK = part ? sKi : sKt;
@@ -437,7 +417,7 @@ __global__ __launch_bounds__(256, 2) void ip_attn_kernel(const IPAttnParams p, i
                 float gb[6];
 #pragma unroll
                 for (int g = 0; g < 6; ++g)
-                    gb[g] = (part && !(((fastg ? gopen >> g : open_ip[g >> 1] >> ((g & 1) * 16))) & 1u)) ? -10000.0f : 0.0f;
+                    gb[g] = (part && !((open_ip[g >> 1] >> ((g & 1) * 16)) & 1u)) ? -10000.0f : 0.0f;
                 const f32x2 sc2 = {p.qk_scale, p.qk_scale};
 #pragma unroll
                 for (int kb = 0; kb < 3; ++kb) {
