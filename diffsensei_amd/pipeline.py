@@ -482,6 +482,7 @@ class DiffSenseiPipeline:
         seeds and `num_samples` are per request.  Returns one `.images`-like object per request, in order."""
         if not requests:
             return []
+        self._interrupt = False          # like `__call__` (reference :226): an earlier interrupted call must not leak into this one
         key = lambda r: (r.get("height"), r.get("width"), r.get("num_inference_steps", 40), r.get("guidance_scale", 5.0),
                          r.get("ip_scale", 1.0))
         if any(key(r) != key(requests[0]) for r in requests):

@@ -77,6 +77,11 @@ def test_call_prompt_to_pil_vs_call_oracle(hip_lib):
     # a later un-interrupted call runs all steps again (the flag is reset at entry like reference :226)
     full = pipe(latents=lat0.clone(), ip_images=list(imgs), num_samples=ns, output_type="latent", **req).images
     assert not pipe.interrupt and not torch.equal(full, outs[True][0])
+    # ... and neither does `generate_batch` inherit the flag of an interrupted `__call__`
+    pipe(latents=lat0.clone(), ip_images=list(imgs), num_samples=ns, output_type="latent", callback_on_step_end=stop, **req)
+    assert pipe.interrupt
+    batch = pipe.generate_batch([dict(req, latents=lat0.clone(), ip_images=list(imgs), num_samples=ns)], output_type="latent")[0]
+    assert not pipe.interrupt and torch.equal(batch, full)
     lat, u8 = outs[True]
     rl = ref["latents"]
     e_lat = ((lat.float().cpu() - rl).norm() / rl.norm()).item()
