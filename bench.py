@@ -98,7 +98,7 @@ def build_pipeline(device, num_gpus, rank, seed=0, with_vae=True, agent=None, ke
     with torch.device("cpu"):
         te1 = ClipTextEngine.from_transformers(cpu_module("text_encoder", CLIPTextModel(t1)), device)
         te2 = ClipTextEngine.from_transformers(cpu_module("text_encoder_2", CLIPTextModelWithProjection(t2)), device)
-    # SDXL VAE decoder (49.5 M parameters) at its true shapes, random init, bf16 HIP engine
+    # SDXL VAE decoder (49.5 M parameters) at its true shapes, random init (scaled-fp16 HIP engine unless DIFFSENSEI_VAE_PRECISION says bf16)
     from diffsensei_amd.vae import VaeConfig, VaeDecoderEngine
     vae = VaeDecoderEngine.init_random(VaeConfig(), seed + 2, device) if with_vae else None
     t_init = time.perf_counter() - t0
@@ -401,7 +401,9 @@ def main():
             if not os.path.exists(pmc_path):
                 continue
             pmc = json.load(open(pmc_path))
-            if pmc.get("kernel") == name:
+            # ... and for a launch this workload issues: the pass measured the GEGLU projection of the 32x32-token level at one
+            # UNet batch (M = batch x 1024 tokens), so other --num-samples / --size settings leave traffic null.
+            if pmc.get("kernel") == name and pmc["shape"].get("M") == 2 * ns * (args.size // 32) ** 2:
                 roofline["traffic"] = pmc["traffic_bytes_per_launch"]
                 roofline["traffic_detail"] = {"unit": "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, L2 fabric side)",
                                               "launch": pmc["shape"], "algorithmic_bytes": pmc["algorithmic_bytes_per_launch"],
@@ -441,7 +443,7 @@ def main():
                        "timed_region": "2 SDXL text encoders (prompt + negative prompt), CLIP-H + ViT-MAE + Resampler "
                                        "character encoding, 50 x (UNet + CFG + scheduler step)" +
                                        ("; VAE decode excluded (output: latents)" if args.no_vae else
-                                        ", SDXL VAE decode + denormalize (bf16 HIP engine)" +
+                                        f", SDXL VAE decode + denormalize ({pipe.vae.precision} HIP engine)" +
                                         ("; uint8 conversion on the device, D2H, PIL images on the host (reference :367)"
                                          if out_type == "pil" else "; output: [0,1] fp32 images on the device")),
                        "mllm_prepass": ("LLaMA-2-13B dims, 111-token prompt + 66 new tokens (64-token image block), both "
