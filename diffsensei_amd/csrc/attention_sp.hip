@@ -80,23 +80,6 @@ __global__ __launch_bounds__(256, 2) void self_attn_sp_kernel(const SelfAttnPara
     const int nt = (p.Nk + 63) / 64;
     const bool ragged = (p.Nk & 63) != 0;
 
-    // ---- Q fragments (B operand of S^T), pre-multiplied by scale * log2(e): scores arrive as base-2 logits
-    h8 qf[2][4];
-    {
-        const float c = p.scale * LOG2E;
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
-            const int qrow = min(q0 + qb * 32 + l31, p.Nq - 1);
-            const half_t* qp = p.q + (long)b * p.sq + (long)qrow * p.ldq + h * 64 + lhi * 8;
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const h8 v = *reinterpret_cast<const h8*>(qp + kk * 16);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) qf[qb][kk][e] = (half_t)((float)v[e] * c);
-            }
-        }
-    }
-
     // ---- LDS-DMA staging: per tile and operand two 4-KiB instructions; wave w, piece j covers tile rows (4 j + w) * 8 .. + 7
     const half_t* const kbase = p.k + (long)b * p.sk + h * 64;
     const half_t* const vbase = p.vt + ((long)(b * p.heads + h) * 64) * p.ldv;
@@ -121,6 +104,28 @@ __global__ __launch_bounds__(256, 2) void self_attn_sp_kernel(const SelfAttnPara
                                              (lds_void*)(smem + V_BASE + buf * TILE_B + (4 * j + wave) * 1024), 16, 0, 0);
         }
     };
+
+    // ---- prologue, part 1: K(0), V(0), K(1) are requested BEFORE the Q rows, so the two round trips overlap
+    issue_k(0, 0);
+    issue_v(0, 0);
+    if (nt > 1) issue_k(1, 1);
+
+    // ---- Q fragments (B operand of S^T), pre-multiplied by scale * log2(e): scores arrive as base-2 logits
+    h8 qf[2][4];
+    {
+        const float c = p.scale * LOG2E;
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            const int qrow = min(q0 + qb * 32 + l31, p.Nq - 1);
+            const half_t* qp = p.q + (long)b * p.sq + (long)qrow * p.ldq + h * 64 + lhi * 8;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const h8 v = *reinterpret_cast<const h8*>(qp + kk * 16);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) qf[qb][kk][e] = (half_t)((float)v[e] * c);
+            }
+        }
+    }
 
     // ---- fragment addresses (bytes into smem, without the ring-buffer base)
     unsigned koff[4], voff[4];
@@ -260,10 +265,7 @@ __global__ __launch_bounds__(256, 2) void self_attn_sp_kernel(const SelfAttnPara
         }
     };
 
-    // ---- prologue: K(0), V(0), K(1); scores of pair (0, qb 0)
-    issue_k(0, 0);
-    issue_v(0, 0);
-    if (nt > 1) issue_k(1, 1);
+    // ---- prologue, part 2: scores of pair (0, qb 0)
     SP_SYNC();
     qk(S0, 0, 0u);
     float mx0 = cross_max(tile_max(S0)), mx1 = 0.f;

@@ -104,37 +104,54 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GroupNormParams p) {
     }
 }
 
-// one block per batch item; wave w handles groups w, w+4, ...
+// one block per (batch item, group): 256 lanes walk the group's nchunks x cpg partial pairs, four independent 8-byte loads
+// in flight per lane (one wave per group with one load in flight took 35 us per launch - 80 dependent round trips - whatever
+// the batch: 5 % of a batch-2 forward)
 template <typename T>
 __global__ __launch_bounds__(256) void gn_finalize_kernel(GroupNormParams p, int nchunks) {
+    __shared__ float red[8];
     const int C = p.C1 + p.C2;
-    const int b = blockIdx.x;
+    const int b = blockIdx.x, g = blockIdx.y;
     const int cpg = C / p.groups;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float* part = p.ws + (long)b * nchunks * C * 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* part = p.ws + (long)b * nchunks * C * 2 + (long)g * cpg * 2;
     float* tabA = p.ws + (long)gridDim.x * nchunks * C * 2 + (long)b * C * 2;
     float* tabS = tabA + C;
     const float inv_n = 1.0f / ((float)cpg * (float)p.HW);
-    for (int g = blockIdx.y * 4 + wave; g < p.groups; g += 4 * gridDim.y) {
-        float s = 0.f, ss = 0.f;
-        const int items = nchunks * cpg;
-        for (int i = lane; i < items; i += 64) {
-            const int ch = i / cpg, cc = i - ch * cpg;
-            const float* q = part + ((long)ch * C + g * cpg + cc) * 2;
-            s += q[0];
-            ss += q[1];
-        }
-        s = wave_sum(s);
-        ss = wave_sum(ss);
-        const float mean = s * inv_n;
-        const float var = fmaxf(ss * inv_n - mean * mean, 0.f);
-        const float rstd = rsqrtf(var + p.eps);
-        for (int cc = lane; cc < cpg; cc += 64) {
-            const int c = g * cpg + cc;
-            const float a = rstd * (float)reinterpret_cast<const T*>(p.gamma)[c];
-            tabA[c] = a;
-            tabS[c] = (float)reinterpret_cast<const T*>(p.beta)[c] - mean * a;
-        }
+    const int items = nchunks * cpg;
+    auto at = [&](int i) {
+        const int ch = i / cpg, cc = i - ch * cpg;
+        return *reinterpret_cast<const f32x2*>(part + ((long)ch * C + cc) * 2);
+    };
+    float s = 0.f, ss = 0.f;
+    int i = tid;
+    for (; i + 768 < items; i += 1024) {
+        const f32x2 q0 = at(i), q1 = at(i + 256), q2 = at(i + 512), q3 = at(i + 768);
+        s += (q0[0] + q1[0]) + (q2[0] + q3[0]);
+        ss += (q0[1] + q1[1]) + (q2[1] + q3[1]);
+    }
+    for (; i < items; i += 256) {
+        const f32x2 q = at(i);
+        s += q[0];
+        ss += q[1];
+    }
+    s = wave_sum(s);
+    ss = wave_sum(ss);
+    if (lane == 0) {
+        red[wave] = s;
+        red[4 + wave] = ss;
+    }
+    __syncthreads();
+    s = (red[0] + red[1]) + (red[2] + red[3]);
+    ss = (red[4] + red[5]) + (red[6] + red[7]);
+    const float mean = s * inv_n;
+    const float var = fmaxf(ss * inv_n - mean * mean, 0.f);
+    const float rstd = rsqrtf(var + p.eps);
+    for (int cc = tid; cc < cpg; cc += 256) {
+        const int c = g * cpg + cc;
+        const float a = rstd * (float)reinterpret_cast<const T*>(p.gamma)[c];
+        tabA[c] = a;
+        tabS[c] = (float)reinterpret_cast<const T*>(p.beta)[c] - mean * a;
     }
 }
 
@@ -253,11 +270,11 @@ int ds_launch_groupnorm(const GroupNormParams& p, hipStream_t stream) {
     dim3 grid(nslab, nch, p.B);
     if (p.dtype == DS_DTYPE_BF16) {
         hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, grid, dim3(256), 0, stream, p);
-        hipLaunchKernelGGL(gn_finalize_kernel<bf16_t>, dim3(p.B, (p.groups + 3) / 4), dim3(256), 0, stream, p, nch);
+        hipLaunchKernelGGL(gn_finalize_kernel<bf16_t>, dim3(p.B, p.groups), dim3(256), 0, stream, p, nch);
         hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, grid, dim3(256), 0, stream, p, nch);
     } else {
         hipLaunchKernelGGL(gn_stats_kernel<half_t>, grid, dim3(256), 0, stream, p);
-        hipLaunchKernelGGL(gn_finalize_kernel<half_t>, dim3(p.B, (p.groups + 3) / 4), dim3(256), 0, stream, p, nch);
+        hipLaunchKernelGGL(gn_finalize_kernel<half_t>, dim3(p.B, p.groups), dim3(256), 0, stream, p, nch);
         hipLaunchKernelGGL(gn_apply_kernel<half_t>, grid, dim3(256), 0, stream, p, nch);
     }
     DS_LAUNCH_CHECK();
