@@ -28,6 +28,10 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # RCCL shares device buffers between the ranks of a node through dmabuf IPC; the legacy IPC mode fails on hosts whose
+    # driver only supports dmabuf (hipIpcGetMemHandle: invalid argument).  Read when the HSA runtime starts, i.e. at the
+    # first device call below - a value the launcher already exported is left alone.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     # test hooks (a 1-GPU box can still drive the N > 1 control flow): DS_DIST_BACKEND overrides the backend (gloo moves
     # CUDA tensors through the host), DS_FORCE_DEVICE pins every rank to one device index
     backend = os.environ.get("DS_DIST_BACKEND", backend)
