@@ -245,54 +245,60 @@ __global__ __launch_bounds__(256) void vae_conv_in_kernel(const float* __restric
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// conv_out: 3x3, C -> 3, NHWC T in, fp32 NCHW image out.  One thread per output pixel, weights broadcast from LDS.
+// conv_out: 3x3, C -> 3, NHWC T in, fp32 NCHW image out.  Eight lanes per output pixel: lane s takes the 16-byte channel chunks
+// s, s + 8, ... of every tap, so a wave reads 8 adjacent pixels x 128 contiguous bytes per instruction, and the three sums are
+// folded over the 8 lanes at the end.  (Round 1-2 had one THREAD per pixel: 2.3 KiB of 256-byte-strided reads and three
+// dependent chains of 1152 FMAs each - 2.4 ms per 1024 x 1024 image for 0.27 GB of input, 9.6 ms per launch of four images in
+// profiles/r03_rocprof_kernel_stats/.)  fp32 accumulation as before; the weight panel sits in LDS in its storage type.
 // ---------------------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void vae_conv_out_kernel(const T* __restrict__ x, const T* __restrict__ w,
                                                            const T* __restrict__ bias, float* __restrict__ img, int B,
                                                            int H, int W, int C, int denorm) {
     typedef typename Elt<T>::v8 V8;
-    extern __shared__ float sw[];  // [3][9][C]
-    for (int i = threadIdx.x; i < 27 * C; i += 256) sw[i] = (float)w[i];
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T* sw = reinterpret_cast<T*>(smem_raw);  // [3][9][C]
+    for (int i = threadIdx.x; i < 27 * C / 8; i += 256) reinterpret_cast<V8*>(sw)[i] = reinterpret_cast<const V8*>(w)[i];
     __syncthreads();
-    // 8 x 32 pixel tiles: neighbouring lanes read neighbouring pixels, rows of a tile share cache lines across taps
-    const int tiles_x = (W + 31) / 32;
-    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, b = blockIdx.y;
-    const int ox = tx * 32 + (threadIdx.x & 31), oy = ty * 8 + (threadIdx.x >> 5);
-    if (ox >= W || oy >= H) return;
-    float a0 = (float)bias[0], a1 = (float)bias[1], a2 = (float)bias[2];
-    for (int ky = 0; ky < 3; ++ky) {
-        const int iy = oy + ky - 1;
-        if (iy < 0 || iy >= H) continue;
-        for (int kx = 0; kx < 3; ++kx) {
-            const int ix = ox + kx - 1;
-            if (ix < 0 || ix >= W) continue;
+    const int sub = threadIdx.x & 7;
+    const long plane = (long)H * W, npix = (long)B * plane;
+    const float bsel = (float)bias[sub < 3 ? sub : 0];
+    // grid-stride over groups of 32 pixels (consecutive along x): the weight panel is staged once per resident block
+    for (long pix0 = (long)blockIdx.x * 32; pix0 < npix; pix0 += (long)gridDim.x * 32) {
+        const long pix = pix0 + (threadIdx.x >> 3);
+        const bool live = pix < npix;
+        const long pc = live ? pix : 0;
+        const int b = (int)(pc / plane);
+        const int rem = (int)(pc - (long)b * plane);
+        const int oy = rem / W, ox = rem - oy * W;
+        float acc[3] = {0.f, 0.f, 0.f};
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            const int iy = oy + ky - 1, ix = ox + kx - 1;
+            if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
             const T* xp = x + (((long)b * H + iy) * W + ix) * C;
-            const float* w0 = sw + (0 * 9 + ky * 3 + kx) * C;
-            const float* w1 = sw + (1 * 9 + ky * 3 + kx) * C;
-            const float* w2 = sw + (2 * 9 + ky * 3 + kx) * C;
-            for (int c8 = 0; c8 < C; c8 += 8) {
-                const V8 v = *reinterpret_cast<const V8*>(xp + c8);
+            for (int c = sub * 8; c < C; c += 64) {
+                const V8 xv = *reinterpret_cast<const V8*>(xp + c);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float f = (float)v[e];
-                    a0 = fmaf(f, w0[c8 + e], a0);
-                    a1 = fmaf(f, w1[c8 + e], a1);
-                    a2 = fmaf(f, w2[c8 + e], a2);
+                for (int co = 0; co < 3; ++co) {
+                    const V8 wv = *reinterpret_cast<const V8*>(sw + (co * 9 + tap) * C + c);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[co] = fmaf((float)xv[e], (float)wv[e], acc[co]);
                 }
             }
         }
+#pragma unroll
+        for (int co = 0; co < 3; ++co) {
+            acc[co] += __shfl_xor(acc[co], 1, 64);
+            acc[co] += __shfl_xor(acc[co], 2, 64);
+            acc[co] += __shfl_xor(acc[co], 4, 64);
+        }
+        if (live && sub < 3) {  // lanes 0..2 of the pixel's group write the three colour planes
+            float v = (sub == 0 ? acc[0] : sub == 1 ? acc[1] : acc[2]) + bsel;
+            if (denorm) v = fminf(fmaxf(v * 0.5f + 0.5f, 0.f), 1.f);  // VaeImageProcessor.denormalize: (x / 2 + 0.5).clamp(0, 1)
+            img[((long)b * 3 + sub) * plane + rem] = v;
+        }
     }
-    const long plane = (long)H * W;
-    float* op = img + (long)b * 3 * plane + (long)oy * W + ox;
-    if (denorm) {  // VaeImageProcessor.denormalize: (x / 2 + 0.5).clamp(0, 1)
-        a0 = fminf(fmaxf(a0 * 0.5f + 0.5f, 0.f), 1.f);
-        a1 = fminf(fmaxf(a1 * 0.5f + 0.5f, 0.f), 1.f);
-        a2 = fminf(fmaxf(a2 * 0.5f + 0.5f, 0.f), 1.f);
-    }
-    op[0] = a0;
-    op[plane] = a1;
-    op[2 * plane] = a2;
 }
 
 }  // namespace
@@ -352,9 +358,10 @@ int ds_launch_vae_conv_in(const float* lat, const float* wpq, const float* bpq, 
 int ds_launch_vae_conv_out(const void* x, const void* w, const void* bias, float* img, int B, int H, int W, int C,
                            int denorm, int dtype, hipStream_t stream) {
     DS_REQUIRE(C % 8 == 0 && C > 0, "vae_conv_out: C (%d) must be a multiple of 8", C);
-    const size_t lds = (size_t)27 * C * sizeof(float);
+    const size_t lds = (size_t)27 * C * 2;
     DS_REQUIRE(lds <= 64 * 1024, "vae_conv_out: weights (%zu B) exceed 64 KiB of LDS", lds);
-    dim3 grid(((W + 31) / 32) * ((H + 7) / 8), B);
+    const long groups = ((long)B * H * W + 31) / 32;
+    dim3 grid((unsigned)(groups < 4096 ? groups : 4096));
     if (dtype == DS_DTYPE_BF16)
         hipLaunchKernelGGL(vae_conv_out_kernel<bf16_t>, grid, dim3(256), lds, stream, (const bf16_t*)x, (const bf16_t*)w,
                            (const bf16_t*)bias, img, B, H, W, C, denorm);
