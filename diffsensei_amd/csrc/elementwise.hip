@@ -24,10 +24,10 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const half_t* __restrict__
                                                       const half_t* __restrict__ demb, half_t* __restrict__ y, int B,
                                                       int H, int W, int Cout, int ndialog) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    half_t* sw = reinterpret_cast<half_t*>(smem_raw);  // [36][Cout]
+    half_t* sw = reinterpret_cast<half_t*>(smem_raw);  // [9 taps][2 channel pairs][Cout] of (w[ci = 2 pair], w[ci = 2 pair + 1])
     for (int i = threadIdx.x; i < 36 * Cout; i += 256) {
-        const int k = i / Cout, co = i - k * Cout;
-        sw[i] = w[co * 36 + k];
+        const int j = i & 1, co = (i >> 1) % Cout, tp = (i >> 1) / Cout;   // tp = tap * 2 + pair
+        sw[i] = w[co * 36 + tp * 2 + j];
     }
     __syncthreads();
     const int ncc = Cout >> 3;
@@ -50,12 +50,18 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const half_t* __restrict__
             const int iy = oy + ky - 1, ix = ox + kx - 1;
             if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
             const h4 xv = *reinterpret_cast<const h4*>(x + ((long)(b * H + iy) * W + ix) * 4);
+            // v_dot2_f32_f16: two input channels per instruction, f16 products summed in f32 - no converts (the f32 fma form
+            // spent 2/3 of its VALU instructions on them: 1.0 ms per batch-64 launch for 0.7 GB of output)
 #pragma unroll
-            for (int ci = 0; ci < 4; ++ci) {
-                const h8 wv = *reinterpret_cast<const h8*>(sw + ((ky * 3 + kx) * 4 + ci) * Cout + cc * 8);
-                const float xf = (float)xv[ci];
+            for (int pr = 0; pr < 2; ++pr) {
+                const h2 xp = {xv[2 * pr], xv[2 * pr + 1]};
+                const half_t* wp = sw + (((ky * 3 + kx) * 2 + pr) * Cout + cc * 8) * 2;
+                const h8 w0 = *reinterpret_cast<const h8*>(wp), w1 = *reinterpret_cast<const h8*>(wp + 8);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] = fmaf(xf, (float)wv[e], acc[e]);
+                for (int e = 0; e < 4; ++e) {
+                    acc[e] = __builtin_amdgcn_fdot2(xp, (h2){w0[2 * e], w0[2 * e + 1]}, acc[e], false);
+                    acc[4 + e] = __builtin_amdgcn_fdot2(xp, (h2){w1[2 * e], w1[2 * e + 1]}, acc[4 + e], false);
+                }
             }
         }
     bool inside = false;
@@ -110,7 +116,8 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const half_t* __restrict_
             for (int co = 0; co < 4; ++co) {
                 const h8 wv = *reinterpret_cast<const h8*>(sw + co * K + tap * Cin + c);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc[co] = fmaf((float)xv[e], (float)wv[e], acc[co]);
+                for (int e = 0; e < 8; e += 2)   // v_dot2_f32_f16: two channels per instruction, no converts
+                    acc[co] = __builtin_amdgcn_fdot2((h2){xv[e], xv[e + 1]}, (h2){wv[e], wv[e + 1]}, acc[co], false);
             }
         }
     }

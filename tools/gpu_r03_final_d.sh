@@ -1,5 +1,5 @@
 #!/usr/bin/env bash
-# Round 3 evidence run, part D (final tree after the gn_finalize / attention-prologue changes): build, whole GPU suite, smoke,
+# Round 3 evidence run, part D (final tree: after the gn_finalize, attention-prologue, vae_conv_out and conv_in / conv_out dot2 changes): build, whole GPU suite, smoke,
 # the default bench line and the two small-batch configurations.
 set -u
 out=gpurun_out
