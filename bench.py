@@ -99,15 +99,23 @@ def build_pipeline(device, num_gpus, rank, seed=0, with_vae=True, agent=None, ke
         te1 = ClipTextEngine.from_transformers(cpu_module("text_encoder", CLIPTextModel(t1)), device)
         te2 = ClipTextEngine.from_transformers(cpu_module("text_encoder_2", CLIPTextModelWithProjection(t2)), device)
     # SDXL VAE decoder (49.5 M parameters) at its true shapes, random init (scaled-fp16 HIP engine unless DIFFSENSEI_VAE_PRECISION says bf16)
-    from diffsensei_amd.vae import VaeConfig, VaeDecoderEngine
-    vae = VaeDecoderEngine.init_random(VaeConfig(), seed + 2, device) if with_vae else None
+    # The seeded state dict is rounded ONCE to the engine's storage type and that very dict feeds both the engine and (kept
+    # below) the oracle of `parity`, so the two sides hold the same weights bit for bit (the oracle used a bf16
+    # rounding of its own while the scaled-fp16 engine held fp16 roundings).
+    from diffsensei_amd.vae import VaeConfig, VaeDecoderEngine, random_state_dict as vae_random_sd
+    vae = vae_sd = None
+    if with_vae:
+        vprec = os.environ.get("DIFFSENSEI_VAE_PRECISION", "fp16-scaled")
+        vdt = torch.bfloat16 if vprec == "bf16" else torch.float16
+        vae_sd = {k: v.to(vdt).float() for k, v in vae_random_sd(VaeConfig(), seed + 2).items()}
+        vae = VaeDecoderEngine.from_state_dict(vae_sd, VaeConfig(), device, precision=vprec)
     t_init = time.perf_counter() - t0
     tok = SyntheticTokenizer()
     pipe = DiffSenseiPipeline(vae=vae, text_encoder=te1, text_encoder_2=te2, tokenizer=tok, tokenizer_2=tok,
                               scheduler=EulerDiscreteScheduler(), unet=unet, image_encoder=clip)
     pipe.register_manga_modules(magi_image_encoder=magi, image_proj_model=resampler)
     if keep_oracle:
-        keep.update(tokenizer=tok, tokenizer_2=tok, resampler_heads=20, resampler_dim_head=64, vae_seed=seed + 2)
+        keep.update(tokenizer=tok, tokenizer_2=tok, resampler_heads=20, resampler_dim_head=64, vae_sd=vae_sd)
         pipe._oracle_modules = keep
     # N > 1: every engine's frozen weights (pipe.tensors() [+ the MLLM agent]) are re-homed into one flat arena per dtype and
     # the arena goes out from rank 0 in asynchronous 512 MiB slices (no staging copies), then an all-reduced checksum proves
@@ -191,12 +199,12 @@ def cpu_call_and_gpu_parity(pipe, req, cpu_full=False, parity=True, budget_steps
       fraction of bytes that differ at all and by more than 1 LSB, the largest difference)."""
     import numpy as np
     from diffsensei_amd.unet_config import sdxl_config
-    from diffsensei_amd.vae import VaeConfig, random_state_dict as vae_random_sd
+    from diffsensei_amd.vae import VaeConfig
     from oracle.pipeline_ref import call_oracle
     from oracle.unet_ref import UNetOracle
     mods = dict(pipe._oracle_modules)
     vcfg = VaeConfig()
-    mods["vae_sd"] = {k: v.to(torch.bfloat16).float() for k, v in vae_random_sd(vcfg, mods["vae_seed"]).items()}
+    assert mods.get("vae_sd") is not None, "parity needs the VAE (the engine and the oracle share ONE rounded state dict)"
     mods["vae_cfg"] = {"layers_per_block": vcfg.layers_per_block, "norm_num_groups": vcfg.norm_num_groups, "eps": vcfg.eps,
                        "scaling_factor": vcfg.scaling_factor}
     mods["resampler_sd"] = {k: v.float().cpu() for k, v in pipe.image_proj_model.state_dict().items()}
@@ -249,6 +257,24 @@ def cpu_call_and_gpu_parity(pipe, req, cpu_full=False, parity=True, budget_steps
            "u8_max_diff": int(np.abs(d).max()), "u8_std_ref": round(float(ref["u8"][0].std()), 2),
            "vs": "oracle/pipeline_ref.call_oracle (fp32 torch + transformers modules, CPU) on the same weights / prompt / noise"}
     return cpu, par
+
+
+def vae_precision_note(pipe, ns, size, call_s, world):
+    """What the VAE leg of the timed region computes in, beside what the reference does there (fp32: it upcasts the VAE,
+    pipeline_diffsensei.py:339-344), and a LOWER bound of the headline if a true-fp32 decode were required: fp32 MFMA runs at
+    1/16 of the fp16 rate (157 TFLOP/s, MI355X_MICROARCH.md), so 10.5 TFLOP per 1024^2 image cost >= 67 ms instead of the
+    ~14 ms measured for the scaled-fp16 decoder (tools/vae_bench.py, profiles/r03_vae_conv_out_8lane.txt)."""
+    fp32_ms = 10.5e12 * (size / 1024.0) ** 2 / 157e12 * 1e3
+    ours_ms = 14.3 * (size / 1024.0) ** 2
+    extra_s = ns * max(fp32_ms - ours_ms, 0.0) * 1e-3
+    return {"engine": pipe.vae.precision,
+            "arithmetic": ("fp16 operands with every stored tensor scaled by 2^-6, fp32 accumulation / statistics / softmax"
+                           if pipe.vae.precision == "fp16-scaled" else "bf16 storage, fp32 accumulation / statistics / softmax"),
+            "reference": "fp32 (vae upcast, pipeline_diffsensei.py:339-344)",
+            "parity_evidence": "tests/test_gpu_vae.py::test_vae_decode_1024_vs_oracle (1024x1024, chunked batch 8, uint8 within "
+                               "1 LSB of the fp32 oracle on >= 99.9 % of the bytes), ::test_decoder_uint8_parity_where_fp16_would_overflow",
+            "fp32_decode_exposure": {"per_image_ms_at_fp32_mfma_peak": round(fp32_ms, 1), "per_image_ms_this_engine": round(ours_ms, 1),
+                                     "value_lower_bound_if_fp32_decode": round(world * ns / (call_s + extra_s), 4)}}
 
 
 def profile_forward_ops(pipe, reps=3):
@@ -448,6 +474,7 @@ def main():
                                          if out_type == "pil" else "; output: [0,1] fp32 images on the device")),
                        "mllm_prepass": ("LLaMA-2-13B dims, 111-token prompt + 66 new tokens (64-token image block), both "
                                         "QwenResamplers, blend; timed") if args.mllm else None,
+                       "vae_precision": None if args.no_vae else vae_precision_note(pipe, ns, args.size, dt / args.steps, world),
                        "num_samples": ns, "unet_batch": 2 * ns, "hipgraph": pipe.last_run_info.get("graph"),
                        "kernel_launches_per_denoise_step": pipe.last_run_info.get("ops_per_step"),
                        "weights": "seeded random at SDXL UNet / CLIP-L + bigG text / CLIP-H / ViT-MAE / Resampler / VAE decoder shapes", **setup},

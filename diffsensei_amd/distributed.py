@@ -49,66 +49,112 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
 
 
 class WeightArena:
-    """Every frozen weight of a serving process in ONE flat buffer per (device, dtype).
+    """Every frozen weight of a serving process in a few flat buffers ("segments", <= 1 GiB each) per (device, dtype).
 
     `WeightArena(tensors)` re-homes the given tensors: each keeps its Python identity, shape and values, but its storage
-    becomes a 256-byte-aligned slice of the arena (`Tensor.set_`), after ONE device-to-device copy per tensor at start-up.
-    The weight broadcast then runs on slices of the arena itself - no `torch.cat` staging buffer, no copy-back (the
-    round-2 path moved every byte three times and held an extra 512 MiB), and the slices are issued as asynchronous
-    collectives with a single wait at the end, so RCCL pipelines them over the xGMI ring.
-    Data pointers change: callers must drop launch plans / packed copies derived from the old storage
-    (`weights_changed()` of the engines - `broadcast_pipeline` does it)."""
-    ALIGN = 256
+    becomes a 256-byte-aligned slice of a segment (`Tensor.set_`), after ONE device-to-device copy per tensor at start-up.
+    The weight broadcast then runs on slices of the segments themselves - no `torch.cat` staging buffer, no copy-back (the
+    round-2 path moved every byte three times), and the slices are issued as asynchronous collectives with a single wait at
+    the end, so RCCL pipelines them over the xGMI ring.  Segments are filled one after the other and every tensor's old
+    storage is released as soon as it has moved, so the transient peak is the weights + ONE segment (a single flat buffer per
+    dtype held ~2x the weights while it was being filled).
 
-    def __init__(self, tensors: Sequence[Tensor]):
-        self.buffers: Dict[Tuple[torch.device, torch.dtype], Tensor] = {}
-        self.loose: List[Tensor] = []          # not contiguous, or views of a larger storage: left where they are, broadcast one by one
+    Aliasing is preserved: the same memory listed twice - under the same or under different shapes (`w` and `w.view(-1)`) -
+    occupies one slot; a view into a LISTED tensor's storage (a slice of a packed weight, a transposed view) is re-pointed
+    into that tensor's new slot with its offset and strides.  What is left over - non-contiguous tensors and views whose base
+    is not listed - stays where it is (`loose`) and goes through one contiguous staging buffer per dtype in
+    `broadcast_arena` (RCCL / NCCL refuse non-contiguous tensors).
+    Data pointers change: callers must drop launch plans / packed copies derived from the old storage
+    (`weights_changed()` of the engines - `broadcast_pipeline` calls it on every engine)."""
+    ALIGN = 256
+    SEGMENT_BYTES = 1 << 30
+
+    def __init__(self, tensors: Sequence[Tensor], segment_bytes: Optional[int] = None):
+        seg_bytes = int(segment_bytes or self.SEGMENT_BYTES)
+        self.buffers: Dict[Tuple[torch.device, torch.dtype], List[Tensor]] = {}   # the segments, in fill order
+        self.loose: List[Tensor] = []
         groups: Dict[Tuple[torch.device, torch.dtype], List[Tensor]] = {}
-        seen: Dict[Tuple[int, int, Tuple[int, ...]], Tensor] = {}
-        self._alias: List[Tuple[Tensor, Tensor]] = []
+        owner_of: Dict[Tuple[int, int], Tensor] = {}     # (storage address, storage bytes) -> the listed tensor that owns it
+        seen_ids = set()
+        aliases: List[Tuple[Tensor, Tensor]] = []
+        views: List[Tuple[Tensor, Tuple[int, int], int]] = []
+        self.payload_bytes = 0                  # bytes of distinct weight memory (an alias or a view of a listed tensor counts once)
         for t in tensors:
-            # only tensors that OWN their storage move: a view into a larger tensor (a slice of a packed weight) must keep
-            # aliasing its base - the in-place broadcast into it updates the base as before
-            owns = t.storage_offset() == 0 and t.untyped_storage().nbytes() == t.numel() * t.element_size()
-            if not t.is_contiguous() or not owns:
-                self.loose.append(t)
+            if id(t) in seen_ids:               # the same Python object listed twice
                 continue
-            key = (t.data_ptr(), t.numel() * t.element_size(), tuple(t.shape))
-            if t.numel() and key in seen:       # the same memory listed twice (shared weights): one slot, both re-homed to it
-                if seen[key] is not t:
-                    self._alias.append((t, seen[key]))
+            seen_ids.add(id(t))
+            st = t.untyped_storage()
+            skey = (st.data_ptr(), st.nbytes())
+            owns = t.storage_offset() == 0 and st.nbytes() == t.numel() * t.element_size() and t.is_contiguous()
+            if owns and t.numel():
+                first = owner_of.get(skey)
+                if first is None:
+                    owner_of[skey] = t
+                    groups.setdefault((t.device, t.dtype), []).append(t)
+                    self.payload_bytes += t.numel() * t.element_size()
+                elif first.dtype == t.dtype:
+                    aliases.append((t, first))  # same memory, maybe another shape: one slot
+                else:
+                    self.loose.append(t)
+            elif owns:                          # empty tensor: nothing to move or send
                 continue
-            seen[key] = t
-            groups.setdefault((t.device, t.dtype), []).append(t)
+            else:
+                views.append((t, skey, t.storage_offset()))
         self.bytes = 0                          # arena size (with alignment padding)
-        self.payload_bytes = sum(t.numel() * t.element_size() for t in tensors)
         for (dev, dtype), lst in groups.items():
             esz = lst[0].element_size()
             step = max(1, self.ALIGN // esz)
-            offs, n = [], 0
-            for t in lst:
-                offs.append(n)
-                n += (t.numel() + step - 1) // step * step
-            flat = torch.zeros(n, dtype=dtype, device=dev)
-            for t, off in zip(lst, offs):
-                view = flat[off:off + t.numel()].view(t.shape)
-                view.copy_(t)
-                t.set_(view)
-            self.buffers[(dev, dtype)] = flat
-            self.bytes += n * esz
-        for t, first in self._alias:
-            t.set_(first)
+            cap = max(step, seg_bytes // esz // step * step)
+            segs: List[Tensor] = []
+            i = 0
+            while i < len(lst):
+                # one segment: as many tensors as fit (a tensor larger than a segment gets one of its own)
+                offs, n, j = [], 0, i
+                while j < len(lst):
+                    need = (lst[j].numel() + step - 1) // step * step
+                    if j > i and n + need > cap:
+                        break
+                    offs.append(n)
+                    n += need
+                    j += 1
+                flat = torch.zeros(n, dtype=dtype, device=dev)
+                for t, off in zip(lst[i:j], offs):
+                    view = flat[off:off + t.numel()].view(t.shape)
+                    view.copy_(t)
+                    t.set_(view)                # the old storage is released here (unless a loose view still holds it)
+                segs.append(flat)
+                self.bytes += n * esz
+                i = j
+                if dev.type == "cuda" and i < len(lst):
+                    torch.cuda.empty_cache()    # hand the freed originals back before the next segment is allocated
+            self.buffers[(dev, dtype)] = segs
+        for t, first in aliases:
+            t.set_(first.untyped_storage(), first.storage_offset(), t.size(), t.stride())
+        for t, skey, off in views:
+            base = owner_of.get(skey)
+            if base is not None and base.dtype == t.dtype:
+                # a window onto a listed tensor: follows it into its slot (offset and strides kept), needs no message of its own
+                t.set_(base.untyped_storage(), base.storage_offset() + off, t.size(), t.stride())
+            else:
+                self.loose.append(t)
+                self.payload_bytes += t.numel() * t.element_size()
+
+    def segments(self) -> List[Tensor]:
+        return [f for segs in self.buffers.values() for f in segs]
 
     def slices(self, bucket_bytes: int) -> List[Tensor]:
+        """Contiguous slices of the segments, <= bucket_bytes each (the `loose` tensors are handled by `broadcast_arena`)."""
         out = []
-        for flat in self.buffers.values():
+        for flat in self.segments():
             m = max(1, bucket_bytes // flat.element_size())
             out += [flat[o:o + m] for o in range(0, flat.numel(), m)]
-        return out + list(self.loose)
+        return out
 
 
 def broadcast_arena(arena: WeightArena, src: int = 0, bucket_bytes: int = 512 << 20, force: bool = False) -> Dict[str, float]:
-    """Broadcast the arena's buffers from `src` in `bucket_bytes` slices: all collectives issued asynchronously, one wait."""
+    """Broadcast the arena's segments from `src` in `bucket_bytes` slices: all collectives issued asynchronously, one wait.
+    Loose tensors (non-contiguous, or views of unlisted storage) travel through ONE contiguous staging buffer per
+    (device, dtype) and are copied back after the wait."""
     stats = {"bytes": 0, "buckets": 0, "seconds": 0.0}
     if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return stats
@@ -118,9 +164,25 @@ def broadcast_arena(arena: WeightArena, src: int = 0, bucket_bytes: int = 512 <<
         work.append(dist.broadcast(sl, src=src, async_op=True))
         stats["bytes"] += sl.numel() * sl.element_size()
         stats["buckets"] += 1
+    staged: List[Tuple[Tensor, List[Tensor]]] = []
+    by_type: Dict[Tuple[torch.device, torch.dtype], List[Tensor]] = {}
+    for t in arena.loose:
+        if t.numel():
+            by_type.setdefault((t.device, t.dtype), []).append(t)
+    for lst in by_type.values():
+        stage = torch.cat([t.reshape(-1) for t in lst])
+        work.append(dist.broadcast(stage, src=src, async_op=True))
+        staged.append((stage, lst))
+        stats["bytes"] += stage.numel() * stage.element_size()
+        stats["buckets"] += 1
     for w in work:
         w.wait()
-    if any(dev.type == "cuda" for dev, _ in arena.buffers):
+    for stage, lst in staged:
+        o = 0
+        for t in lst:
+            t.copy_(stage[o:o + t.numel()].view(t.shape))
+            o += t.numel()
+    if any(dev.type == "cuda" for dev, _ in arena.buffers) or any(t.is_cuda for t in arena.loose):
         torch.cuda.synchronize()
     stats["seconds"] = time.perf_counter() - t0
     return stats
@@ -195,8 +257,12 @@ def broadcast_pipeline(pipe, extra: Sequence = (), src: int = 0, bucket_bytes: i
     # drops what it derived from the old storage (packed copies, launch plans with raw pointers)
     names = ("unet", "text_encoder", "text_encoder_2", "image_encoder", "magi_image_encoder", "image_proj_model", "vae")
     for m in [getattr(pipe, n, None) for n in names] + list(extra):
-        if m is not None and hasattr(m, "weights_changed"):
-            m.weights_changed()
+        if m is None or not hasattr(m, "tensors"):
+            continue            # not one of this package's engines (e.g. a user-supplied torch module): nothing was re-homed
+        if not hasattr(m, "weights_changed"):
+            raise TypeError(f"{type(m).__name__} lists tensors() for the weight broadcast but has no weights_changed(): a "
+                            f"raw-pointer cache inside it would go stale silently")
+        m.weights_changed()
     t0 = time.perf_counter()
     ver = verify_replicas(tensors) if (dist.is_initialized() and (dist.get_world_size() > 1 or force)) else \
         {"checksum": None, "elements": sum(t.numel() for t in tensors)}
@@ -239,29 +305,60 @@ def shard_requests(requests: Sequence[PanelRequest], world_size: int) -> List[Li
     return shards
 
 
-def run_sharded(requests: Sequence[PanelRequest], worker: Callable[[PanelRequest], object], gather: bool = True):
-    """Every rank runs `worker` on its shard; rank 0 optionally receives all results keyed by request_id."""
+def _to_wire(x):
+    """What crosses the process boundary in a result gather: uint8 / float arrays, not pickled PIL objects (3 bytes per pixel,
+    one contiguous buffer per image; rank 0 wraps them back into PIL images only if the caller asks for it)."""
+    import numpy as np
+    if isinstance(x, (list, tuple)):
+        return [_to_wire(v) for v in x]
+    if isinstance(x, Tensor):
+        return x.detach().cpu().numpy()
+    if hasattr(x, "mode") and hasattr(x, "size") and hasattr(x, "tobytes"):   # a PIL image
+        return np.asarray(x)
+    return x
+
+
+def _from_wire(x, as_pil: bool):
+    import numpy as np
+    if isinstance(x, list):
+        return [_from_wire(v, as_pil) for v in x]
+    if as_pil and isinstance(x, np.ndarray) and x.dtype == np.uint8 and x.ndim == 3 and x.shape[2] in (1, 3, 4):
+        from PIL import Image
+        return Image.fromarray(x if x.shape[2] != 1 else x[:, :, 0])
+    return x
+
+
+def _gather_results(results: dict, rank: int, world: int, as_pil: bool):
+    wire = {k: _to_wire(v) for k, v in results.items()}
+    gathered: List[Optional[dict]] = [None] * world if rank == 0 else None
+    dist.gather_object(wire, gathered, dst=0)
+    if rank != 0:
+        return None
+    out = {}
+    for d in gathered:
+        out.update({k: _from_wire(v, as_pil) for k, v in d.items()})
+    return out
+
+
+def run_sharded(requests: Sequence[PanelRequest], worker: Callable[[PanelRequest], object], gather: bool = True,
+                as_pil: bool = False):
+    """Every rank runs `worker` on its shard; rank 0 optionally receives all results keyed by request_id.  Gathered images
+    travel as uint8 arrays ([H,W,3]); `as_pil` re-wraps them on rank 0."""
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
     mine = shard_requests(requests, world)[rank]
     results = {r.request_id: worker(r) for r in mine}
     if not gather or world == 1:
         return results
-    gathered: List[Optional[dict]] = [None] * world if rank == 0 else None
-    dist.gather_object(results, gathered, dst=0)
-    if rank != 0:
-        return None
-    out = {}
-    for d in gathered:
-        out.update(d)
-    return out
+    return _gather_results(results, rank, world, as_pil)
 
 
 def run_sharded_batched(requests: Sequence[PanelRequest], pipe, max_panels: int = 16, max_pixels: Optional[int] = None,
-                        output_type: str = "pil", gather: bool = True):
+                        output_type: str = "pil", gather: bool = True, as_pil: bool = False):
     """`run_sharded` for a whole queue: every rank pushes its shard through a `serving.BucketBatcher`, so requests of
     one (size, steps, guidance) bucket share UNet batches on that rank (BASELINE.json configs[3]: mixed-resolution
-    queue over the GPUs of a node).  `PanelRequest.payload` holds the other `__call__` keyword arguments."""
+    queue over the GPUs of a node).  `PanelRequest.payload` holds the other `__call__` keyword arguments.  With
+    `gather`, rank 0 receives every request's images as uint8 arrays (`as_pil`: re-wrapped into PIL images there)."""
     from .serving import BucketBatcher
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
@@ -274,11 +371,4 @@ def run_sharded_batched(requests: Sequence[PanelRequest], pipe, max_panels: int 
     results = {r.request_id: o for r, o in zip(mine, outs)}
     if not gather or world == 1:
         return results
-    gathered: List[Optional[dict]] = [None] * world if rank == 0 else None
-    dist.gather_object(results, gathered, dst=0)
-    if rank != 0:
-        return None
-    out = {}
-    for d in gathered:
-        out.update(d)
-    return out
+    return _gather_results(results, rank, world, as_pil)

@@ -55,6 +55,11 @@ class ViTEncoderEngine:
     def n_patches(self) -> int:
         return (self.image_size // self.patch) ** 2
 
+    def weights_changed(self) -> None:
+        """Called after `tensors()` were rewritten in place / re-homed (the RCCL start-up broadcast).  The kernels read the
+        listed tensors themselves at every call - nothing derived from them is cached here - so there is nothing to drop; the
+        hook exists so that `distributed.broadcast_pipeline` can require it of every engine."""
+
     def tensors(self) -> List[Tensor]:
         """Frozen weights in kernel layout (the multi-GPU weight broadcast list)."""
         out = [getattr(L, s) for L in self.layers for s in L.__slots__]
@@ -247,6 +252,11 @@ class ClipTextEngine:
 
     def parameters(self):
         yield self.tok_emb
+
+    def weights_changed(self) -> None:
+        """Called after `tensors()` were rewritten in place / re-homed (the RCCL start-up broadcast).  The kernels read the
+        listed tensors themselves at every call - nothing derived from them is cached here - so there is nothing to drop; the
+        hook exists so that `distributed.broadcast_pipeline` can require it of every engine."""
 
     def tensors(self) -> List[Tensor]:
         """Frozen weights in kernel layout (the multi-GPU weight broadcast list)."""

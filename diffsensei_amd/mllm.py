@@ -357,6 +357,10 @@ class QwenResampler:
         self._add: Dict[int, Tensor] = {}
         self.w_out, self.b_out = half(f32("attn.out_proj.weight")), half(f32("attn.out_proj.bias"))
 
+    def weights_changed(self) -> None:
+        """Drop the per-length key addends derived from the (rewritten) weights."""
+        self._add.clear()
+
     def tensors(self) -> List[Tensor]:
         """Frozen (folded) weights (the multi-GPU weight broadcast list); the per-length key addends are derived."""
         self._add.clear()
@@ -434,8 +438,8 @@ class ContinuousLVLM:
 
     def weights_changed(self) -> None:
         self.llm.weights_changed()
-        self.input_resampler._add.clear()
-        self.output_resampler._add.clear()
+        self.input_resampler.weights_changed()
+        self.output_resampler.weights_changed()
 
     @torch.no_grad()
     def generate(self, tokenizer=None, prompt=None, input_ids=None, image_embeds=None, ids_cmp_mask=None,

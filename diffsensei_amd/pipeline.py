@@ -19,7 +19,7 @@ from __future__ import annotations
 
 import os
 from dataclasses import dataclass
-from typing import Any, List, Optional, Tuple, Union
+from typing import Any, List, Optional, Sequence, Tuple, Union
 
 import torch
 
@@ -312,10 +312,16 @@ class DiffSenseiPipeline:
                  latents: Optional[Tensor] = None, prompt_embeds: Optional[Tensor] = None,
                  negative_prompt_embeds: Optional[Tensor] = None, pooled_prompt_embeds: Optional[Tensor] = None,
                  negative_pooled_prompt_embeds: Optional[Tensor] = None, output_type: str = "pil",
-                 callback_on_step_end=None):
+                 callback_on_step_end=None, callback_on_step_end_tensor_inputs: Sequence[str] = ("latents",)):
         """`callback_on_step_end(pipe, step_index, timestep, {"latents": device tensor}) -> dict | None` is diffusers'
         SDXL-pipeline hook [3P]; together with `pipe._interrupt = True` it is the reference's early exit: the loop
-        `continue`s over the remaining steps (reference :314-315) and the call still decodes and post-processes."""
+        `continue`s over the remaining steps (reference :314-315) and the call still decodes and post-processes.  Latents
+        may be edited in place or returned (`{"latents": new}`), as in diffusers; `latents` is the only tensor the launch
+        plan can hand out per step, so other `callback_on_step_end_tensor_inputs` are refused like diffusers refuses unknown
+        names."""
+        bad = [k for k in callback_on_step_end_tensor_inputs if k != "latents"]
+        if bad:
+            raise ValueError(f"`callback_on_step_end_tensor_inputs` has to be in ['latents'], but found {bad}")
         self._interrupt = False                                   # reference :226
         cond = self._conditioning(prompt, prompt_2, height, width, num_inference_steps, guidance_scale, negative_prompt,
                                   negative_prompt_2, num_samples, generator, original_size, crops_coords_top_left,
@@ -421,8 +427,18 @@ class DiffSenseiPipeline:
                     eng.step_plan.capture(st.cuda_stream)
                 graph = True
             timesteps = self.scheduler.timesteps
+
+            def hook(i):
+                # diffusers' contract [3P]: `latents = callback_outputs.pop("latents", latents)` - a callback may return a
+                # dict with replaced latents instead of editing `eng.latents` in place; both forms are honoured
+                ret = callback_on_step_end(self, i, timesteps[i], {"latents": eng.latents})
+                if isinstance(ret, dict):
+                    new = ret.get("latents")
+                    if isinstance(new, Tensor) and new.data_ptr() != eng.latents.data_ptr():
+                        eng.latents.copy_(new.to(eng.latents.device, eng.latents.dtype).reshape(eng.latents.shape))
+
             if n0 and callback_on_step_end is not None:
-                callback_on_step_end(self, 0, timesteps[0], {"latents": eng.latents})
+                hook(0)
             for i in range(n0, num_inference_steps):
                 if self._interrupt:                               # reference :314-315 `if self.interrupt: continue`
                     continue
@@ -431,7 +447,7 @@ class DiffSenseiPipeline:
                 else:
                     eng.step_plan.run(st.cuda_stream)
                 if callback_on_step_end is not None:              # launched, not synchronised: the hook sees device tensors
-                    callback_on_step_end(self, i, timesteps[i], {"latents": eng.latents})
+                    hook(i)
         torch.cuda.current_stream(device).wait_stream(st)
         self.last_run_info = {"graph": graph, "ops_per_step": eng.step_plan.n, "batch": B, "latent_hw": (H, W)}
         return eng.latents.clone()

@@ -56,6 +56,11 @@ class Resampler:
     def state_dict(self):
         return dict(self._sd)
 
+    def weights_changed(self) -> None:
+        """Called after `tensors()` were rewritten in place / re-homed (the RCCL start-up broadcast).  The kernels read the
+        listed tensors themselves at every call - nothing derived from them is cached here - so there is nothing to drop; the
+        hook exists so that `distributed.broadcast_pipeline` can require it of every engine."""
+
     def tensors(self):
         """Frozen weights (the multi-GPU weight broadcast list)."""
         return list(self._sd.values())

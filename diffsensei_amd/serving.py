@@ -28,7 +28,8 @@ def bucket_key(request: dict) -> Tuple:
 
 def plan_batches(requests: List[dict], max_panels: int, max_pixels: Optional[int] = None) -> List[List[int]]:
     """Indices of `requests` grouped into batches: same bucket, at most `max_panels` panels (sum of num_samples) per
-    batch - and at most `max_pixels` output pixels if given, so small resolutions get proportionally larger batches -
+    batch - and at most `max_pixels` output pixels if given, so small resolutions get proportionally larger batches (a
+    single request above the pixel cap but within `max_panels` runs alone; only `num_samples > max_panels` is an error) -
     submission order kept inside a bucket, buckets ordered by decreasing pixel count (the long jobs first)."""
     if max_panels < 1:
         raise ValueError("max_panels must be >= 1")
@@ -44,8 +45,16 @@ def plan_batches(requests: List[dict], max_panels: int, max_pixels: Optional[int
         cur, panels = [], 0
         for i in buckets[k]:
             n = int(requests[i].get("num_samples", 1) or 1)
+            if n > max_panels:
+                raise ValueError(f"request {i}: num_samples {n} exceeds max_panels {max_panels}")
             if n > cap:
-                raise ValueError(f"request {i}: num_samples {n} exceeds the batch cap {cap} of its bucket")
+                # the pixel cap only shapes how requests are PACKED: a single request that is larger than it (2048 x 2048 with
+                # num_samples 9..16 under the 32 Mpx default) is still served, in a batch of its own, as before the cap existed
+                if cur:
+                    batches.append(cur)
+                    cur, panels = [], 0
+                batches.append([i])
+                continue
             if cur and panels + n > cap:
                 batches.append(cur)
                 cur, panels = [], 0

@@ -332,6 +332,11 @@ class VaeDecoderEngine:
     def to(self, *a, **k):
         return self
 
+    def weights_changed(self) -> None:
+        """Called after `tensors()` were rewritten in place / re-homed (the RCCL start-up broadcast).  The kernels read the
+        listed tensors themselves at every call - nothing derived from them is cached here - so there is nothing to drop; the
+        hook exists so that `distributed.broadcast_pipeline` can require it of every engine."""
+
     def tensors(self):
         """Every weight tensor (for the one-off RCCL broadcast)."""
         return list(self.w.values())

@@ -183,14 +183,16 @@ def _pipeline_bcast_worker(rank, world, port, q):
         def __init__(self, shapes, dtype):
             self.ts = [torch.randn(s, generator=g).to(dtype) for s in shapes]
 
+        changed = 0
+
         def tensors(self):
             return self.ts
 
-    class UNet(Engine):
-        changed = 0
-
         def weights_changed(self):
             self.changed += 1
+
+    class UNet(Engine):
+        pass
 
     class Pipe:
         def __init__(self):
@@ -205,7 +207,8 @@ def _pipeline_bcast_worker(rank, world, port, q):
     before = int(tensors_checksum(pipe.tensors() + agent.tensors())[0])
     stats = broadcast_pipeline(pipe, extra=[agent], bucket_bytes=1 << 14)
     after = int(tensors_checksum(pipe.tensors() + agent.tensors())[0])
-    ok = stats["tensors"] == 8 and stats["checksum"] == after and stats["buckets"] >= 3 and pipe.unet.changed == 1
+    ok = stats["tensors"] == 8 and stats["checksum"] == after and stats["buckets"] >= 3
+    ok = ok and [m.changed for m in (pipe.unet, pipe.vae, agent)] == [1, 1, 1]      # every engine the pipeline names + the extra
     raised = False
     if rank == 1:
         pipe.enc.ts[0][3, 3] += 1.0                      # one value differs on one rank
@@ -236,32 +239,135 @@ def test_broadcast_pipeline_and_replica_check_world2():
 
 def test_weight_arena_rehomes_tensors_in_place():
     """`WeightArena` (the no-staging weight broadcast): every tensor keeps its identity, shape and values but ends up as a
-    256-byte-aligned slice of ONE flat buffer per dtype; memory listed twice is re-homed once; a non-contiguous tensor is
-    left alone and broadcast on its own."""
+    256-byte-aligned slice of a flat segment per dtype; memory listed twice - also under another shape - is re-homed once and
+    keeps aliasing; a view of a LISTED tensor follows it into its slot; a non-contiguous tensor and a view of unlisted storage
+    are left alone (`loose`) and go through the staging buffer of `broadcast_arena`."""
     from diffsensei_amd.distributed import WeightArena
     g = torch.Generator().manual_seed(0)
     ts = [torch.randn(s, generator=g).half() for s in [(7, 3), (640, 640), (5,), (33, 2, 2)]]
     ts += [torch.arange(6, dtype=torch.float32), torch.randn(3, 3, generator=g)]
     shared = ts[1]
-    odd = torch.randn(8, 6, generator=g).half().t()               # not contiguous
-    base = torch.randn(3, 16, 16, generator=g).half()             # a packed weight ...
+    flat_alias = ts[1].view(-1)                                   # the same storage under another shape
+    odd = torch.randn(8, 6, generator=g).half().t()               # not contiguous, base not listed
+    base = torch.randn(3, 16, 16, generator=g).half()             # a packed weight that is NOT listed ...
     view = base[1]                                                # ... and a slice of it that an engine lists: must keep aliasing
-    lst = ts + [shared, odd, view]
+    packed = torch.randn(4, 8, 8, generator=g).half()             # a packed weight that IS listed ...
+    window, tview = packed[2], packed[1].t()                      # ... with a contiguous and a transposed window onto it
+    lst = ts + [shared, flat_alias, odd, view, packed, window, tview]
     before = [t.clone() for t in lst]
     ids = [id(t) for t in lst]
     arena = WeightArena(lst)
     assert [id(t) for t in lst] == ids and all(torch.equal(a, b) for a, b in zip(lst, before))
-    assert set(k[1] for k in arena.buffers) == {torch.float16, torch.float32} and len(arena.loose) == 2
-    assert arena.loose[0] is odd and arena.loose[1] is view and view.data_ptr() == base[1].data_ptr()
+    assert set(k[1] for k in arena.buffers) == {torch.float16, torch.float32}
+    assert len(arena.loose) == 2 and arena.loose[0] is odd and arena.loose[1] is view and view.data_ptr() == base[1].data_ptr()
     view.fill_(7.0)
-    assert float(base[1].float().mean()) == 7.0                   # still a window onto the packed weight
-    f16 = next(v for k, v in arena.buffers.items() if k[1] == torch.float16)
+    assert float(base[1].float().mean()) == 7.0                   # still a window onto the unlisted packed weight
+    (f16,) = arena.buffers[(torch.device("cpu"), torch.float16)]
     lo, hi = f16.data_ptr(), f16.data_ptr() + f16.numel() * 2
-    for t in ts[:4]:
+    for t in ts[:4] + [packed]:
         assert lo <= t.data_ptr() < hi and (t.data_ptr() - lo) % 256 == 0 and t.is_contiguous()
-    assert arena.payload_bytes == sum(t.numel() * t.element_size() for t in lst) and arena.bytes >= sum(t.numel() * t.element_size() for t in ts)
+    # aliases and windows moved WITH their owners
+    assert flat_alias.data_ptr() == ts[1].data_ptr() and flat_alias.shape == (640 * 640,)
+    assert window.data_ptr() == packed[2].data_ptr() and tview.data_ptr() == packed[1].data_ptr() and not tview.is_contiguous()
+    packed[2].fill_(3.0)
+    packed[1].copy_(torch.arange(64).view(8, 8).half())
+    assert float(window.float().mean()) == 3.0 and torch.equal(tview, torch.arange(64).view(8, 8).half().t())
+    ts[1].view(-1)[5] = 9.0
+    assert float(flat_alias[5]) == 9.0
+    # distinct memory is counted once
+    unique = ts + [odd, view, packed]
+    assert arena.payload_bytes == sum(t.numel() * t.element_size() for t in unique)
+    assert arena.bytes >= sum(t.numel() * t.element_size() for t in ts + [packed])
     # writing through the arena IS writing the tensors (what the in-place broadcast relies on)
     f16.zero_()
-    assert all(float(t.abs().sum()) == 0 for t in ts[:4]) and float(ts[4].sum()) == 15.0
+    assert all(float(t.abs().sum()) == 0 for t in ts[:4]) and float(ts[4].sum()) == 15.0 and float(window.abs().sum()) == 0
     sl = arena.slices(1 << 10)
-    assert sum(x.numel() * x.element_size() for x in sl[:-2]) == arena.bytes and sl[-2] is odd and sl[-1] is view
+    assert sum(x.numel() * x.element_size() for x in sl) == arena.bytes and all(x.is_contiguous() for x in sl)
+
+
+def test_weight_arena_segments_bound_the_transient_copy():
+    """Segments: the arena is filled in pieces of at most `segment_bytes` (1 GiB in production), so re-homing never holds a
+    second copy of all weights; a tensor larger than a segment gets a segment of its own."""
+    from diffsensei_amd.distributed import WeightArena
+    ts = [torch.full((1000,), float(i)).half() for i in range(10)] + [torch.ones(5000).half()]
+    arena = WeightArena(ts, segment_bytes=4096)                   # 2 x 2048-byte slots per segment
+    segs = arena.buffers[(torch.device("cpu"), torch.float16)]
+    assert len(segs) == 6 and [s.numel() * 2 for s in segs[:5]] == [4096] * 5 and segs[5].numel() >= 5000
+    assert all(float(t[0]) == float(i) for i, t in enumerate(ts[:10])) and float(ts[10].sum()) == 5000
+    assert sum(x.numel() for x in arena.slices(1 << 20)) * 2 == arena.bytes
+
+
+def _loose_worker(rank, world, port, q):
+    """A non-contiguous tensor, a view of unlisted storage, a view of a LISTED tensor and a re-shaped alias all arrive
+    intact on rank 1 (RCCL / NCCL raise "Tensors must be contiguous" for the first one if it is sent as it is)."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from diffsensei_amd.distributed import broadcast_tensors, init_from_env
+    init_from_env("gloo")
+    g = torch.Generator().manual_seed(3)
+    mk = lambda *s: torch.randn(*s, generator=g).half() if rank == 0 else torch.full(s, -1.0).half()
+    plain = mk(33, 7)
+    odd = mk(8, 6).t()                                            # not contiguous
+    hidden_base = mk(3, 16, 16)
+    view = hidden_base[1]                                         # base not listed
+    packed = mk(4, 8, 8)
+    window, alias = packed[2].t(), packed.view(-1)                # base listed
+    f32odd = (torch.randn(5, 4, generator=g) if rank == 0 else torch.zeros(5, 4)).t()
+    lst = [plain, odd, view, packed, window, alias, f32odd]
+    stats = broadcast_tensors(lst, src=0, bucket_bytes=1 << 10)
+    g2 = torch.Generator().manual_seed(3)
+    exp = lambda *s: torch.randn(*s, generator=g2).half()
+    e_plain, e_odd, e_base, e_packed = exp(33, 7), exp(8, 6).t(), exp(3, 16, 16), exp(4, 8, 8)
+    e_f32 = torch.randn(5, 4, generator=g2).t()
+    ok = torch.equal(plain, e_plain) and torch.equal(odd, e_odd) and torch.equal(view, e_base[1]) and torch.equal(packed, e_packed)
+    ok = ok and torch.equal(window, e_packed[2].t()) and torch.equal(alias, e_packed.view(-1)) and torch.equal(f32odd, e_f32)
+    ok = ok and torch.equal(hidden_base[1], e_base[1]) and window.data_ptr() == packed[2].data_ptr()
+    if rank == 1:
+        ok = ok and float(hidden_base[0].float().mean()) == -1.0   # only the listed window of the hidden base was written
+    dist.barrier()
+    q.put((rank, ok, stats["buckets"], stats["bytes"]))
+    dist.destroy_process_group()
+
+
+def test_broadcast_non_contiguous_and_views_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_loose_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, ok0, nb0, by0), (_, ok1, nb1, by1) = res
+    assert ok0 and ok1 and nb0 == nb1 and nb0 >= 3
+    # payload: plain + odd + view + packed + f32odd, the window / alias of `packed` counted once with it
+    assert by0 == by1 == (33 * 7 + 48 + 256 + 256) * 2 + 20 * 4
+
+
+def test_broadcast_pipeline_requires_weights_changed_of_every_engine():
+    """an engine that lists `tensors()` but has no `weights_changed()` would keep stale raw-pointer caches silently
+    after the re-homing broadcast - `broadcast_pipeline` refuses it (no process group needed for the check); every engine of
+    the package defines the hook."""
+    import pytest
+    from diffsensei_amd.distributed import broadcast_pipeline
+    from diffsensei_amd import encoders, mllm, resampler, unet, vae
+
+    class NoHook:
+        def tensors(self):
+            return [torch.zeros(3)]
+
+    class Pipe:
+        unet = NoHook()
+
+        def tensors(self):
+            return self.unet.tensors()
+
+    with pytest.raises(TypeError, match="weights_changed"):
+        broadcast_pipeline(Pipe())
+    for cls in (encoders.ViTEncoderEngine, encoders.ClipTextEngine, resampler.Resampler, unet.UNetMangaModel,
+                vae.VaeDecoderEngine, mllm.LlamaDecodeEngine, mllm.QwenResampler, mllm.ContinuousLVLM):
+        assert callable(getattr(cls, "weights_changed", None)) and callable(getattr(cls, "tensors", None)), cls

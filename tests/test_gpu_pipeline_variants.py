@@ -320,3 +320,30 @@ def test_mllm_prepass_end_to_end(pipe):
             latents=lat0.clone(), **common).images
     ref_lat = _oracle(cfg, sd, rs, clip, mae, common, [], boxes, [], 1, lat0, ip_embeds=hq(want))
     assert _rel(out, ref_lat) <= 5e-2, _rel(out, ref_lat)
+
+
+def test_callback_may_return_replaced_latents(pipe):
+    """diffusers' `callback_on_step_end` contract [3P] (`latents = callback_outputs.pop("latents", latents)`): a hook that
+    RETURNS new latents must have the same effect as one that edits the tensor it was handed in place; hooks that
+    return nothing / the dict they got change nothing; unknown `callback_on_step_end_tensor_inputs` are refused."""
+    p, cfg, sd, rs, clip, mae, common = pipe
+    lat0 = torch.randn(1, 4, 16, 16, generator=torch.Generator().manual_seed(21))
+    kw = dict(common, ip_images=[], ip_bbox=[], latents=lat0)
+    base = p(**kw).images.clone()
+
+    def in_place(pp, i, t, d):
+        if i == 0:
+            d["latents"].mul_(0.5)
+
+    def returned(pp, i, t, d):
+        return {"latents": d["latents"] * 0.5} if i == 0 else {}
+
+    def passthrough(pp, i, t, d):
+        return d
+
+    a = p(callback_on_step_end=in_place, **kw).images.clone()
+    b = p(callback_on_step_end=returned, callback_on_step_end_tensor_inputs=["latents"], **kw).images.clone()
+    c = p(callback_on_step_end=passthrough, **kw).images.clone()
+    assert torch.equal(a, b) and not torch.equal(a, base) and torch.equal(c, base)
+    with pytest.raises(ValueError):
+        p(callback_on_step_end=passthrough, callback_on_step_end_tensor_inputs=["prompt_embeds"], **kw)

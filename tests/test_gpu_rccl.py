@@ -131,3 +131,107 @@ def test_rccl_broadcast_arena_rate_world1(hip_lib):
         assert stats["seconds"] * 1e3 <= 250.0 * gb / 9.0, stats
     finally:
         dist.destroy_process_group()
+
+
+def _two_rank_main(rank, world, port, q):
+    """One serving process of a 2-GPU node, started the way the driver's `torch.distributed.run` starts bench.py ranks."""
+    import sys
+    import traceback
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)          # `init_from_env` must default it before the first device call
+    try:
+        import numpy as np
+        import torch
+        import torch.distributed as dist
+        from diffsensei_amd.distributed import (PanelRequest, broadcast_pipeline, init_from_env, run_sharded,
+                                                tensors_checksum, verify_replicas)
+        from diffsensei_amd.pipeline import DiffSenseiPipeline
+        from diffsensei_amd.resampler import Resampler
+        from diffsensei_amd.schedulers import EulerDiscreteScheduler
+        from diffsensei_amd.unet import UNetMangaModel
+        from diffsensei_amd.unet_config import tiny_config
+        from diffsensei_amd.vae import VaeConfig, VaeDecoderEngine
+        r, w, local = init_from_env("nccl")
+        assert (r, w, local) == (rank, world, rank) and os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+        assert dist.get_backend() == "nccl" and torch.cuda.current_device() == rank
+        dev = torch.device("cuda", local)
+        cfg = tiny_config()
+        unet = UNetMangaModel(cfg, device=dev).init_random(1 + 10 * rank)            # ranks start from DIFFERENT weights
+        rs = Resampler(dim=128, depth=2, dim_head=64, heads=2, num_queries=16, num_dummy_tokens=16, embedding_dim=160,
+                       magi_embedding_dim=128, output_dim=cfg.cross_attention_dim, ff_mult=4, device=dev).init_random(5 + rank)
+        vae = VaeDecoderEngine.init_random(VaeConfig(block_out_channels=(128, 128, 256, 512), layers_per_block=1), 3 + rank, dev)
+        from transformers import CLIPVisionConfig, CLIPVisionModel, ViTMAEConfig, ViTMAEModel
+        torch.manual_seed(100 + rank)
+        clip = CLIPVisionModel(CLIPVisionConfig(hidden_size=160, intermediate_size=320, num_hidden_layers=3, num_attention_heads=2,
+                                                image_size=224, patch_size=14, hidden_act="quick_gelu")).eval()
+        mae = ViTMAEModel(ViTMAEConfig(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                                       image_size=224, patch_size=16, mask_ratio=0.0)).eval()
+        pipe = DiffSenseiPipeline(vae, None, None, None, None, EulerDiscreteScheduler(), unet, clip)
+        pipe.register_manga_modules(magi_image_encoder=mae, image_proj_model=rs)
+        before = int(tensors_checksum(pipe.tensors())[0])
+        stats = broadcast_pipeline(pipe)                                              # RCCL broadcast over xGMI + checksum
+        after = int(tensors_checksum(pipe.tensors())[0])
+        verify_replicas(pipe.tensors())
+        g = torch.Generator().manual_seed(9)
+        kw = dict(prompt="a", height=128, width=128, num_inference_steps=2, guidance_scale=7.5, ip_images=[], ip_bbox=[],
+                  prompt_embeds=torch.randn(1, 77, cfg.cross_attention_dim, generator=g).half(),
+                  pooled_prompt_embeds=torch.randn(1, 128, generator=g).half())
+        lat0 = torch.randn(1, 4, 16, 16, generator=g).half()
+        lat = pipe(latents=lat0.clone(), output_type="latent", **kw).images
+        both = [torch.empty_like(lat) for _ in range(world)]
+        dist.all_gather(both, lat.contiguous())
+        same = bool(torch.equal(both[0], both[1]))                                    # identical replicas -> identical panels
+
+        def work(req):                                                                # no data-path collective: a rank's own panels
+            seed_lat = torch.randn(1, 4, 16, 16, generator=torch.Generator().manual_seed(req.request_id)).half()
+            return pipe(latents=seed_lat, output_type="pil", **kw).images
+
+        out = run_sharded([PanelRequest(i, 128, 128, 2, 1) for i in range(4)], work, gather=True)
+        info = None
+        if rank == 0:
+            info = {k: (type(v[0]).__name__, tuple(v[0].shape), str(v[0].dtype), float(np.std(v[0]))) for k, v in out.items()}
+        perturbed = False
+        if rank == 1:
+            pipe.tensors()[0].view(-1)[0] += 1.0
+        try:
+            verify_replicas(pipe.tensors())
+        except RuntimeError:
+            perturbed = True
+        dist.barrier()
+        q.put((rank, "ok", before, after, stats["bytes"], stats["seconds"], same, info, perturbed))
+        dist.destroy_process_group()
+    except Exception:
+        q.put((rank, "error", traceback.format_exc()))
+        raise
+
+
+@pytest.mark.timeout(600)
+def test_rccl_two_ranks_broadcast_and_sharded_serving(hip_lib):
+    """FIRST CONTACT OF RCCL WITH MORE THAN ONE RANK.  Needs two GPUs: skipped on the 1-GPU development box,
+    runs on the driver's multi-GPU node.  Two processes started with the torchrun environment: `init_from_env` (with the
+    dmabuf-IPC default it sets itself), `broadcast_pipeline` of a whole tiny pipeline from rank 0 (the ranks are seeded
+    differently on purpose), `verify_replicas` over RCCL all-reduce, the same request giving bit-identical latents on both GPUs,
+    `run_sharded` returning every panel to rank 0 as uint8 arrays, and a perturbed replica being detected on BOTH ranks."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip(f"needs >= 2 GPUs for a 2-rank RCCL group, this box has {torch.cuda.device_count()}")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_two_rank_main, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=480) for _ in procs])
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == "ok" for r in res), res
+    (_, _, b0, a0, by0, s0, same0, info0, pert0), (_, _, b1, a1, by1, s1, same1, info1, pert1) = res
+    assert b0 != b1 and a0 == a1 == b0                             # rank 1 now holds rank 0's weights, rank 0 unchanged
+    assert by0 == by1 > 0 and same0 and same1
+    assert sorted(info0) == [0, 1, 2, 3] and info1 is None
+    for name, shape, dtype, std in info0.values():
+        assert name == "ndarray" and shape == (128, 128, 3) and dtype == "uint8" and std > 0
+    assert pert0 and pert1
+    print(f"2-rank RCCL: {by0 / 1e6:.1f} MB broadcast in {max(s0, s1) * 1e3:.1f} ms")

@@ -204,11 +204,12 @@ def test_unet_sdxl_forward_vs_oracle_1024(sdxl_model):
     """PARITY AT THE METRIC'S SHAPE (BASELINE.json metric / configs[1], [2]): full SDXL-size weights, 1024x1024
     (128x128 latents), CFG batch 2, 2 character boxes + 2 dialog boxes - the HIP launch plan vs the CPU oracle with
     fp16-storage emulation, relative L2 <= 2e-2 (reference path: src/pipelines/pipeline_diffsensei.py:322-329 ->
-    src/models/unet.py:116-347).  Then the SAME two rows inside the benchmark's UNet batch of 32 (rows 0..15 = the
-    unconditional row, 16..31 = the conditional row): the batch-32 launch plan dispatches to the large-problem kernels
-    (gemm_pp at M = 32768 / 131072, conv_halo256, self_attn_kernel<2>, the N = 4096 masked-IP grid), and its rows 0 / 16 must
-    reproduce the oracle-checked B = 2 result (<= 2e-3 relative L2; bit-equality is reported), tying the benched dispatch
-    paths to the oracle-checked ones."""
+    src/models/unet.py:116-347).  Then the SAME two rows inside UNet batches of 32 and of 64 - 64 is the batch `python bench.py`
+    runs (num_samples 32; rows 0..31 = the unconditional row, 32..63 = the conditional row): those launch plans dispatch to
+    the large-problem kernels (gemm_pp at M = 65536 / 262144 with the V^T projections folded into the persistent walk at
+    nbatch 64, conv_halo256, self_attn_sp_kernel, the N = 4096 masked-IP grid; single activation tensors reach 1.3 GB), and
+    their rows must reproduce the oracle-checked B = 2 result (<= 2e-3 relative L2; bit-equality is reported) and each other
+    bit for bit inside a batch, tying the BENCHED dispatch to the oracle-checked one."""
     from oracle.unet_ref import UNetOracle
     cfg, m = sdxl_model
     x, enc, te, tid, bbox, db = _inputs(cfg, 2, 128, 128, seed=13)
@@ -227,14 +228,28 @@ def test_unet_sdxl_forward_vs_oracle_1024(sdxl_model):
     print(f"SDXL 1024x1024: batch-32 rows vs batch-2 rows rel-L2 {d0:.3e} / {d1:.3e}, bit-equal: "
           f"{torch.equal(y32[0], y[0]) and torch.equal(y32[16], y[1])}")
     assert d0 <= 2e-3 and d1 <= 2e-3, (d0, d1)
+    # ---- batch 64 = the benchmark's own UNet batch (bench.py: num_samples 32, CFG): rows replicated 32x per CFG half
+    rep64 = lambda t: torch.cat([t[:1].repeat(32, *([1] * (t.dim() - 1))), t[1:].repeat(32, *([1] * (t.dim() - 1)))])
+    y64 = m(rep64(x).to(DEV), 801.0, rep64(enc).to(DEV), **kw(rep64(bbox), rep64(te), rep64(tid), rep64(db))).sample
+    assert y64.shape == (64, 4, 128, 128) and torch.isfinite(y64).all()
+    for r in range(64):
+        assert torch.equal(y64[r], y64[0 if r < 32 else 32]), f"row {r} of the batch-64 forward differs from its replica"
+    e0, e1 = _rel(y64[0], y[0]), _rel(y64[32], y[1])
+    print(f"SDXL 1024x1024: batch-64 rows vs batch-2 rows rel-L2 {e0:.3e} / {e1:.3e}, bit-equal to the batch-32 rows: "
+          f"{torch.equal(y64[0], y32[0]) and torch.equal(y64[32], y32[16])}")
+    assert e0 <= 2e-3 and e1 <= 2e-3, (e0, e1)
+    y64 = torch.stack([y64[0], y64[32]]).clone()
+    torch.cuda.empty_cache()
     # ---- oracle (one forward, ~1 min on the GPU box's host cores)
     sd = {k: v.float().cpu() for k, v in m.state_dict().items()}
     with torch.no_grad():
         o16 = UNetOracle(cfg, sd, q=hq)
         o16.ip_scale = 0.6
         r16 = o16.forward(x, 801.0, enc, te, tid, bbox, 1.0, db)
-    e2, e32 = _rel(y, r16), _rel(torch.stack([y32[0], y32[16]]), r16)
-    print(f"SDXL 1024x1024 forward: rel-L2 vs fp16-storage oracle: batch 2 {e2:.3e}, rows of batch 32 {e32:.3e}")
+    e2, e32, e64 = _rel(y, r16), _rel(torch.stack([y32[0], y32[16]]), r16), _rel(y64, r16)
+    print(f"SDXL 1024x1024 forward: rel-L2 vs fp16-storage oracle: batch 2 {e2:.3e}, rows of batch 32 {e32:.3e}, "
+          f"rows of batch 64 (the benched batch) {e64:.3e}")
     assert e2 <= 2e-2, e2
     assert e32 <= 2e-2, e32
+    assert e64 <= 2e-2, e64
     assert _rel(y[1], y[0]) > 1e-3

@@ -201,3 +201,74 @@ def test_decoder_uint8_parity_where_fp16_would_overflow(hip_lib):
     rel, gt1, mx, _ = out["fp16-scaled"]
     assert torch.isfinite(got).all() and ref8.std() > 5
     assert rel <= 3e-3 and gt1 <= 1e-3 and mx <= 2, out
+
+
+def test_vae_decode_1024_vs_oracle(hip_lib):
+    """PARITY OF THE VAE LEG AT THE BENCHED SIZE (reference src/pipelines/pipeline_diffsensei.py:339-367:
+    the reference upcasts the VAE to fp32 and decodes there).  One 128 x 128 latent -> 1024 x 1024 image on the fp32 CPU oracle
+    (10.5 TFLOP, mid-block attention = one head of dim 512 over N = 16 384 tokens) vs `VaeDecoderEngine` in its default
+    scaled-fp16 storage, fed a batch of 8 copies through the pipeline's own call (`scaling_factor`, `denormalize`, device
+    uint8 conversion): 8 images of 1024^2 exceed the conv kernels' 32-bit offsets, so this runs the chunk-of-4 path
+    `python bench.py` runs (32 images = 8 chunks).  Bar: all 8 outputs identical; uint8 image within 1 LSB of the fp32 decode on
+    >= 99.9 % of the bytes (max 2); relative L2 of the float image <= 3e-3."""
+    import numpy as np
+    from diffsensei_amd import ops
+    from diffsensei_amd.vae import VaeConfig, VaeDecoderEngine, random_state_dict
+    from oracle.vae_ref import vae_decode
+    cfg = VaeConfig()
+    sd = {k: v.half().float() for k, v in random_state_dict(cfg, 11).items()}      # both sides: fp16-representable weights
+    eng = VaeDecoderEngine.from_state_dict(sd, cfg, DEV)
+    assert eng.precision == "fp16-scaled"
+    lat = torch.randn(1, 4, 128, 128, generator=torch.Generator().manual_seed(12)) * 0.9
+    got = eng.decode(lat.repeat(8, 1, 1, 1).to(DEV), return_dict=False, scaling_factor=cfg.scaling_factor, denormalize=True)[0]
+    assert got.shape == (8, 3, 1024, 1024) and got.dtype == torch.float32 and torch.isfinite(got).all()
+    for r in range(1, 8):
+        assert torch.equal(got[r], got[0]), f"image {r} of the chunked batch-8 decode differs from image 0"
+    got8 = ops.image_to_u8(got[:4].contiguous()).cpu().numpy()                      # the pipeline's own device conversion
+    assert got8.shape == (4, 1024, 1024, 3) and (got8[1] == got8[0]).all()
+    g0 = got[0].cpu()
+    del got
+    torch.cuda.empty_cache()
+    with torch.no_grad():
+        ref = vae_decode(sd, lat / cfg.scaling_factor, cfg.layers_per_block, cfg.norm_num_groups, cfg.eps)[0]
+    ref01 = (ref / 2 + 0.5).clamp(0, 1)
+    ref8 = (ref01.permute(1, 2, 0).numpy() * 255).round().astype("uint8")
+    d = np.abs(got8[0].astype(np.int16) - ref8.astype(np.int16))
+    rel = ((g0 - ref01).norm() / ref01.norm()).item()
+    print(f"VAE decode 1024x1024 (batch 8 = 2 chunks of 4, scaled fp16) vs the fp32 oracle: rel-L2 {rel:.3e}, bytes differing "
+          f"{(d != 0).mean():.4f}, off by > 1 LSB {(d > 1).mean():.6f}, max {int(d.max())}; image std {ref8.std():.1f} LSB")
+    assert ref8.std() > 5
+    assert rel <= 3e-3, rel
+    assert (d > 1).mean() <= 1e-3 and d.max() <= 2, ((d > 1).mean(), d.max())
+
+
+def test_wide_attention_f16_at_decode_size(hip_lib):
+    """`wide_attn_kernel<half>` - the instantiation the default (scaled-fp16) decoder runs - at the 1024 x 1024 image's own
+    size: ONE head of dim 512 over N = 16 384 tokens, vs fp32 softmax(QK^T / sqrt(512)) V in plain PyTorch (the score matrix
+    is 1 GB in fp32, so the reference is evaluated on the device in row blocks).  Tolerance: max |err| <= 1e-2 max|ref|
+    (fp16 operands and P, fp32 accumulation), relative L2 <= 2e-3; also a ragged key count (n_valid < N)."""
+    from diffsensei_amd import ops
+    g = torch.Generator().manual_seed(16384)
+    N, C = 16384, 512
+    q = (torch.randn((1, N, C), generator=g)).half()
+    k = (torch.randn((1, N, C), generator=g)).half()
+    v = (torch.randn((1, N, C), generator=g)).half()
+    scale = 1 / math.sqrt(C)
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+
+    def ref_rows(nv):
+        out = torch.empty((N, C), dtype=torch.float32, device=DEV)
+        kf, vf = kd[0, :nv].float(), vd[0, :nv].float()
+        for i in range(0, N, 2048):
+            s = (qd[0, i:i + 2048].float() @ kf.t()) * scale
+            out[i:i + 2048] = torch.softmax(s, -1) @ vf
+        return out.cpu()
+
+    vt = vd.transpose(1, 2).contiguous()
+    for nv in (0, N - 24):
+        got = ops.wide_attention_f16(qd, kd, vt, scale, n_valid=nv)[0].float().cpu()
+        ref = ref_rows(nv if nv else N)
+        _close(got, ref, tol=1e-2, what=f"wide attention f16 N={N} n_valid={nv}")
+        rel = ((got - ref).norm() / ref.norm()).item()
+        print(f"wide_attn_kernel<half> N = {N}, n_valid = {nv or N}: rel-L2 {rel:.3e}")
+        assert rel <= 2e-3, rel

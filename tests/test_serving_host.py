@@ -23,6 +23,16 @@ def test_plan_batches_buckets_and_caps():
         plan_batches([_req(512, 8)], max_panels=4)
 
 
+def test_pixel_cap_shapes_packing_not_single_requests():
+    """with the 32 Mpx default a 2048 x 2048 request of 9..16 samples is above the pixel cap (8 panels); it must
+    still be served - alone - as it was before the cap existed; only `num_samples > max_panels` is an error."""
+    reqs = [_req(2048, 12), _req(2048, 2), _req(2048, 5), _req(2048, 2), _req(512, 20)]
+    plan = plan_batches(reqs, max_panels=32, max_pixels=32 * 1024 * 1024)
+    assert plan[:3] == [[0], [1, 2], [3]] and plan[3] == [4]      # 12 alone; 2 + 5 <= 8 packed; 2 after the flush; 512: cap 32
+    with pytest.raises(ValueError):
+        plan_batches([_req(2048, 33)], max_panels=32, max_pixels=32 * 1024 * 1024)
+
+
 def test_batcher_routes_results_by_ticket():
     calls = []
 
