@@ -24,7 +24,7 @@ class DsOp(C.Structure):
 OP = dict(GEMM=1, CONV3X3=2, GROUPNORM=3, LAYERNORM=4, SELF_ATTN=5, IP_ATTN=6, CONV_IN=7, CONV_OUT=8, SKINNY=9,
           TIMESTEP_EMBED=10, ADD_TIME_IDS=11, SAMPLER_STEP=12, PREP_INPUT=13, ADVANCE=14, NHWC2NCHW=15, NCHW2NHWC=16,
           PAD_ROWS=17, SMALL_ATTN=18, LLM_GEMV=19, LLM_ATTN=20, LLM_RMSNORM=21, LLM_EMBED=22, LLM_SELECT=23,
-          LLM_ADVANCE=24, QUANT_FP8=25, SELF_ATTN_FP8=26)
+          LLM_ADVANCE=24, QUANT_FP8=25, SELF_ATTN_FP8=26, LN_FINALIZE=27)
 
 # name -> (restype, argtypes).  Every symbol declared in include/diffsensei_hip.h appears here;
 # tests/test_capi_symbols.py checks the two lists against each other.
@@ -34,6 +34,10 @@ SIGNATURES = {
     "ds_device_info": (i32, [C.POINTER(i32), C.POINTER(i32), C.c_char_p, i32]),
     "ds_set_option": (i32, [C.c_char_p, i32]),
     "ds_gemm_f16": (i32, [vp, i64, vp, i64, i32, vp, i64, vp, vp, i64, vp, i64, i32, i32, i32, i32, vp]),
+    "ds_gemm_ln_f16": (i32, [vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp, i32, i32, i32, i32, vp]),
+    "ds_ln_finalize": (i32, [vp, vp, i32, i32, i32, f32, vp]),
+    "ds_gemm_ln_fusable": (i32, [i32, i32, i32, i32, i32]),
+    "ds_gemm_ln_swapped_f16": (i32, [vp, i64, vp, i64, i64, vp, i64, vp, vp, i64, i64, i32, i32, i32, i32, vp]),
     "ds_gemm_f16_batched": (i32, [vp, i64, i64, vp, i64, i64, vp, i64, i64, i32, i32, i32, i32, vp]),
     "ds_conv3x3_f16": (i32, [vp, vp, vp, vp, i64, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "ds_conv3x3_resize_f16": (i32, [vp, vp, vp, vp, i64, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),

@@ -49,8 +49,10 @@ def _digest(extra=()) -> str:
 
 def build(force: bool = False, verbose: bool = True, ablation: bool = False) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
-    lib = LIB
-    stamp = os.path.join(LIBDIR, "build.stamp")
+    # the ablation build (extra template instantiations behind -DDS_ABLATION) is a SEPARATE library, selected per process with
+    # DIFFSENSEI_LIB=.../libdiffsensei_hip_ablation.so: the production library is never replaced by it
+    lib = LIB.replace(".so", "_ablation.so") if ablation else LIB
+    stamp = os.path.join(LIBDIR, "build_ablation.stamp" if ablation else "build.stamp")
     flags = FLAGS + (["-DDS_ABLATION"] if ablation else [])
     sources = SOURCES
     dig = _digest() + ("+ablation" if ablation else "")
@@ -60,7 +62,7 @@ def build(force: bool = False, verbose: bool = True, ablation: bool = False) -> 
     objs = []
 
     def compile_one(src):
-        obj = os.path.join(LIBDIR, os.path.basename(src).replace(".hip", ".o"))
+        obj = os.path.join(LIBDIR, os.path.basename(src).replace(".hip", "_abl.o" if ablation else ".o"))
         cmd = [hipcc, *flags, "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:

@@ -94,6 +94,34 @@ int ds_gemm_f16(const void* x, int64_t ldx, const void* x2, int64_t ldx2, int k1
     return ds_launch_gemm(p, 1, S(stream));
 }
 
+int ds_gemm_ln_f16(const void* x, int64_t ldx, const void* gw, int64_t ldw, const void* bias_ln, const float* ln_stats,
+                   const void* ln_c, const void* residual, int64_t ldr, void* y, int64_t ldy, float* stats_out, int M, int N,
+                   int K, int epilogue, void* stream) {
+    GemmParams p;
+    p.A = H(x); p.lda = ldx; p.K1 = K; p.W = H(gw); p.ldw = ldw; p.bias = H(bias_ln); p.residual = H(residual); p.ldr = ldr;
+    p.C = HM(y); p.ldc = ldy; p.M = M; p.N = N; p.K = K; p.epi = epilogue;
+    p.ln_stats = ln_stats; p.ln_c = H(ln_c); p.stats_out = stats_out;
+    DS_REQUIRE(ln_stats || stats_out, "ds_gemm_ln_f16: neither row statistics to consume nor to emit - use ds_gemm_f16");
+    return ds_launch_gemm(p, 1, S(stream));
+}
+
+int ds_ln_finalize(const float* partial, float* stats, int M, int strips, int C, float eps, void* stream) {
+    return ds_launch_ln_finalize(partial, stats, M, strips, C, eps, S(stream));
+}
+
+int ds_gemm_ln_swapped_f16(const void* a, int64_t lda, const void* x, int64_t ldx, int64_t sx, const float* ln_stats,
+                           int64_t ln_bstride, const void* ln_cb, void* y, int64_t ldy, int64_t sy, int M, int N, int K,
+                           int batch, void* stream) {
+    GemmParams p;
+    p.A = H(a); p.lda = lda; p.sA = 0; p.K1 = K; p.W = H(x); p.ldw = ldx; p.sW = sx;
+    p.C = HM(y); p.ldc = ldy; p.sC = sy; p.M = M; p.N = N; p.K = K;
+    p.ln_stats = ln_stats; p.ln_c = H(ln_cb); p.ln_swapped = 1; p.ln_bstride = ln_bstride;
+    DS_REQUIRE(ln_stats && ln_cb, "ds_gemm_ln_swapped_f16: statistics and (c, b') are required");
+    return ds_launch_gemm(p, batch, S(stream));
+}
+
+int ds_gemm_ln_fusable(int M, int N, int K, int epilogue, int batch) { return ds_gemm_pp_fast_path(M, N, K, batch, epilogue) ? 1 : 0; }
+
 int ds_gemm_f16_batched(const void* x, int64_t ldx, int64_t sx, const void* w, int64_t ldw, int64_t sw, void* y,
                         int64_t ldy, int64_t sy, int M, int N, int K, int batch, void* stream) {
     GemmParams p;
@@ -426,8 +454,13 @@ static int run_op(const ds_op& o, hipStream_t st) {
             g.M = i[0]; g.N = i[1]; g.K = i[2]; g.K1 = g.A2 ? i[3] : i[2];
             g.epi = i[4];
             g.rowbias_ld = i[6]; g.rows_per_group = i[7] > 0 ? i[7] : 1;
+            g.ln_stats = reinterpret_cast<const float*>(p[7]); g.ln_c = H(p[8]); g.stats_out = reinterpret_cast<float*>(p[9]);
+            g.ln_swapped = i[8]; g.ln_bstride = l[10];
             return ds_launch_gemm(g, i[5] > 0 ? i[5] : 1, st);
         }
+        case DS_OP_LN_FINALIZE:
+            return ds_launch_ln_finalize(reinterpret_cast<const float*>(p[0]), reinterpret_cast<float*>(p[1]), i[0], i[1], i[2],
+                                         o.f[0], st);
         case DS_OP_CONV3X3:
             return conv3x3_impl(p[0], p[1], p[3], p[4], i[7], p[5], p[2], i[0], i[1], i[2], i[3], i[4], i[5], i[6], st,
                                 DS_DTYPE_F16, i[8], i[9]);
@@ -533,6 +566,7 @@ int ds_op_describe(const ds_op* op, char* name, int name_len, double* flops, dou
         case DS_OP_GEMM: {
             GemmParams g;
             g.M = i[0]; g.N = i[1]; g.K = i[2];
+            g.ln_stats = reinterpret_cast<const float*>(op->p[7]); g.stats_out = reinterpret_cast<float*>(op->p[9]);
             const int batch = i[5] > 0 ? i[5] : 1;
             nm = ds_gemm_kernel_name(g, batch);
             fl = 2.0 * i[0] * (double)i[1] * i[2] * batch;
@@ -553,6 +587,7 @@ int ds_op_describe(const ds_op* op, char* name, int name_len, double* flops, dou
         }
         case DS_OP_GROUPNORM: nm = "groupnorm(3 kernels)"; by = 2.0 * 2.0 * i[0] * (double)i[1] * (i[2] + i[3]); break;
         case DS_OP_LAYERNORM: nm = "layernorm_kernel"; by = 2.0 * 2.0 * i[0] * (double)i[1]; break;
+        case DS_OP_LN_FINALIZE: nm = "ln_finalize_kernel"; by = 8.0 * i[0] * (double)(i[1] + 1); break;
         case DS_OP_SELF_ATTN:
             nm = ds_self_attn_kernel_name(i[0], i[1], i[2], i[3]);
             fl = 4.0 * i[0] * (double)i[1] * i[2] * (double)i[3] * 64;

@@ -14,6 +14,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16_t;  // VAE decoder path: fp16 overflows there (the reference upcasts the VAE to fp32)
 typedef __bf16 b8 __attribute__((ext_vector_type(8)));
 typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+typedef __bf16 b2 __attribute__((ext_vector_type(2)));
 
 enum { DS_DTYPE_F16 = 0, DS_DTYPE_BF16 = 1 };
 
@@ -24,6 +25,7 @@ template <>
 struct Elt<half_t> {
     typedef h8 v8;
     typedef h4 v4;
+    typedef h2 v2;
     static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
     }
@@ -32,6 +34,7 @@ template <>
 struct Elt<bf16_t> {
     typedef b8 v8;
     typedef b4 v4;
+    typedef b2 v2;
     static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
     }

@@ -22,6 +22,17 @@ struct GemmParams {
     float up_sy = 0.5f, up_sx = 0.5f;  // upsample: nearest-resize scales float(Hin)/Hout, float(Win)/Wout (ATen's definition)
     int tiles_m = 0, tiles_n = 0;
     int nbatch = 1;  // gemm_pp_kernel only: batch items folded into the persistent tile walk (id -> item, tile); others use grid.z
+    // ---- LayerNorm fused across a producer / consumer pair of gemm_pp_kernel launches (gemm_pp.hip header, "LayerNorm"):
+    // producer: per-row partial sums of the STORED output, one (sum, sum of squares) pair per row and 64-column strip,
+    //           laid out [N / 64][M] (float2); consumer: y = rstd_m * (x_m . gw_n - mu_m c_n) + b'_n with gw = gamma (.) W
+    //           packed at load time, (mu, rstd) per row from ds_launch_ln_finalize, c_n = sum_k gw_nk as a NEGATED f16
+    //           (hi, lo) pair per output column, b' = bias + W beta passed as `bias`.
+    float* stats_out = nullptr;        // producer: [N/64][M] float2 partials (fast plain epilogue, nbatch 1)
+    const float* ln_stats = nullptr;   // consumer: [M] float2 (mu, rstd)
+    const half_t* ln_c = nullptr;      // consumer: [N][2] f16 (-c hi, -c lo), in the (packed) row order of W
+    int ln_swapped = 0;                // consumer, operand-swapped form (V^T = Wv X_b^T): the normalised rows are the rows of W
+                                       // (tile columns): ln_stats[b * ln_bstride + n], ln_c = [M][4] f16 (-c hi, -c lo, b' hi, b' lo)
+    long ln_bstride = 0;               //   rows of the normalised matrix per batch item
     int dtype = DS_DTYPE_F16;  // element type of A / W / C / bias / residual (the pointers are 2-byte opaque): bf16 = VAE path
     int debug = 0;  // ablation only (ds_set_option "gemm_debug"): 1 skip MFMA, 2 skip tile loads — results are garbage
 };
@@ -63,6 +74,9 @@ size_t ds_groupnorm_ws_floats(int B, int C);
 int ds_launch_groupnorm(const GroupNormParams& p, hipStream_t stream);
 int ds_launch_layernorm(const half_t* x, half_t* y, const half_t* gamma, const half_t* beta, int rows, int C,
                         float eps, hipStream_t stream);
+// row statistics of a fused LayerNorm: partial [strips][M] float2 (sum, sum of squares) -> stats [M] float2 (mean, rstd)
+int ds_launch_ln_finalize(const float* partial, float* stats, int M, int strips, int C, float eps, hipStream_t stream);
+bool ds_gemm_pp_fast_path(int M, int N, int K, int batch, int epi);  // gemm.hip: such a GEMM runs gemm_pp_kernel's branch-free epilogues
 
 // ---- attention -------------------------------------------------------------------------------------
 struct SelfAttnParams {

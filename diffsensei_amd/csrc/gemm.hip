@@ -688,7 +688,19 @@ Choice choose(const GemmParams& p, int batch) {
 
 }  // namespace
 
+// Would ds_launch_gemm run this plain f16 GEMM on gemm_pp_kernel with every tile on a branch-free epilogue?  (The launch-plan
+// builder asks before it replaces a LayerNorm launch by the fused producer / consumer pair; small batches keep the LayerNorm.)
+bool ds_gemm_pp_fast_path(int M, int N, int K, int batch, int epi) {
+    GemmParams p;
+    p.M = M; p.N = N; p.K = K; p.lda = K; p.ldw = K; p.ldc = N; p.epi = epi; p.K1 = K;
+    if (M <= 0 || N <= 0 || K <= 0 || M % 256 || N % 256 || batch < 1 || (epi != EPI_NONE && epi != EPI_GEGLU)) return false;
+    if (g_gemm_variant != 0 && g_gemm_variant != 3) return false;
+    if (!ds_gemm_pp_applicable(p)) return false;
+    return g_gemm_variant == 3 || choose(p, batch).kind == K_PP;
+}
+
 const char* ds_gemm_kernel_name(const GemmParams& p, int batch) {
+    if (p.ln_stats || p.stats_out) return "gemm_pp_kernel<0>";
     const Choice c = choose(p, batch);
     const bool conv = p.conv != 0;
     switch (c.kind) {
@@ -724,6 +736,10 @@ int ds_launch_gemm(const GemmParams& p_in, int batch, hipStream_t stream) {
     }
     if (p.epi == EPI_GEGLU) DS_REQUIRE(p.N % 128 == 0, "geglu: packed N (%d) must be a multiple of 128", p.N);
     Choice c = choose(p, batch);
+    if (p.ln_stats || p.ln_c || p.stats_out) {  // fused LayerNorm exists in gemm_pp_kernel only (the caller asked ds_gemm_ln_fusable)
+        DS_REQUIRE(!conv && ds_gemm_pp_applicable(p), "gemm: fused LayerNorm needs the 256 x 256 kernel (M=%d N=%d K=%d)", p.M, p.N, p.K);
+        c.kind = K_PP;
+    }
     if (p.dtype != DS_DTYPE_F16) {  // bf16 (VAE decoder): only the two kernels that are templated on the element type
         if (conv) {
             DS_REQUIRE(ds_conv_halo_applicable(p), "conv3x3 bf16: needs stride 1 and Cin %% 64 == 0");

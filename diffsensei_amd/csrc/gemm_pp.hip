@@ -39,6 +39,19 @@
 //          a hidden value (B0 strip) and its gate (B1 strip), so h * gelu(g) happens in registers.
 // The epilogue transposes 32-row pieces through the wave's private 4 KiB of LDS (swizzled, conflict-free, no
 // barrier) so every global store / residual load is 16 bytes per lane over whole rows.
+//
+// LayerNorm (round 4; the three LayerNorms of a BasicTransformerBlock [3P], reached from src/models/unet.py:244-338, were
+// stand-alone passes: read h, write LN(h), 76 us each at UNet batch 64).  The normalisation is folded into the GEMM pair
+// around it instead:
+//   producer (the +residual projection that writes h): the branch-free plain epilogue also emits, per row and 64-column
+//     strip, the (sum, sum of squares) of the f16 values it stores (`stats_out`, [N/64][M] float2; 8-lane DPP butterfly in
+//     the row-contiguous layout the stores already use); a 5-us launch (`ln_finalize_kernel`) turns them into (mean, rstd);
+//   consumer: A is the RAW h (the LDS-DMA staging cannot transform it), W is gamma (.) W packed at load time, and
+//     LN(h) W^T + b = rstd_m (h_m . gw_n - mean_m c_n) + b'_n with c_n = sum_k gw_nk, b' = b + W beta.  The rank-1 term is
+//     ONE extra MFMA per 32 x 32 accumulator block (k slots {-c hi, -c lo, -c hi} x {mean hi, mean hi, mean lo} in f16
+//     pairs: the product is exact to 2^-22) and the row factor is the multiplier of the fma that used to be the bias add -
+//     in this kernel a lane owns a tile ROW, so rstd is a per-lane scalar.  The tile's statistics / c slices are LDS-DMA
+//     pieces staged with the tile's first k-tiles, like the bias.
 #include "ds_common.h"
 #include "ds_kernels.h"
 
@@ -59,6 +72,13 @@ struct IC {
     static constexpr int value = V;
 };
 
+// v_mov_b32 with a DPP control: 0xB1 = quad_perm [1,0,3,2] (lane ^ 1), 0x4E = quad_perm [2,3,0,1] (lane ^ 2),
+// 0x141 = row_half_mirror (lane j of every 8 <-> lane 7 - j)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
 #define PP_FENCE()                               \
     do {                                         \
         asm volatile("" ::: "memory");           \
@@ -76,7 +96,10 @@ struct IC {
         if constexpr ((DBG & 8) == 0) __builtin_amdgcn_s_setprio(v); \
     } while (0)
 
-template <typename T, int DBG>  // T: half_t (UNet) or bf16_t (VAE decoder).  DBG: ablation builds only: 1 = no MFMA, 2 = no tile loads, 4 = no fragment reads (garbage results), 8 = no s_setprio, 16 = clock probe written over C[0..15]; 0 in production
+// FUSE (fused LayerNorm, see the header): 0 none - the instantiation every other GEMM runs, its code is untouched by the
+// feature; 1 consumer (statistics + c pieces, one extra MFMA per accumulator block, rstd in the bias fma); 2 producer (row
+// statistics out of the plain epilogue).  Separate instantiations because the kernel sits exactly at its 256-register budget.
+template <typename T, int DBG, int FUSE = 0>  // T: half_t (UNet) or bf16_t (VAE decoder).  DBG: ablation builds only: 1 = no MFMA, 2 = no tile loads, 4 = no fragment reads (garbage results), 8 = no s_setprio, 16 = clock probe written over C[0..15]; 0 in production
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     typedef typename Elt<T>::v8 V8;
     typedef typename Elt<T>::v4 V4;
@@ -181,11 +204,34 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
         const int col = geglu ? tn0 + (wc >> 1) * 128 + (wc & 1) * 32 + (l7 >> 2) * 64 + (l7 & 3) * 8 : tn0 + wc * 64 + l7 * 8;
         __builtin_amdgcn_global_load_lds((glb_void*)(p.bias + col), (lds_void*)ep, 16, 0, 0);
     };
-    auto pad_tail = [&]() {  // EX_TAIL harmless pieces into the idle upper 3 KiB of `ep`
+    auto pad_tail = [&]() {  // EX_TAIL harmless pieces into the idle last KiB of `ep` (KiB 1 and 2 hold the LayerNorm pieces)
 #pragma unroll
         for (int j = 0; j < EX_TAIL; ++j)
             __builtin_amdgcn_global_load_lds((glb_void*)(reinterpret_cast<const char*>(gA[0]) + (size_t)oA[0]),
-                                             (lds_void*)(ep + 1024 + (j % 3) * 1024), 16, 0, 0);
+                                             (lds_void*)(ep + 3072), 16, 0, 0);
+    };
+    // Fused LayerNorm, consumer side: two more LDS-DMA pieces per tile, issued where the bias piece is -
+    //   ep + 1024: (-c hi, -c lo) of the wave's 64 output columns, 4 bytes each, in accumulator-strip order (lanes 16.. repeat);
+    //   ep + 2048: (mean, rstd) of the wave's 128 rows, 8 bytes each: rows 64 wr.. at +0, rows 128 + 64 wr.. at +512.
+    auto stage_ln = [&](int tm0, int tn0, int tbz) {
+        const int ln = lane_id();
+        if constexpr ((FUSE & 4) != 0) {
+            // operand-swapped form (V^T = Wv X_b^T: the normalised rows are the rows of W, i.e. the tile COLUMNS):
+            //   ep + 1024: (mean, rstd) of the wave's 64 output columns = rows tbz * ln_bstride + tn0 + 64 wc .. of the
+            //              normalised matrix, 8 bytes each (lanes 32.. repeat);
+            //   ep + 2048: (-c hi, -c lo, b' hi, b' lo) of the wave's 128 output rows, 8 bytes each, laid out like the
+            //              statistics of the row form.
+            const long col = (long)tbz * p.ln_bstride + tn0 + wc * 64 + (ln & 31) * 2;
+            __builtin_amdgcn_global_load_lds((glb_void*)(p.ln_stats + 2 * col), (lds_void*)(ep + 1024), 16, 0, 0);
+            const int row = tm0 + (ln >> 5) * 128 + wr * 64 + (ln & 31) * 2;
+            __builtin_amdgcn_global_load_lds((glb_void*)(p.ln_c + 4 * (long)row), (lds_void*)(ep + 2048), 16, 0, 0);
+        } else {
+            const int L = ln & 15;
+            const int col = geglu ? tn0 + (wc >> 1) * 128 + (wc & 1) * 32 + (L >> 3) * 64 + (L & 7) * 4 : tn0 + wc * 64 + L * 4;
+            __builtin_amdgcn_global_load_lds((glb_void*)(p.ln_c + 2 * (long)col), (lds_void*)(ep + 1024), 16, 0, 0);
+            const int row = tm0 + (ln >> 5) * 128 + wr * 64 + (ln & 31) * 2;
+            __builtin_amdgcn_global_load_lds((glb_void*)(p.ln_stats + 2 * (long)row), (lds_void*)(ep + 2048), 16, 0, 0);
+        }
     };
 
     // ---- fragment addresses: row r of a half-tile at r*128, 16-byte chunk c at ((c ^ ((r>>1)&7)) << 4)
@@ -324,6 +370,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     derive_stage();
     stage_prologue();
     if (p.bias && is_fast(m0, n0)) stage_bias(n0);
+    if constexpr ((FUSE & 5) != 0) stage_ln(m0, n0, bz);
     pad_tail();  // no epilogue yet behind the first prologue
     while (true) {
 #pragma unroll
@@ -368,13 +415,82 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
         // bias or residual load - loads, converts and stores ran strictly one after the other (4-8 us per tile, all of
         // it with the matrix pipe idle).  Here the bias values are fetched once per tile, and the residual loads of a
         // 32-row piece are in flight while the previous piece is transposed through LDS and stored.
-        const bool fast = is_fast(cm0, cn0);
+        // (the fused-LayerNorm instantiations only ever see interior tiles without a row bias: the launcher checks it, and the
+        // generic epilogues are not compiled into them - the kernel has no registers to spare for paths it never takes)
+        const bool fast = FUSE != 0 ? true : is_fast(cm0, cn0);
         const int nwg = cn0 + (wc >> 1) * 128 + (wc & 1) * 32;  // GEGLU: the wave's hidden strip; its gates 64 columns further
         const int nwp = cn0 + wc * 64;                          // plain: the wave's 64 adjacent columns
         // The bias slice of this tile has been sitting in the first 128 bytes of the wave's transposition tile since the
         // tile's first k-tiles (`stage_bias`): reading it is an LDS read.  (Loaded from memory here, its wait - vmcnt
         // retires in issue order - either drained the next tile's prologue or, requested ahead of it, was turned into a
         // vmcnt(0) by the compiler all the same.)  Kept packed: the accumulators still occupy 128 registers.
+        // Fused LayerNorm (consumer): the rank-1 term - mean_m c_n goes into the accumulators as ONE more MFMA per 32 x 32
+        // block; rstd_m (the lane's own tile row) becomes the multiplier of the bias fma below.
+        if constexpr ((FUSE & 1) != 0) {
+            V8 cf[2];
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const auto cc = *reinterpret_cast<const typename Elt<T>::v2*>(ep + 1024 + (ni * 32 + l31) * 4);
+                const T z = (T)0.f;
+                cf[ni] = V8{cc[0], cc[1], cc[0], z, z, z, z, z};
+                if (lhi) cf[ni] = V8{z, z, z, z, z, z, z, z};
+            }
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {  // one row block at a time: 4 + 8 fragment registers live beside the accumulators
+                const f32x2 st = *reinterpret_cast<const f32x2*>(ep + 2048 + ((mi >> 1) * 64 + (mi & 1) * 32 + l31) * 8);
+                const T z = (T)0.f, mh = (T)st[0], ml = (T)(st[0] - (float)mh);
+                V8 mf = V8{mh, mh, ml, z, z, z, z, z};
+                if (lhi) mf = V8{z, z, z, z, z, z, z, z};
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = Elt<T>::mfma(cf[ni], mf, acc[mi][ni]);
+                asm volatile("" : "+v"(mf));   // keep the blocks in sequence (the scheduler would hoist all four fragment builds)
+            }
+            // rstd of the lane's own tile row, applied to the accumulators in place: no register stays live across the
+            // epilogue for it, and the epilogues below are the unfused ones (acc + b')
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const float rs = *reinterpret_cast<const float*>(ep + 2048 + ((mi >> 1) * 64 + (mi & 1) * 32 + l31) * 8 + 4);
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mi][ni][r] *= rs;
+            }
+        }
+        if constexpr ((FUSE & 4) != 0) {
+            // operand-swapped form: the statistics run along the tile columns (first MFMA operand), c and b' along the rows
+            V8 mfc[2];
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const float mu = *reinterpret_cast<const float*>(ep + 1024 + (ni * 32 + l31) * 8);
+                const T z = (T)0.f, mh = (T)mu, ml = (T)(mu - (float)mh);
+                mfc[ni] = V8{mh, mh, ml, z, z, z, z, z};
+                if (lhi) mfc[ni] = V8{z, z, z, z, z, z, z, z};
+            }
+            float brow[4];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const V4 cb = *reinterpret_cast<const V4*>(ep + 2048 + ((mi >> 1) * 64 + (mi & 1) * 32 + l31) * 8);
+                const T z = (T)0.f;
+                V8 cfr = V8{cb[0], cb[1], cb[0], z, z, z, z, z};
+                if (lhi) cfr = V8{z, z, z, z, z, z, z, z};
+                brow[mi] = (float)cb[2] + (float)cb[3];
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = Elt<T>::mfma(mfc[ni], cfr, acc[mi][ni]);
+                asm volatile("" : "+v"(cfr));
+            }
+            // y = rstd_n acc + b'_m: register r of strip ni is tile column (r & 3) + 8 (r >> 2) + 4 lhi of the strip
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                float rs[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    rs[r] = *reinterpret_cast<const float*>(ep + 1024 + (ni * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * 8 + 4);
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mi][ni][r] = fmaf(acc[mi][ni][r], rs[r], brow[mi]);
+            }
+        }
         V4 bq[8];
         if (fast) {
 #pragma unroll
@@ -395,7 +511,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
             stage_prologue();
         }
         PP_FENCE();
-        if (fast && geglu) {
+        if (FUSE != 2 && fast && geglu) {
             const int no = (cn0 >> 1) + wc * 32;
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) {
@@ -446,6 +562,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
                             *reinterpret_cast<V4*>(ep + l31 * 128 + ((((c >> 3) ^ (l31 >> 1)) & 7) << 4) + ((c >> 2) & 1) * 8) = o;
                         }
                     V8 v[4];
+                    float sv = 0.f, qv = 0.f;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int row = i * 8 + (lane_e >> 3), ch = lane_e & 7;
@@ -454,11 +571,38 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 #pragma unroll
                             for (int e = 0; e < 8; ++e) v[i][e] = (T)((float)v[i][e] + (float)rv[i][e]);
                         }
+                        // Fused LayerNorm (producer): (sum, sum of squares) of the 64 values this wave stores per row.  Row
+                        // i * 8 + (lane >> 3) of the piece is spread over the 8 lanes lane & 7: butterfly over them with DPP
+                        // (quad_perm xor 1, xor 2, then row_half_mirror pairs lane j with 7 - j), after which lane & 7 == i
+                        // keeps row group i: one 8-byte store per row from 32 lanes, 256 contiguous bytes per piece.
+                        if constexpr ((FUSE & 2) != 0) {
+                            float s1 = 0.f, q1 = 0.f;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                const float f = (float)v[i][e];
+                                s1 += f;
+                                q1 = fmaf(f, f, q1);
+                            }
+                            s1 += dpp_f32<0xB1>(s1);
+                            q1 += dpp_f32<0xB1>(q1);
+                            s1 += dpp_f32<0x4E>(s1);
+                            q1 += dpp_f32<0x4E>(q1);
+                            s1 += dpp_f32<0x141>(s1);
+                            q1 += dpp_f32<0x141>(q1);
+                            if ((lane_e & 7) == i) sv = s1, qv = q1;
+                        }
                     }
                     // the NEXT piece's residual rows are requested before this piece's stores: the wait for them then
                     // leaves the stores in flight (requested behind them, it would wait for their acknowledgement)
                     if constexpr (RES) {
                         if (mi < 3) load_res(mi + 1);
+                    }
+                    if constexpr ((FUSE & 2) != 0) {
+                        if ((lane_e & 7) < 4) {
+                            const int row = (lane_e & 7) * 8 + (lane_e >> 3);
+                            f32x2 o2 = {sv, qv};
+                            *reinterpret_cast<f32x2*>(p.stats_out + 2 * ((long)(nwp >> 6) * p.M + mb + row)) = o2;
+                        }
                     }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
@@ -469,6 +613,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
             };
             if (__builtin_amdgcn_readfirstlane((int)(Rg != nullptr))) plain(IC<1>{});
             else plain(IC<0>{});
+        } else if constexpr (FUSE != 0) {
         } else if (geglu) {
             const int nw = cn0 + (wc >> 1) * 128 + (wc & 1) * 32;  // hidden strip; gates 64 columns further
             const int no = (cn0 >> 1) + wc * 32;                   // first output column of the wave
@@ -580,6 +725,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
         }
         if (!more) break;
         if (p.bias && is_fast(m0, n0)) stage_bias(n0);  // the next tile's (m0, n0 were advanced by set_tile above)
+        if constexpr ((FUSE & 5) != 0) stage_ln(m0, n0, bz);
         if (!fast) pad_tail();                          // generic epilogue: its store count depends on the tile's edges
     }
     if constexpr ((DBG & 16) != 0) {
@@ -615,6 +761,18 @@ bool ds_gemm_pp_applicable(const GemmParams& p) {
 int ds_launch_gemm_pp(const GemmParams& p0, int batch, hipStream_t stream) {
     GemmParams p = p0;
     DS_REQUIRE(ds_gemm_pp_applicable(p), "gemm_pp: shape M=%d N=%d K=%d not supported", p.M, p.N, p.K);
+    if (p.ln_stats || p.ln_c || p.stats_out) {  // fused LayerNorm: only the branch-free epilogues implement it
+        DS_REQUIRE(p.M % 256 == 0 && p.N % 256 == 0 && !p.rowbias && (p.epi == EPI_NONE || p.epi == EPI_GEGLU),
+                   "gemm_pp: fused LayerNorm needs whole 256 x 256 tiles and no row bias (M=%d N=%d epi=%d)", p.M, p.N, p.epi);
+        DS_REQUIRE(batch == 1 || (p.ln_swapped && p.ln_stats), "gemm_pp: only the operand-swapped fused consumer is batched");
+        DS_REQUIRE((p.ln_stats != nullptr) == (p.ln_c != nullptr), "gemm_pp: ln_stats and ln_c come as a pair");
+        DS_REQUIRE(!p.ln_stats || p.ln_swapped || p.bias, "gemm_pp: the fused-LayerNorm consumer takes b' = bias + W beta as its bias");
+        DS_REQUIRE(!p.ln_swapped || (p.ln_stats && !p.bias && !p.residual && p.epi == EPI_NONE),
+                   "gemm_pp: the operand-swapped fused consumer carries b' in ln_c and takes no bias / residual / activation");
+        DS_REQUIRE(!p.stats_out || p.epi == EPI_NONE, "gemm_pp: row statistics are emitted by the plain epilogue only");
+        DS_REQUIRE(p.dtype == DS_DTYPE_F16, "gemm_pp: fused LayerNorm is an f16 path");
+        DS_REQUIRE(!(p.ln_stats && p.stats_out), "gemm_pp: one launch is either the consumer or the producer of a fused LayerNorm");
+    }
     p.tiles_m = (p.M + 255) / 256;
     p.tiles_n = (p.N + 255) / 256;
     const size_t lds = 8 * HT + 8 * 4096;
@@ -627,8 +785,11 @@ int ds_launch_gemm_pp(const GemmParams& p0, int batch, hipStream_t stream) {
         {1, gemm_pp_kernel<half_t, 1>},   {2, gemm_pp_kernel<half_t, 2>},   {3, gemm_pp_kernel<half_t, 3>},
         {4, gemm_pp_kernel<half_t, 4>},   {6, gemm_pp_kernel<half_t, 6>},   {8, gemm_pp_kernel<half_t, 8>},   {16, gemm_pp_kernel<half_t, 16>},
         {17, gemm_pp_kernel<half_t, 17>}, {18, gemm_pp_kernel<half_t, 18>}, {20, gemm_pp_kernel<half_t, 20>}, {22, gemm_pp_kernel<half_t, 22>},
-        {24, gemm_pp_kernel<half_t, 24>}, {48, gemm_pp_kernel<half_t, 48>}, {49, gemm_pp_kernel<half_t, 49>}, {64, gemm_pp_kernel<half_t, 64>}, {128, gemm_pp_kernel<half_t, 128>},
+        {24, gemm_pp_kernel<half_t, 24>}, {32, gemm_pp_kernel<half_t, 32>}, {48, gemm_pp_kernel<half_t, 48>}, {49, gemm_pp_kernel<half_t, 49>}, {64, gemm_pp_kernel<half_t, 64>}, {128, gemm_pp_kernel<half_t, 128>},
 #endif
+        {-2, gemm_pp_kernel<half_t, 0, 1>},  // -2 / -3: fused LayerNorm, consumer / producer
+        {-3, gemm_pp_kernel<half_t, 0, 2>},
+        {-4, gemm_pp_kernel<half_t, 0, 4>},  // consumer in the operand-swapped (V^T) form
         {-1, gemm_pp_kernel<bf16_t, 0>}};  // -1: the bf16 build (VAE decoder), no ablation variants
     static unsigned long long attr_devs = 0;
     if (ds_first_on_device(attr_devs)) {
@@ -651,7 +812,7 @@ int ds_launch_gemm_pp(const GemmParams& p0, int batch, hipStream_t stream) {
     dim3 grid(nblk, 1, 1);
     kern_t kern = nullptr;
     for (const auto& e : table)
-        if (e.dbg == (p.dtype == DS_DTYPE_BF16 ? -1 : (p.debug & 255))) kern = e.k;
+        if (e.dbg == (p.dtype == DS_DTYPE_BF16 ? -1 : p.ln_stats ? (p.ln_swapped ? -4 : -2) : p.stats_out ? -3 : (p.debug & 255))) kern = e.k;
     DS_REQUIRE(kern != nullptr, "gemm_pp: no ablation build for gemm_debug=%d", p.debug);
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, p);
     DS_LAUNCH_CHECK();

@@ -43,6 +43,28 @@ def pack_geglu(w: Tensor, b: Tensor) -> Tuple[Tensor, Tensor]:
     return wp.contiguous(), bp.contiguous()
 
 
+def pack_ln_fused(w: Tensor, bias: Optional[Tensor], gamma: Tensor, beta: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+    """LayerNorm folded into the linear that consumes it (csrc/gemm_pp.hip, "LayerNorm"):
+    LN(x) W^T + b = rstd (x (gamma (.) W)^T - mean c) + b',  c_n = sum_k (gamma (.) W)_nk,  b' = b + W beta.
+    Returns (gw f16 [N,K], c2 f16 [N,2] = (-c hi, -c lo), b' f16 [N]).  c is summed from the f16-ROUNDED gw - the values
+    the MFMA contracts - so the rank-1 correction cancels the mean exactly; the (hi, lo) pair keeps it to 2^-22."""
+    wf = w.double()
+    gw = (wf * gamma.double()[None, :]).to(torch.float16)
+    nc = (-gw.double().sum(1)).float()
+    hi = nc.to(torch.float16)
+    lo = (nc - hi.float()).to(torch.float16)
+    bp = wf @ beta.double()
+    if bias is not None:
+        bp = bp + bias.double()
+    return gw.contiguous(), torch.stack([hi, lo], dim=1).contiguous(), bp.to(torch.float16).contiguous()
+
+
+def ln_fusion_enabled() -> bool:
+    """DIFFSENSEI_LN_FUSION=0 keeps the stand-alone LayerNorm launches everywhere (A/B runs)."""
+    import os
+    return os.environ.get("DIFFSENSEI_LN_FUSION", "1") != "0"
+
+
 class PackedUNet:
     """Device-resident fp16 weights in kernel layout.  `names` follow the diffusers state dict."""
 
@@ -137,6 +159,33 @@ class PackedUNet:
                 wp, bp = pack_geglu(sd[f"{t}.ff.net.0.proj.weight"].to(device), sd[f"{t}.ff.net.0.proj.bias"].to(device))
                 put(f"{t}.ff.net.0.proj.weight", wp)
                 put(f"{t}.ff.net.0.proj.bias", bp)
+                if a.channels % 256 == 0 and ln_fusion_enabled():
+                    # fused-LayerNorm copies (norm2 -> attn2.to_q, norm3 -> GEGLU projection): only widths whose GEMMs can
+                    # run whole 256 x 256 tiles (SDXL: the 1280-channel level, 60 of 70 blocks, +1.8 GB)
+                    dv = lambda n: sd[n].to(device)
+                    # norm1 -> q|k (row form) and -> to_v, produced transposed (operand-swapped form: (-c, b') per output row)
+                    gw, c2, b2 = pack_ln_fused(self.w[f"{t}.attn1.qk.weight"], None, dv(f"{t}.norm1.weight"), dv(f"{t}.norm1.bias"))
+                    put(f"{t}.attn1.qk.weight_ln", gw)
+                    put(f"{t}.attn1.qk.c_ln", c2)
+                    put(f"{t}.attn1.qk.bias_ln", b2)
+                    gw, c2, b2 = pack_ln_fused(dv(f"{t}.attn1.to_v.weight"), None, dv(f"{t}.norm1.weight"), dv(f"{t}.norm1.bias"))
+                    bf = (dv(f"{t}.attn1.to_v.weight").double() @ dv(f"{t}.norm1.bias").double()).float()   # b' as an f16 (hi, lo) pair
+                    bh = bf.to(torch.float16)
+                    bl = (bf - bh.float()).to(torch.float16)
+                    put(f"{t}.attn1.to_v.weight_ln", gw)
+                    put(f"{t}.attn1.to_v.cb_ln", torch.cat([c2, torch.stack([bh, bl], dim=1)], dim=1).contiguous())
+                    gw, c2, b2 = pack_ln_fused(dv(f"{t}.attn2.to_q.weight"), None, dv(f"{t}.norm2.weight"), dv(f"{t}.norm2.bias"))
+                    put(f"{t}.attn2.to_q.weight_ln", gw)
+                    put(f"{t}.attn2.to_q.c_ln", c2)
+                    put(f"{t}.attn2.to_q.bias_ln", b2)
+                    gw, c2, b2 = pack_ln_fused(dv(f"{t}.ff.net.0.proj.weight"), dv(f"{t}.ff.net.0.proj.bias"),
+                                               dv(f"{t}.norm3.weight"), dv(f"{t}.norm3.bias"))
+                    gwp, b2p = pack_geglu(gw, b2)
+                    half = c2.shape[0] // 2
+                    c2p = torch.stack([c2[:half].reshape(-1, 64, 2), c2[half:].reshape(-1, 64, 2)], dim=1).reshape(-1, 2)
+                    put(f"{t}.ff.net.0.proj.weight_ln", gwp)
+                    put(f"{t}.ff.net.0.proj.c_ln", c2p)
+                    put(f"{t}.ff.net.0.proj.bias_ln", b2p)
                 put(f"{t}.ff.net.2.weight", sd[f"{t}.ff.net.2.weight"])
                 put(f"{t}.ff.net.2.bias", sd[f"{t}.ff.net.2.bias"])
         self.kv_total = off
@@ -309,6 +358,15 @@ class UNetEngine:
             self.scratch[key] = t
         return t
 
+    def _buf32(self, role: str, level: int, n: int) -> Tensor:
+        """fp32 scratch keyed like `_buf` (row statistics of the fused LayerNorms)."""
+        key = (role, level)
+        t = self.scratch.get(key)
+        if t is None or t.numel() < n:
+            t = self._alloc((n,), torch.float32)
+            self.scratch[key] = t
+        return t
+
     def nbytes(self) -> int:
         return sum(t.numel() * t.element_size() for t in self.keep)
 
@@ -351,11 +409,14 @@ class UNetEngine:
         ops.append(make_op("CONV3X3", i=(self.B, H, W, Cin, Cout, stride, upsample, self.pk.temb_total, out_hw[0], out_hw[1]),
                            p=(x, w[wname + ".weight"], y, w[wname + ".bias"], rowbias, residual)))
 
-    def _gemm(self, ops, x, wt, y, M, N, K, bias=None, residual=None, geglu=False, x2=None, K1=0):
+    def _gemm(self, ops, x, wt, y, M, N, K, bias=None, residual=None, geglu=False, x2=None, K1=0, ln_stats=None, ln_c=None,
+              stats_out=None):
+        """ln_stats / ln_c: this GEMM consumes a fused LayerNorm (x is the raw residual stream, wt / bias the `_ln` copies);
+        stats_out: it emits the row statistics of what it stores (csrc/gemm_pp.hip, "LayerNorm")."""
         n_out = N // 2 if geglu else N
         ops.append(make_op("GEMM", i=(M, N, K, K1 if x2 is not None else K, int(geglu), 1, 0, 1),
                            l=(K1 if x2 is not None else K, (K - K1) if x2 is not None else 0, K, n_out, n_out),
-                           p=(x, x2, wt, y, bias, None, residual)))
+                           p=(x, x2, wt, y, bias, None, residual, ln_stats, ln_c, stats_out)))
 
     def _resnet(self, ops, r: ResnetSpec, x1: Tensor, x2: Optional[Tensor], c1: int, c2: int, out: Tensor):
         cfg, w = self.cfg, self.pk.w
@@ -398,15 +459,37 @@ class UNetEngine:
         mh, mw = mask_grid_size(N, self.aspect_ratio)
         kvt = self.pk.kv_total
         scale = 1.0 / (Cc // a.heads) ** 0.5
+        # LayerNorm fusion (norm1 -> q|k and the transposed to_v, norm2 -> attn2.to_q, norm3 -> GEGLU projection): when every
+        # GEMM that writes h and every consumer runs gemm_pp_kernel's branch-free epilogues at this batch, the three LayerNorm
+        # launches of every block are replaced by row statistics out of the producer's epilogue + a finalize launch (a few
+        # us instead of 76 at batch 64); smaller batches and the 640-channel level keep the LayerNorm kernel
+        lib = _lib.load()
+        fuse = (f"{p}.transformer_blocks.0.attn2.to_q.weight_ln" in w and ln_fusion_enabled()
+                and bool(lib.ds_gemm_ln_fusable(M, Cc, Cc, 0, 1)) and bool(lib.ds_gemm_ln_fusable(M, 8 * Cc, Cc, 1, 1))
+                and bool(lib.ds_gemm_ln_fusable(M, 2 * Cc, Cc, 0, 1)) and bool(lib.ds_gemm_ln_fusable(M, Cc, 4 * Cc, 0, 1))
+                and Np == N and bool(lib.ds_gemm_ln_fusable(Cc, N, Cc, 0, B)))
+        if fuse:
+            part = self._buf32("ln_part", a.level, (Cc // 64) * M * 2)
+            st = self._buf32("ln_stats", a.level, M * 2)
+        self.ln_fused_blocks = getattr(self, "ln_fused_blocks", 0) + (a.depth if fuse else 0)
         self._gn(ops, x, None, tn, w[p + ".norm.weight"], w[p + ".norm.bias"], N, Cc, 0, 1e-6, False)
-        self._gemm(ops, tn, w[p + ".proj_in.weight"], h, M, Cc, Cc, bias=w[p + ".proj_in.bias"])
+        self._gemm(ops, tn, w[p + ".proj_in.weight"], h, M, Cc, Cc, bias=w[p + ".proj_in.bias"],
+                   stats_out=part if fuse else None)
         for k in range(a.depth):
             t = f"{p}.transformer_blocks.{k}"
             # ---- attn1 (AttnProcessor2_0): q|k projection, V^T projection, flash attention, out-proj + residual
-            ops.append(make_op("LAYERNORM", i=(M, Cc), f=(1e-5,), p=(h, tn, w[t + ".norm1.weight"], w[t + ".norm1.bias"])))
-            self._gemm(ops, tn, w[t + ".attn1.qk.weight"], qk, M, 2 * Cc, Cc)
-            ops.append(make_op("GEMM", i=(Cc, Np, Cc, Cc, 0, B, 0, 1), l=(Cc, 0, Cc, Np, 0, 0, 0, N * Cc, Cc * Np, 0),
-                               p=(w[t + ".attn1.to_v.weight"], None, tn, vt)))
+            if fuse:     # norm1: statistics of h came out of proj_in / the previous block's FF down-projection
+                ops.append(make_op("LN_FINALIZE", i=(M, Cc // 64, Cc), f=(1e-5,), p=(part, st)))
+                self._gemm(ops, h, w[t + ".attn1.qk.weight_ln"], qk, M, 2 * Cc, Cc, bias=w[t + ".attn1.qk.bias_ln"],
+                           ln_stats=st, ln_c=w[t + ".attn1.qk.c_ln"])
+                ops.append(make_op("GEMM", i=(Cc, Np, Cc, Cc, 0, B, 0, 1, 1), l=(Cc, 0, Cc, Np, 0, 0, 0, N * Cc, Cc * Np, 0, N),
+                                   p=(w[t + ".attn1.to_v.weight_ln"], None, h, vt, None, None, None, st,
+                                      w[t + ".attn1.to_v.cb_ln"], None)))
+            else:
+                ops.append(make_op("LAYERNORM", i=(M, Cc), f=(1e-5,), p=(h, tn, w[t + ".norm1.weight"], w[t + ".norm1.bias"])))
+                self._gemm(ops, tn, w[t + ".attn1.qk.weight"], qk, M, 2 * Cc, Cc)
+                ops.append(make_op("GEMM", i=(Cc, Np, Cc, Cc, 0, B, 0, 1), l=(Cc, 0, Cc, Np, 0, 0, 0, N * Cc, Cc * Np, 0),
+                                   p=(w[t + ".attn1.to_v.weight"], None, tn, vt)))
             if self.attention == "fp8" and N % 64 == 0:
                 k8 = self._buf("t_k8", a.level, M, Cc // 2)      # bytes: M*Cc uint8 in an f16-typed scratch
                 v8 = self._buf("t_v8", a.level, M, Cc // 2)
@@ -420,10 +503,15 @@ class UNetEngine:
                                    l=(2 * Cc, 2 * Cc, Np, Cc, N * 2 * Cc, N * 2 * Cc, N * Cc),
                                    p=(qk, qk.data_ptr() + 2 * Cc, vt, ao)))
             self._gemm(ops, ao, w[t + ".attn1.to_out.0.weight"], h, M, Cc, Cc, bias=w[t + ".attn1.to_out.0.bias"],
-                       residual=h)
+                       residual=h, stats_out=part if fuse else None)
             # ---- attn2 (MaskedIPAttnProcessor2_0): q projection, fused text+masked-IP attention, out-proj + residual
-            ops.append(make_op("LAYERNORM", i=(M, Cc), f=(1e-5,), p=(h, tn, w[t + ".norm2.weight"], w[t + ".norm2.bias"])))
-            self._gemm(ops, tn, w[t + ".attn2.to_q.weight"], q2, M, Cc, Cc)
+            if fuse:
+                ops.append(make_op("LN_FINALIZE", i=(M, Cc // 64, Cc), f=(1e-5,), p=(part, st)))
+                self._gemm(ops, h, w[t + ".attn2.to_q.weight_ln"], q2, M, Cc, Cc, bias=w[t + ".attn2.to_q.bias_ln"],
+                           ln_stats=st, ln_c=w[t + ".attn2.to_q.c_ln"])
+            else:
+                ops.append(make_op("LAYERNORM", i=(M, Cc), f=(1e-5,), p=(h, tn, w[t + ".norm2.weight"], w[t + ".norm2.bias"])))
+                self._gemm(ops, tn, w[t + ".attn2.to_q.weight"], q2, M, Cc, Cc)
             off = self.pk.kv_off[t]
             ops.append(make_op(
                 "IP_ATTN",
@@ -433,12 +521,18 @@ class UNetEngine:
                 p=(q2, self.k_txt.data_ptr() + 2 * off, self.v_txt.data_ptr() + 2 * off * LP,
                    self.k_ip.data_ptr() + 2 * off, self.v_ip.data_ptr() + 2 * off * LP, self.bbox, ao, self.ip_scale)))
             self._gemm(ops, ao, w[t + ".attn2.to_out.0.weight"], h, M, Cc, Cc, bias=w[t + ".attn2.to_out.0.bias"],
-                       residual=h)
+                       residual=h, stats_out=part if fuse else None)
             # ---- GEGLU feed-forward + residual
-            ops.append(make_op("LAYERNORM", i=(M, Cc), f=(1e-5,), p=(h, tn, w[t + ".norm3.weight"], w[t + ".norm3.bias"])))
-            self._gemm(ops, tn, w[t + ".ff.net.0.proj.weight"], ff, M, 8 * Cc, Cc, bias=w[t + ".ff.net.0.proj.bias"],
-                       geglu=True)
-            self._gemm(ops, ff, w[t + ".ff.net.2.weight"], h, M, Cc, 4 * Cc, bias=w[t + ".ff.net.2.bias"], residual=h)
+            if fuse:
+                ops.append(make_op("LN_FINALIZE", i=(M, Cc // 64, Cc), f=(1e-5,), p=(part, st)))
+                self._gemm(ops, h, w[t + ".ff.net.0.proj.weight_ln"], ff, M, 8 * Cc, Cc, bias=w[t + ".ff.net.0.proj.bias_ln"],
+                           geglu=True, ln_stats=st, ln_c=w[t + ".ff.net.0.proj.c_ln"])
+            else:
+                ops.append(make_op("LAYERNORM", i=(M, Cc), f=(1e-5,), p=(h, tn, w[t + ".norm3.weight"], w[t + ".norm3.bias"])))
+                self._gemm(ops, tn, w[t + ".ff.net.0.proj.weight"], ff, M, 8 * Cc, Cc, bias=w[t + ".ff.net.0.proj.bias"],
+                           geglu=True)
+            self._gemm(ops, ff, w[t + ".ff.net.2.weight"], h, M, Cc, 4 * Cc, bias=w[t + ".ff.net.2.bias"], residual=h,
+                       stats_out=part if (fuse and k + 1 < a.depth) else None)
         self._gemm(ops, h, w[p + ".proj_out.weight"], out, M, Cc, Cc, bias=w[p + ".proj_out.bias"], residual=x)
 
     def _build_forward(self) -> List[DsOp]:

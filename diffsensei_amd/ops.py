@@ -69,6 +69,55 @@ def gemm(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, residual: Optional
     return out
 
 
+def gemm_ln(x: Tensor, gw: Tensor, bias_ln: Optional[Tensor] = None, ln_c: Optional[Tensor] = None,
+            ln_stats: Optional[Tensor] = None, residual: Optional[Tensor] = None, geglu: bool = False,
+            emit_stats: bool = False, out: Optional[Tensor] = None):
+    """The two roles of a fused LayerNorm (include/diffsensei_hip.h, ds_gemm_ln_f16):
+    consumer (`ln_stats` [M,2] fp32 (mean, rstd), `ln_c` [N,2] f16, `gw`, `bias_ln` from `engine.pack_ln_fused`):
+        y = rstd (x gw^T - mean c) + b' on the RAW x;
+    producer (`emit_stats`): y = x gw^T + bias (+ residual) and the [N/64, M, 2] fp32 partial (sum, sum of squares) of the stored
+        rows -> returns (y, partial)."""
+    _chk(x, gw, bias_ln, ln_c, residual)
+    _chk(ln_stats, dtype=torch.float32)
+    M, K = x.shape
+    N = gw.shape[0]
+    n_out = N // 2 if geglu else N
+    if out is None:
+        out = torch.empty((M, n_out), dtype=torch.float16, device=x.device)
+    part = torch.empty((N // 64, M, 2), dtype=torch.float32, device=x.device) if emit_stats else None
+    L = _lib.load()
+    check(L.ds_gemm_ln_f16(_p(x), K, _p(gw), K, _p(bias_ln), _p(ln_stats), _p(ln_c), _p(residual), n_out, _p(out), n_out,
+                           _p(part), M, N, K, 1 if geglu else 0, _stream()), "ds_gemm_ln_f16")
+    return (out, part) if emit_stats else out
+
+
+def ln_finalize(partial: Tensor, C: int, eps: float = 1e-5) -> Tensor:
+    """[strips, M, 2] fp32 partial sums of a producer GEMM -> [M, 2] fp32 (mean, rstd) over C columns."""
+    _chk(partial, dtype=torch.float32)
+    strips, M, _ = partial.shape
+    st = torch.empty((M, 2), dtype=torch.float32, device=partial.device)
+    check(_lib.load().ds_ln_finalize(_p(partial), _p(st), M, strips, C, eps, _stream()), "ds_ln_finalize")
+    return st
+
+
+def gemm_ln_fusable(M: int, N: int, K: int, geglu: bool = False, batch: int = 1) -> bool:
+    return bool(_lib.load().ds_gemm_ln_fusable(M, N, K, 1 if geglu else 0, batch))
+
+
+def gemm_ln_swapped(a: Tensor, x: Tensor, ln_stats: Tensor, ln_cb: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    """out[z] = a @ LN(x[z])^T with the LayerNorm folded in (ds_gemm_ln_swapped_f16): a = gamma (.) W [M,K], x [Z,N,K] raw,
+    ln_stats [Z*N,2] fp32 (mean, rstd), ln_cb [M,4] f16 (-c hi, -c lo, b' hi, b' lo) -> [Z,M,N]."""
+    _chk(a, x, ln_cb)
+    _chk(ln_stats, dtype=torch.float32)
+    Z, N, K = x.shape
+    M = a.shape[0]
+    if out is None:
+        out = torch.empty((Z, M, N), dtype=torch.float16, device=x.device)
+    check(_lib.load().ds_gemm_ln_swapped_f16(_p(a), K, _p(x), K, N * K, _p(ln_stats), N, _p(ln_cb), _p(out), N, M * N, M, N, K,
+                                             Z, _stream()), "ds_gemm_ln_swapped_f16")
+    return out
+
+
 def gemm_batched_nt(a: Tensor, b: Tensor, out: Optional[Tensor] = None) -> Tensor:
     """out[z] = a[z or shared] @ b[z].T ; a: [M,K] or [Z,M,K], b: [Z,N,K] -> [Z,M,N]."""
     _chk(a, b)

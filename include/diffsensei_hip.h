@@ -65,6 +65,29 @@ int ds_gemm_f16(const void* x, int64_t ldx, const void* x2, int64_t ldx2, int k1
                 const void* bias, const void* residual, int64_t ldr, void* y, int64_t ldy, int M, int N, int K,
                 int epilogue, void* stream);
 
+/* LayerNorm fused into the GEMM pair around it (round 4).  Replaces the three `nn.LayerNorm` passes of diffusers'
+ * BasicTransformerBlock [3P] that the reference reaches from src/models/unet.py:244-338 (norm2 -> attn2.to_q,
+ * norm3 -> ff.net.0 GEGLU; attention_processor.py:209 takes the normalised hidden states as its query input):
+ *   producer  y = x w^T + bias (+ residual), and `stats_out` [N/64][M] float2 receives the (sum, sum of squares) of every
+ *             stored row per 64-column strip;
+ *   ds_ln_finalize: partial sums -> stats [M] float2 (mean, rstd = rsqrt(var + eps));
+ *   consumer  y = rstd_m (x_m . gw_n - mean_m c_n) + b'_n on the RAW x, with gw = gamma (.) w (f16), ln_c [N][2] f16 =
+ *             (-c hi, -c lo), c_n = sum_k gw_nk, bias_ln = bias + w beta - all packed once at load time (GEGLU: in the packed
+ *             row order).  epilogue 0 or 1 (GEGLU).  Either role may be absent (null pointers), both may be combined.
+ * Only the 256 x 256 persistent kernel implements it: M, N multiples of 256, K of 128; ds_gemm_ln_fusable says whether
+ * ds_gemm_f16 would pick that kernel for the shape (callers keep ds_layernorm_f16 + ds_gemm_f16 otherwise). */
+int ds_gemm_ln_f16(const void* x, int64_t ldx, const void* gw, int64_t ldw, const void* bias_ln, const float* ln_stats,
+                   const void* ln_c, const void* residual, int64_t ldr, void* y, int64_t ldy, float* stats_out, int M, int N,
+                   int K, int epilogue, void* stream);
+int ds_ln_finalize(const float* partial, float* stats, int M, int strips, int C, float eps, void* stream);
+/* operand-swapped consumer (norm1 -> attn1.to_v, produced transposed: y[b] = a @ LN(x[b])^T, a = gamma (.) Wv [M,K] shared,
+ * x[b] the raw rows [N,K] of batch item b): the normalised rows index the OUTPUT COLUMNS, so ln_stats is read at
+ * [b * ln_bstride + n] and ln_cb is [M][4] f16 = (-c hi, -c lo, b' hi, b' lo) per output row. */
+int ds_gemm_ln_swapped_f16(const void* a, int64_t lda, const void* x, int64_t ldx, int64_t sx, const float* ln_stats,
+                           int64_t ln_bstride, const void* ln_cb, void* y, int64_t ldy, int64_t sy, int M, int N, int K,
+                           int batch, void* stream);
+int ds_gemm_ln_fusable(int M, int N, int K, int epilogue, int batch);
+
 /* batched variant: grid.z = batch with element strides (0 = shared operand); used for V^T = Wv @ X_b^T */
 int ds_gemm_f16_batched(const void* x, int64_t ldx, int64_t sx, const void* w, int64_t ldw, int64_t sw, void* y,
                         int64_t ldy, int64_t sy, int M, int N, int K, int batch, void* stream);
@@ -296,7 +319,7 @@ int ds_resize_v_norm_u8(const uint8_t* tmp, int Ht, int Wt, const int32_t* first
  * and replayed with zero host arithmetic — optionally as a captured hipGraph.
  * ---------------------------------------------------------------------------------------------- */
 enum ds_opcode {
-    DS_OP_GEMM = 1,          /* p: x, x2, w, y, bias, rowbias, residual   l: ldx ldx2 ldw ldy ldr sx sx2 sw sy sr
+    DS_OP_GEMM = 1,          /* p: x, x2, w, y, bias, rowbias, residual, ln_stats, ln_c, stats_out (fused LayerNorm, see ds_gemm_ln_f16; i[8] = operand-swapped form, l[10] = ln_bstride)   l: ldx ldx2 ldw ldy ldr sx sx2 sw sy sr
                                 i: M N K K1 epilogue batch rowbias_ld rows_per_group */
     DS_OP_CONV3X3 = 2,       /* p: x, w, y, bias, rowbias, residual       i: B H W Cin Cout stride upsample rowbias_ld
                                                                            Hout Wout (upsample only; 0 0 = 2H x 2W) */
@@ -325,7 +348,8 @@ enum ds_opcode {
     DS_OP_LLM_SELECT = 23,   /* p: logits, chain, state, out_ids             i: V n_chain out_cap adv */
     DS_OP_LLM_ADVANCE = 24,  /* p: state                                     i: rows */
     DS_OP_QUANT_FP8 = 25,    /* p: x, out                   l: ldx sx        i: batch rows cols permute64   f: scale */
-    DS_OP_SELF_ATTN_FP8 = 26 /* p: q, k8, vt8, o            l: ldq ldo sq so i: B heads Nq Nk               f: scale */
+    DS_OP_SELF_ATTN_FP8 = 26, /* p: q, k8, vt8, o           l: ldq ldo sq so i: B heads Nq Nk               f: scale */
+    DS_OP_LN_FINALIZE = 27   /* p: partial, stats                            i: M strips C               f: eps */
 };
 
 typedef struct ds_op {

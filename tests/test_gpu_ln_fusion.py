@@ -1,0 +1,164 @@
+"""GPU: LayerNorm folded into the GEMM pair around it (csrc/gemm_pp.hip "LayerNorm", include/diffsensei_hip.h ds_gemm_ln_f16)
+vs plain PyTorch fp32 references of the ops it replaces - nn.LayerNorm followed by nn.Linear / GEGLU in diffusers'
+BasicTransformerBlock [3P], reached from reference src/models/unet.py:244-338 (norm2 -> attn2.to_q, norm3 -> ff.net.0).
+
+Tolerances: row statistics (fp32 sums of f16 values) - mean 1e-5 absolute + 1e-5 relative, rstd 1e-4 relative; fused
+consumer output vs fp32 LayerNorm + linear on the same f16 inputs: max |err| <= 3e-3 max|ref| (the unfused HIP pair
+LayerNorm kernel -> GEMM is measured beside it: same size of error - one path rounds LN(x) to f16, the other gamma (.) W);
+rows with a mean of 8 standard deviations still inside 5e-3.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _r(shape, g, scale=1.0):
+    return (torch.randn(shape, generator=g) * scale).half()
+
+
+def _relmax(got, ref):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    assert got.shape == ref.shape and torch.isfinite(got).all()
+    return ((got - ref).abs().max() / ref.abs().max().clamp_min(1e-6)).item()
+
+
+@pytest.mark.parametrize("M,N,K,res", [(512, 1280, 1280, True), (1024, 256, 128, False), (2048, 1280, 5120, True)])
+def test_producer_row_statistics(hip_lib, M, N, K, res):
+    """The +residual projection that writes the residual stream also emits, per row and 64-column strip, the (sum, sum of
+    squares) of the f16 values it stores; `ln_finalize` turns them into (mean, rstd).  The stored output itself must be
+    bit-identical to the GEMM without statistics."""
+    from diffsensei_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    x, w, b = _r((M, K), g), _r((N, K), g, 1 / math.sqrt(K)), _r((N,), g)
+    r = (_r((M, N), g) * 3 + 1.5).half() if res else None
+    dv = lambda t: None if t is None else t.to(DEV)
+    y, part = ops.gemm_ln(dv(x), dv(w), dv(b), residual=dv(r), emit_stats=True)
+    assert part.shape == (N // 64, M, 2)
+    lib = __import__("diffsensei_amd._lib", fromlist=["x"]).load()
+    lib.ds_set_option(b"gemm_variant", 3)
+    try:
+        y0 = ops.gemm(dv(x), dv(w), dv(b), dv(r))
+    finally:
+        lib.ds_set_option(b"gemm_variant", 0)
+    assert torch.equal(y, y0), "statistics emission changed the stored output"
+    yf = y.float().cpu()
+    strips = yf.view(M, N // 64, 64)
+    assert torch.allclose(part[..., 0].t().cpu(), strips.sum(-1), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(part[..., 1].t().cpu(), (strips * strips).sum(-1), rtol=1e-5, atol=1e-3)
+    st = ops.ln_finalize(part, N, 1e-5).cpu()
+    mean, var = yf.mean(1), yf.var(1, unbiased=False)
+    assert torch.allclose(st[:, 0], mean, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(st[:, 1], torch.rsqrt(var + 1e-5), rtol=1e-4, atol=0)
+
+
+def _pack(w, bias, gamma, beta):
+    from diffsensei_amd.engine import pack_ln_fused
+    return pack_ln_fused(w.to(DEV), None if bias is None else bias.to(DEV), gamma.to(DEV), beta.to(DEV))
+
+
+@pytest.mark.parametrize("M,N,K,offset", [(512, 1280, 1280, 0.0), (256, 256, 128, 0.0), (1024, 2560, 1280, 0.3), (512, 1280, 1280, 8.0)])
+def test_consumer_plain_vs_layernorm_linear(hip_lib, M, N, K, offset):
+    """y = rstd (x gw^T - mean c) + b' on the raw x  ==  Linear(LayerNorm(x)); `offset`: row mean in standard deviations
+    (the rank-1 term is carried as an f16 (hi, lo) pair, so a large mean must not cost accuracy)."""
+    from diffsensei_amd import ops
+    g = torch.Generator().manual_seed(M + N + K + int(offset * 10))
+    x = ((torch.randn((M, K), generator=g) + offset) * (1.0 + torch.rand((M, 1), generator=g) * 3)).half()
+    w, gamma, beta = _r((N, K), g, 1 / math.sqrt(K)), (1 + 0.2 * torch.randn(K, generator=g)).half(), _r((K,), g, 0.2)
+    ref = F.linear(F.layer_norm(x.float(), (K,), gamma.float(), beta.float(), 1e-5), w.float())
+    gw, c2, b2 = _pack(w, None, gamma, beta)
+    xd = x.to(DEV)
+    # statistics from a producer GEMM would be those of its output; here: of x itself, through the same finalize kernel
+    xs = x.float().view(M, K // 64, 64)
+    part = torch.stack([xs.sum(-1).t(), (xs * xs).sum(-1).t()], dim=-1).contiguous().to(DEV)
+    st = ops.ln_finalize(part, K, 1e-5)
+    got = ops.gemm_ln(xd, gw, b2, c2, st)
+    unfused = ops.gemm(ops.layernorm(xd, gamma.to(DEV), beta.to(DEV), 1e-5), w.to(DEV))
+    e_f, e_u = _relmax(got, ref), _relmax(unfused, ref)
+    print(f"LN -> linear M={M} N={N} K={K} mean/std {offset}: fused {e_f:.2e}, LayerNorm kernel + GEMM {e_u:.2e}")
+    assert e_f <= (3e-3 if offset < 1 else 5e-3), e_f
+
+
+def test_consumer_geglu_vs_layernorm_geglu(hip_lib):
+    """norm3 -> ff.net.0 (GEGLU, packed weights): h * gelu(g) of Linear(LayerNorm(x)), fused, vs fp32."""
+    from diffsensei_amd import ops
+    from diffsensei_amd.engine import pack_geglu, pack_ln_fused
+    g = torch.Generator().manual_seed(5)
+    M, C = 512, 256
+    x = ((torch.randn((M, C), generator=g) + 0.2) * 2).half()
+    w, b = _r((8 * C, C), g, 1 / math.sqrt(C)), _r((8 * C,), g, 0.3)
+    gamma, beta = (1 + 0.2 * torch.randn(C, generator=g)).half(), _r((C,), g, 0.2)
+    z = F.linear(F.layer_norm(x.float(), (C,), gamma.float(), beta.float(), 1e-5), w.float(), b.float())
+    ref = z[:, :4 * C].half().float() * F.gelu(z[:, 4 * C:].half().float())
+    gw, c2, b2 = pack_ln_fused(w.to(DEV), b.to(DEV), gamma.to(DEV), beta.to(DEV))
+    gwp, b2p = pack_geglu(gw, b2)
+    half = 4 * C
+    c2p = torch.stack([c2[:half].reshape(-1, 64, 2), c2[half:].reshape(-1, 64, 2)], dim=1).reshape(-1, 2).contiguous()
+    xs = x.float().view(M, C // 64, 64)
+    part = torch.stack([xs.sum(-1).t(), (xs * xs).sum(-1).t()], dim=-1).contiguous().to(DEV)
+    st = ops.ln_finalize(part, C, 1e-5)
+    got = ops.gemm_ln(x.to(DEV), gwp, b2p, c2p, st, geglu=True)
+    e = _relmax(got, ref)
+    print(f"LN -> GEGLU fused: {e:.2e}")
+    assert got.shape == (M, 4 * C) and e <= 4e-3, e
+
+
+def test_fused_chain_producer_finalize_consumer_and_refusals(hip_lib):
+    """The sequence the launch plan emits: out-projection + residual (statistics) -> finalize -> fused to_q, against the fp32
+    chain; 30 back-to-back repetitions must give the same bits (the pieces ride the tile hand-over's counted waits); shapes or
+    options the fused epilogues do not implement are refused, not silently mis-served."""
+    from diffsensei_amd import _lib, ops
+    g = torch.Generator().manual_seed(11)
+    M, C = 2048, 1280
+    a, wo, bo = _r((M, C), g), _r((C, C), g, 1 / math.sqrt(C)), _r((C,), g)
+    h0 = (_r((M, C), g) * 2 + 0.5).half()
+    wq, gamma, beta = _r((C, C), g, 1 / math.sqrt(C)), (1 + 0.2 * torch.randn(C, generator=g)).half(), _r((C,), g, 0.2)
+    dv = lambda t: t.to(DEV)
+    h, part = ops.gemm_ln(dv(a), dv(wo), dv(bo), residual=dv(h0), emit_stats=True)
+    st = ops.ln_finalize(part, C, 1e-5)
+    gw, c2, b2 = _pack(wq, None, gamma, beta)
+    q = ops.gemm_ln(h, gw, b2, c2, st)
+    hr = (a.float() @ wo.float().t() + bo.float()).half().float() + h0.float()
+    ref = F.linear(F.layer_norm(hr.half().float(), (C,), gamma.float(), beta.float(), 1e-5), wq.float())
+    e = _relmax(q, ref)
+    print(f"producer -> finalize -> consumer chain: {e:.2e}")
+    assert e <= 3e-3, e
+    for _ in range(30):
+        h2, part2 = ops.gemm_ln(dv(a), dv(wo), dv(bo), residual=dv(h0), emit_stats=True)
+        q2 = ops.gemm_ln(h2, gw, b2, c2, ops.ln_finalize(part2, C, 1e-5))
+        assert torch.equal(h2, h) and torch.equal(part2, part) and torch.equal(q2, q)
+    assert ops.gemm_ln_fusable(65536, 1280, 1280) and ops.gemm_ln_fusable(65536, 10240, 1280, geglu=True)
+    assert not ops.gemm_ln_fusable(2048, 1280, 1280) and not ops.gemm_ln_fusable(65536, 640, 640)
+    with pytest.raises(_lib.DiffSenseiHipError):          # ragged M: the generic epilogue has no fused form
+        ops.gemm_ln(dv(a[:2000]), gw, b2, c2, st[:2000].contiguous())
+    with pytest.raises(_lib.DiffSenseiHipError):          # consumer without its b'
+        ops.gemm_ln(dv(a), gw, None, c2, st)
+
+
+def test_consumer_swapped_vs_layernorm_linear(hip_lib):
+    """norm1 -> attn1.to_v, produced transposed per image: out[z] = Wv LN(x[z])^T (operand-swapped form: the statistics run
+    along the output columns, c and b' along its rows, batch items folded into the persistent tile walk)."""
+    from diffsensei_amd import ops
+    from diffsensei_amd.engine import pack_ln_fused
+    g = torch.Generator().manual_seed(21)
+    Z, N, C = 3, 512, 256
+    x = ((torch.randn((Z, N, C), generator=g) + 0.4) * (1.0 + torch.rand((Z, N, 1), generator=g) * 3)).half()
+    wv, gamma, beta = _r((C, C), g, 1 / math.sqrt(C)), (1 + 0.2 * torch.randn(C, generator=g)).half(), _r((C,), g, 0.3)
+    ref = torch.einsum("ck,znk->zcn", wv.float(), F.layer_norm(x.float(), (C,), gamma.float(), beta.float(), 1e-5))
+    gw, c2, _ = pack_ln_fused(wv.to(DEV), None, gamma.to(DEV), beta.to(DEV))
+    bf = (wv.double() @ beta.double()).float()
+    bh = bf.half()
+    cb = torch.cat([c2.cpu(), torch.stack([bh, (bf - bh.float()).half()], dim=1)], dim=1).contiguous().to(DEV)
+    xs = x.float().view(Z * N, C // 64, 64)
+    part = torch.stack([xs.sum(-1).t(), (xs * xs).sum(-1).t()], dim=-1).contiguous().to(DEV)
+    st = ops.ln_finalize(part, C, 1e-5)
+    got = ops.gemm_ln_swapped(gw, x.to(DEV), st, cb)
+    tn = ops.layernorm(x.view(Z * N, C).to(DEV), gamma.to(DEV), beta.to(DEV), 1e-5).view(Z, N, C)
+    unfused = ops.gemm_batched_nt(wv.to(DEV), tn)
+    e_f, e_u = _relmax(got, ref), _relmax(unfused, ref)
+    print(f"LN -> V^T (swapped) Z={Z} N={N} C={C}: fused {e_f:.2e}, LayerNorm kernel + GEMM {e_u:.2e}")
+    assert got.shape == (Z, C, N) and e_f <= 3e-3, e_f

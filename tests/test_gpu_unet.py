@@ -227,7 +227,9 @@ def test_unet_sdxl_forward_vs_oracle_1024(sdxl_model):
     d0, d1 = _rel(y32[0], y[0]), _rel(y32[16], y[1])
     print(f"SDXL 1024x1024: batch-32 rows vs batch-2 rows rel-L2 {d0:.3e} / {d1:.3e}, bit-equal: "
           f"{torch.equal(y32[0], y[0]) and torch.equal(y32[16], y[1])}")
-    assert d0 <= 2e-3 and d1 <= 2e-3, (d0, d1)
+    # (<= 4e-3: since round 4 the large batches run the LayerNorms of the 1280-channel blocks fused into the GEMMs around
+    # them - 1.3e-3 apart from the LayerNorm-kernel plan of the batch-2 forward, both equally far from the oracle below)
+    assert d0 <= 4e-3 and d1 <= 4e-3, (d0, d1)
     # ---- batch 64 = the benchmark's own UNet batch (bench.py: num_samples 32, CFG): rows replicated 32x per CFG half
     rep64 = lambda t: torch.cat([t[:1].repeat(32, *([1] * (t.dim() - 1))), t[1:].repeat(32, *([1] * (t.dim() - 1)))])
     y64 = m(rep64(x).to(DEV), 801.0, rep64(enc).to(DEV), **kw(rep64(bbox), rep64(te), rep64(tid), rep64(db))).sample
@@ -237,7 +239,9 @@ def test_unet_sdxl_forward_vs_oracle_1024(sdxl_model):
     e0, e1 = _rel(y64[0], y[0]), _rel(y64[32], y[1])
     print(f"SDXL 1024x1024: batch-64 rows vs batch-2 rows rel-L2 {e0:.3e} / {e1:.3e}, bit-equal to the batch-32 rows: "
           f"{torch.equal(y64[0], y32[0]) and torch.equal(y64[32], y32[16])}")
-    assert e0 <= 2e-3 and e1 <= 2e-3, (e0, e1)
+    assert e0 <= 4e-3 and e1 <= 4e-3, (e0, e1)
+    eng64 = m._engines[next(k for k in m._engines if k[0] == 64)]
+    print(f"batch-64 plan: {len(eng64.forward_ops)} launches, {getattr(eng64, 'ln_fused_blocks', 0)} transformer blocks with fused LayerNorms")
     y64 = torch.stack([y64[0], y64[32]]).clone()
     torch.cuda.empty_cache()
     # ---- oracle (one forward, ~1 min on the GPU box's host cores)
