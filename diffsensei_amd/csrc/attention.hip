@@ -22,6 +22,8 @@ static int g_attn_variant = 0;  // 0 auto, 1 force 32 query rows per wave (QB = 
 void ds_attn_set_variant(int v) { g_attn_variant = v; }
 static long g_ip_min_blocks = 1024;  // ip_attn: double the query tiles per block while the grid keeps this many blocks
 void ds_ip_attn_set_min_blocks(int v) { g_ip_min_blocks = v; }
+static int g_ip_variant = 0;  // ip_attn: 0 auto, 1 force the 4-wave register-staged kernel, 2 force the 8-wave LDS-DMA ring kernel
+void ds_ip_attn_set_variant(int v) { g_ip_variant = v; }
 
 namespace {
 
@@ -272,30 +274,69 @@ constexpr int VSTR = 200;  // bytes per V^T row in LDS (96 keys * 2 B + 8 pad): 
 
 // (202 VGPRs -> two blocks per CU.  A build limited to 168 VGPRs for three blocks per CU spills 63 registers and is 20 %
 // slower: 128 vs 106 us at B = 32, heads 20, N = 1024 - profiles/r02_ipattn_occupancy.txt.)
-__global__ __launch_bounds__(256, 2) void ip_attn_kernel(const IPAttnParams p, int qt) {
-    __shared__ __attribute__((aligned(16))) char sKt[LP * 128];
-    __shared__ __attribute__((aligned(16))) char sKi[LP * 128];
-    __shared__ __attribute__((aligned(16))) char sVt[64 * VSTR];
-    __shared__ __attribute__((aligned(16))) char sVi[64 * VSTR];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+//
+// RING (round 4; large grids): the kernel's arithmetic is tiny (192 keys per query row) and what it was actually waiting for
+// was its own input and output - PMC (profiles/r03_pmc_conv_attn_ip_summary.txt): 45 % of the wave cycles in s_waitcnt, 2.2 TB/s.
+// Row-per-lane Q loads and O stores touch 32 cache lines per instruction for 32 bytes each (every 128-byte row slice took four
+// load and eight store instructions), and Q was requested only one tile (~1.4 us) ahead of its use with two waves per SIMD.
+// RING = true: eight waves share the panels (one block per CU, same two waves per SIMD), and every wave owns a ring of three
+// 4-KiB LDS slots: Q tiles arrive by LDS-DMA as WHOLE rows (8 lanes x 16 B per 128-byte row, 8 rows per instruction,
+// chunk-swizzled on the source address), two tiles ahead, with counted vmcnt waits and no barrier (the slots are wave-private);
+// the fragments are ds_read_b128.  The finished O tile is transposed through the slot its Q tile came from and leaves as whole
+// rows as well (16 bytes per lane, 4 instructions instead of 8).  Same arithmetic in the same order: bit-identical to RING = false.
+constexpr int IP_PANEL_BYTES = 2 * LP * 128 + 2 * 64 * VSTR;   // sKt | sKi | sVt | sVi
+constexpr int IP_SLOT = 4096;                                  // one wave's 32 x 64 f16 tile
+
+template <int NW, bool RING>
+__global__ __launch_bounds__(NW * 64, 2) void ip_attn_kernel(const IPAttnParams p, int qt) {
+    extern __shared__ __attribute__((aligned(16))) char ip_smem[];   // ONE LDS object (a second one de-pipelines LDS-DMA waits)
+    char* const sKt = ip_smem;
+    char* const sKi = ip_smem + LP * 128;
+    char* const sVt = ip_smem + 2 * LP * 128;
+    char* const sVi = ip_smem + 2 * LP * 128 + 64 * VSTR;
+    constexpr int ROWS = NW * 32;   // query rows per block and tile
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lhi = lane >> 5;
     const int b = blockIdx.y / p.heads, h = blockIdx.y % p.heads;
+    char* const ring = ip_smem + IP_PANEL_BYTES + wave * (3 * IP_SLOT);   // RING only
+    const int ntile = min(qt, (p.N - (int)blockIdx.x * qt * ROWS + ROWS - 1) / ROWS);   // tiles this block really has
 
     // Q fragments (B operand of S^T) are fetched one query tile ahead: the kernel runs two waves per SIMD, too few to
     // hide a global-load round trip inside the tile loop, and the first tile's rows are requested before the panels.
     h8 qn[4];
     auto load_q = [&](int it) {
-        const int qrow = min((int)(blockIdx.x * qt + it) * 128 + wave * 32 + l31, p.N - 1);
+        const int qrow = min((int)(blockIdx.x * qt + it) * ROWS + wave * 32 + l31, p.N - 1);
         const half_t* qp = p.q + ((long)b * p.N + qrow) * p.ldq + h * 64 + lhi * 8;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) qn[kk] = *reinterpret_cast<const h8*>(qp + kk * 16);
     };
-    load_q(0);
+    // RING: tile `it` of this wave -> slot it % 3, four 1-KiB LDS-DMA pieces of 8 whole rows each; LDS row r keeps its 16-byte
+    // chunk c at position c ^ ((r >> 1) & 7) (the swizzle is applied to the lane's SOURCE chunk, the DMA destination is linear)
+    auto dma_q = [&](int it) {
+        typedef __attribute__((address_space(3))) void lds_void;
+        typedef const __attribute__((address_space(1))) void glb_void;
+        char* dst = ring + (it % 3) * IP_SLOT;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = j * 8 + (lane >> 3);
+            const int qrow = min((int)(blockIdx.x * qt + it) * ROWS + wave * 32 + r, p.N - 1);
+            const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+            __builtin_amdgcn_global_load_lds((glb_void*)(p.q + ((long)b * p.N + qrow) * p.ldq + h * 64 + chunk * 8),
+                                             (lds_void*)(dst + j * 1024), 16, 0, 0);
+        }
+    };
+    if constexpr (RING) {
+        dma_q(0);
+        if (ntile > 1) dma_q(1);
+    } else {
+        load_q(0);
+    }
     // ---- stage the four panels once
     {
         const half_t* ktp = p.kt + (long)b * p.sk + h * 64;
         const half_t* kip = p.ki + (long)b * p.sk + h * 64;
-        for (int id = tid; id < LP * 8; id += 256) {
+        for (int id = tid; id < LP * 8; id += NW * 64) {
             const int row = id >> 3, c = id & 7;
             *reinterpret_cast<h8*>(&sKt[row * 128 + swz(row, c)]) =
                 *reinterpret_cast<const h8*>(ktp + (long)row * p.ldk + c * 8);
@@ -304,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void ip_attn_kernel(const IPAttnParams p, i
         }
         const half_t* vtp = p.vtt + (long)b * p.sv + (long)(h * 64) * LP;
         const half_t* vip = p.vti + (long)b * p.sv + (long)(h * 64) * LP;
-        for (int id = tid; id < 64 * 12; id += 256) {
+        for (int id = tid; id < 64 * 12; id += NW * 64) {
             const int row = id / 12, c = id - row * 12;
             const h8 a = *reinterpret_cast<const h8*>(vtp + (long)row * LP + c * 8);
             const h8 bb = *reinterpret_cast<const h8*>(vip + (long)row * LP + c * 8);
@@ -341,13 +382,36 @@ __global__ __launch_bounds__(256, 2) void ip_attn_kernel(const IPAttnParams p, i
     }
     const float ip_scale = p.ip_scale_ptr ? *p.ip_scale_ptr : p.ip_scale;
     for (int it = 0; it < qt; ++it) {
-        const int q0 = (blockIdx.x * qt + it) * 128 + wave * 32;
-        if (q0 >= p.N) break;  // wave-uniform
+        const int q0 = (blockIdx.x * qt + it) * ROWS + wave * 32;
+        if constexpr (RING) {
+            if (it >= ntile) break;   // block-uniform (a wave whose rows lie past N still walks its - clamped - tiles: the counts below stay fixed)
+        } else {
+            if (q0 >= p.N) break;     // wave-uniform
+        }
         const int qidx = min(q0 + l31, p.N - 1);
         h8 qf[4];
+        if constexpr (RING) {
+            // Vector-memory instructions this wave has issued behind tile it's four DMA pieces, in order: [4 O stores of tile
+            // it-2] 4 pieces of tile it+1 (requested at the top of tile it-1) [4 O stores of tile it-1] - vmcnt retires in issue
+            // order, so "all but those" is exact.  (Tile 0: only tile 1's pieces; the last tile has no successor's pieces.)
+            const int newer = (it + 1 < ntile ? 4 : 0) + (it >= 1 ? 4 : 0) + (it >= 2 ? 4 : 0);
+            if (newer >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else if (newer >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (newer >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const char* src = ring + (it % 3) * IP_SLOT;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) qf[kk] = qn[kk];
-        if (it + 1 < qt) load_q(it + 1);  // next tile's Q rows land under this tile's MFMAs / softmax
+            for (int kk = 0; kk < 4; ++kk) qf[kk] = *reinterpret_cast<const h8*>(src + l31 * 128 + swz(l31, kk * 2 + lhi));
+            // tile it+2 goes into the slot tile it-1 used (its Q fragments and its O transposition are long retired)
+            if (it + 2 < ntile) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                dma_q(it + 2);
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) qf[kk] = qn[kk];
+            if (it + 1 < qt) load_q(it + 1);  // next tile's Q rows land under this tile's MFMAs / softmax
+        }
         unsigned inside = 0;  // bit k set <=> the token lies in box k (region_flags() with the boxes in registers)
         {
             const int yi = qidx / p.mask_w, xi = qidx - yi * p.mask_w;
@@ -508,7 +572,28 @@ __global__ __launch_bounds__(256, 2) void ip_attn_kernel(const IPAttnParams p, i
                 }
             }
         }
-        if (q0 + l31 < p.N) {
+        if constexpr (RING) {
+            // O^T -> the tile's own (consumed) Q slot, rows of 128 bytes with the same chunk swizzle, -> whole rows out
+            char* ep = ring + (it % 3) * IP_SLOT;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    h4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (half_t)ot[db][4 * g + e];
+                    const int c = db * 32 + 8 * g + 4 * lhi;   // first of the lane's 4 columns
+                    *reinterpret_cast<h4*>(ep + l31 * 128 + swz(l31, c >> 3) + ((c >> 2) & 1) * 8) = o;
+                }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = i * 8 + (lane >> 3), ch = lane & 7;
+                const h8 v = *reinterpret_cast<const h8*>(ep + row * 128 + swz(row, ch));
+                // unconditional (the launcher only picks this variant for N % 256 == 0): the counted waits above assume four
+                // store instructions per tile and wave, and a store whose lanes are all masked off is branched around
+                *reinterpret_cast<h8*>(p.o + ((long)b * p.N + q0 + row) * p.ldo + h * 64 + ch * 8) = v;
+            }
+        } else if (q0 + l31 < p.N) {
             half_t* op = p.o + ((long)b * p.N + q0 + l31) * p.ldo + h * 64;
 #pragma unroll
             for (int db = 0; db < 2; ++db)
@@ -625,11 +710,33 @@ int ds_launch_ip_attn(const IPAttnParams& p0, hipStream_t stream) {
     DS_REQUIRE(p.n_dummy + p.max_ips * p.tok_per_ip == p.Li, "ip_attn: Li (%d) != n_dummy + max_ips*tok_per_ip", p.Li);
     DS_REQUIRE(p.mask_h * p.mask_w == p.N, "ip_attn: mask grid %dx%d != N %d", p.mask_h, p.mask_w, p.N);
     // walk several query tiles per block once there are plenty of blocks (amortises the K/V panel staging)
+    // Large grids (>= 4 blocks per CU of the 8-wave form, i.e. the benchmark's batches): the LDS-DMA ring variant, 256 query rows
+    // per block and tile; g_ip_variant 1 / 2 force the plain / the ring kernel (A/B, tests).
+    {
+        const int tiles8 = (p.N + 255) / 256;
+        int qt8 = 1;
+        while (qt8 < 8 && qt8 * 2 <= tiles8 && (long)((tiles8 + 2 * qt8 - 1) / (2 * qt8)) * p.B * p.heads >= g_ip_min_blocks) qt8 *= 2;
+        const long blocks8 = (long)((tiles8 + qt8 - 1) / qt8) * p.B * p.heads;
+        // Measured (profiles/r04_ipattn_ring_ab.txt, interleaved rounds): B = 64 N = 1024 163 -> 154 us, N = 4096 269 -> 246 us (four
+        // and eight tiles per block); with two tiles per block (B = 32 N = 1024, B = 8 N = 4096) the ring has nothing to run ahead
+        // of and the larger block loses 15-20 %: automatic only from four tiles per block on.
+        if (p.N % 256 == 0 && p.ldo % 8 == 0 && p.ldq % 8 == 0 &&
+            (g_ip_variant == 2 || (g_ip_variant == 0 && blocks8 >= g_ip_min_blocks && qt8 >= 4))) {
+            const size_t lds = IP_PANEL_BYTES + 8 * 3 * IP_SLOT;
+            auto kern = ip_attn_kernel<8, true>;
+            static unsigned long long attr_devs = 0;
+            if (ds_first_on_device(attr_devs))
+                DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, dim3((tiles8 + qt8 - 1) / qt8, p.B * p.heads), dim3(512), lds, stream, p, qt8);
+            DS_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     const int tiles = (p.N + 127) / 128;
     int qt = 1;
     while (qt < 8 && (long)((tiles + 2 * qt - 1) / (2 * qt)) * p.B * p.heads >= g_ip_min_blocks) qt *= 2;
     dim3 grid((tiles + qt - 1) / qt, p.B * p.heads);
-    hipLaunchKernelGGL(ip_attn_kernel, grid, dim3(256), 0, stream, p, qt);
+    hipLaunchKernelGGL((ip_attn_kernel<4, false>), grid, dim3(256), (size_t)IP_PANEL_BYTES, stream, p, qt);
     DS_LAUNCH_CHECK();
     return 0;
 }

@@ -99,6 +99,7 @@ int ds_launch_quantize_fp8(const half_t* x, long ldx, long sx, unsigned char* ou
 int ds_launch_self_attn_fp8(const SelfAttnParams& p, const unsigned char* k8, const unsigned char* vt8, hipStream_t stream);
 void ds_attn_set_variant(int v);  // 0 auto, 1 force 32 query rows per wave, 2 force 64 rows per wave, 3 force the software-pipelined kernel
 void ds_ip_attn_set_min_blocks(int v);
+void ds_ip_attn_set_variant(int v);  // 0 auto, 1 four-wave register-staged kernel, 2 eight-wave LDS-DMA ring kernel (N % 256 == 0)
 
 struct IPAttnParams {
     const half_t* q = nullptr;     // [B,N,C] rows (ldq)

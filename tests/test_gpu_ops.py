@@ -741,6 +741,47 @@ def test_masked_ip_attention_core(hip_lib, B, heads, hw):
     _close(y, ref, tol=4e-3, what="masked ip attn")
 
 
+@pytest.mark.parametrize("B,heads,hw", [(2, 2, (16, 16)), (3, 10, (32, 32)), (1, 20, (32, 64)), (2, 5, (48, 48)), (16, 20, (32, 32))])
+def test_masked_ip_attention_ring_variant(hip_lib, B, heads, hw):
+    """`ip_attn_kernel<8, true>` (round 4: Q tiles by LDS-DMA as whole rows into a wave-private ring of three slots, two tiles
+    ahead, counted vmcnt waits; O leaves as whole rows through the same slot) forced on small and large grids - one, two,
+    several tiles per block, last block with fewer tiles - must reproduce the register-staged kernel BIT FOR BIT (same
+    arithmetic in the same order) and the fp32 oracle at the usual tolerance; 20 back-to-back launches keep giving the same bits
+    (a counted wait that under-waits shows up as a rare wrong tile); N % 256 != 0 falls back to the register-staged kernel."""
+    from diffsensei_amd import _lib
+    from diffsensei_amd.attention_processor import LP
+    ops = _ops(hip_lib)
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(B * 7 + heads + hw[0])
+    N, C, X = hw[0] * hw[1], heads * 64, 128
+    q, enc = _r((B, N, C), g), _r((B, 157, X), g)
+    wk, wv, wki, wvi = (_r((C, X), g, 1 / math.sqrt(X)) for _ in range(4))
+    bbox = torch.zeros(B, 4, 4)
+    bbox[-1, 0] = torch.tensor([0.05, 0.10, 0.50, 0.95])
+    bbox[-1, 1] = torch.tensor([0.50, 0.10, 0.95, 0.95])
+    bbox[B // 2, 2] = torch.tensor([0.30, 0.30, 0.70, 0.60])
+    encd = enc.to(DEV)
+    txt, ip = ops.pad_rows(encd, 0, 77, LP), ops.pad_rows(encd, 77, 80, LP)
+    kt = ops.gemm(txt.view(-1, X), wk.to(DEV)).view(B, LP, C)
+    ki = ops.gemm(ip.view(-1, X), wki.to(DEV)).view(B, LP, C)
+    vtt, vti = ops.gemm_batched_nt(wv.to(DEV), txt), ops.gemm_batched_nt(wvi.to(DEV), ip)
+    qd, bd = q.to(DEV), bbox.to(DEV)
+    run = lambda: ops.masked_ip_attention(qd, kt, vtt, ki, vti, bd, heads, hw, 0.6)
+    try:
+        lib.ds_set_option(b"ip_attn_variant", 1)
+        y1 = run().clone()
+        for min_blocks in (1, 64, 1 << 20):          # 8, some, one tile(s) per block
+            lib.ds_set_option(b"ip_attn_min_blocks", min_blocks)
+            lib.ds_set_option(b"ip_attn_variant", 2)
+            for _ in range(20 if min_blocks == 1 else 2):
+                assert torch.equal(run(), y1), f"ring variant differs from the register-staged kernel (min_blocks {min_blocks})"
+    finally:
+        lib.ds_set_option(b"ip_attn_variant", 0)
+        lib.ds_set_option(b"ip_attn_min_blocks", 1024)
+    if B <= 3:
+        _close(y1, _ip_attn_ref(q, enc, bbox, hw, wk, wv, wki, wvi, heads, 0.6), tol=4e-3, what="masked ip attn (ring)")
+
+
 def test_processors_vs_reference_fixtures(hip_lib, golden_dir):
     """The HIP processors, called with the reference's processor protocol, against outputs of the reference's own
     MaskedIPAttnProcessor2_0 / AttnProcessor2_0 (fp32 on CPU): fp16 tolerance 1e-2 relative to max|y|."""
