@@ -71,6 +71,7 @@ struct GroupNormParams {
     float out_scale = 1.0f;    // y = act(norm(x)) * out_scale (the VAE decoder's scaled-fp16 mode; exact for powers of two)
 };
 size_t ds_groupnorm_ws_floats(int B, int C);
+void ds_groupnorm_set_variant(int v);  // 0 auto (round-4 geometry), 1 round-3 geometry (A/B)
 int ds_launch_groupnorm(const GroupNormParams& p, hipStream_t stream);
 int ds_launch_layernorm(const half_t* x, half_t* y, const half_t* gamma, const half_t* beta, int rows, int C,
                         float eps, hipStream_t stream);

@@ -25,12 +25,16 @@ struct GnGeom {
     int W, R, cc, c, row_start, row_end;
     bool active;
 };
+// A block covers up to 256 16-byte channel chunks (W lanes per row) and as many rows at a time as its threads allow
+// (R = blockDim / W).  512-thread blocks since round 4: with 256 threads the 1280-channel tensors (W = 160 -> R = 1) left 96
+// of 256 lanes idle; 512 threads give R = 3 (480 of 512 lanes active), and 480 or 512 active lanes for every width of the UNet
+// (320, 640, 960, 1280, 1920, 2560 channels).
 __device__ __forceinline__ GnGeom gn_geom(int C, int HW) {
     GnGeom g;
     const int ncc = C >> 3;
     const int slab0 = blockIdx.x * 256;
     g.W = min(ncc - slab0, 256);
-    g.R = 256 / g.W;
+    g.R = (int)blockDim.x / g.W;
     const int t = threadIdx.x;
     const int cw = t % g.W, r = t / g.W;
     g.active = r < g.R;
@@ -44,8 +48,8 @@ __device__ __forceinline__ GnGeom gn_geom(int C, int HW) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void gn_stats_kernel(GroupNormParams p) {
-    __shared__ float red[256 * 16];
+__global__ __launch_bounds__(512) void gn_stats_kernel(GroupNormParams p) {
+    __shared__ float red[512 * 16];
     const int C = p.C1 + p.C2;
     const GnGeom g = gn_geom(C, p.HW);
     const int b = blockIdx.z;
@@ -156,7 +160,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(GroupNormParams p, int
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void gn_apply_kernel(GroupNormParams p, int nchunks_stats) {
+__global__ __launch_bounds__(512) void gn_apply_kernel(GroupNormParams p, int nchunks_stats) {
     const int C = p.C1 + p.C2;
     const GnGeom g = gn_geom(C, p.HW);
     const int b = blockIdx.z;
@@ -285,6 +289,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict
 
 }  // namespace
 
+static int g_gn_variant = 0;  // 0: 512-thread blocks, >= 64 rows per block; 1: the round-3 geometry (256 threads, 8-row chunks)
+void ds_groupnorm_set_variant(int v) { g_gn_variant = v; }
+
 size_t ds_groupnorm_ws_floats(int B, int C) { return (size_t)B * GN_MAX_CHUNKS * C * 2 + (size_t)B * C * 2; }
 
 int ds_launch_groupnorm(const GroupNormParams& p, hipStream_t stream) {
@@ -293,17 +300,25 @@ int ds_launch_groupnorm(const GroupNormParams& p, hipStream_t stream) {
     DS_REQUIRE(C % p.groups == 0, "groupnorm: C (%d) not divisible by groups (%d)", C, p.groups);
     DS_REQUIRE(p.C1 % 8 == 0 && p.C2 % 8 == 0, "groupnorm: channel counts must be multiples of 8");
     DS_REQUIRE(p.ws != nullptr, "groupnorm: workspace missing");
-    const int nch = gn_chunks(p.HW);
     const int nslab = ((C >> 3) + 255) / 256;
+    // Row chunks per image: enough blocks for the chip (>= 1024) first, then >= 64 rows per block.  (The old rule - 8 rows per
+    // block up to 128 chunks - gave the 32 x 32-token level at UNet batch 64 blocks of 20 KiB that wrote 10 KiB of partial
+    // sums each: 84 MB of partials beside a 168 MB tensor.)  g_gn_variant 1 = the round-3 geometry (A/B).
+    int nch = gn_chunks(p.HW), threads = 256;
+    if (g_gn_variant == 0) {
+        const int want = (1024 + p.B * nslab - 1) / (p.B * nslab), by_rows = (p.HW + 63) / 64;
+        nch = min(nch, max(want, by_rows));
+        threads = 512;
+    }
     dim3 grid(nslab, nch, p.B);
     if (p.dtype == DS_DTYPE_BF16) {
-        hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, grid, dim3(256), 0, stream, p);
+        hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, grid, dim3(threads), 0, stream, p);
         hipLaunchKernelGGL(gn_finalize_kernel<bf16_t>, dim3(p.B, p.groups), dim3(256), 0, stream, p, nch);
-        hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, grid, dim3(256), 0, stream, p, nch);
+        hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, grid, dim3(threads), 0, stream, p, nch);
     } else {
-        hipLaunchKernelGGL(gn_stats_kernel<half_t>, grid, dim3(256), 0, stream, p);
+        hipLaunchKernelGGL(gn_stats_kernel<half_t>, grid, dim3(threads), 0, stream, p);
         hipLaunchKernelGGL(gn_finalize_kernel<half_t>, dim3(p.B, p.groups), dim3(256), 0, stream, p, nch);
-        hipLaunchKernelGGL(gn_apply_kernel<half_t>, grid, dim3(256), 0, stream, p, nch);
+        hipLaunchKernelGGL(gn_apply_kernel<half_t>, grid, dim3(threads), 0, stream, p, nch);
     }
     DS_LAUNCH_CHECK();
     return 0;
