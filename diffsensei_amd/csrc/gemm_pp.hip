@@ -97,8 +97,10 @@ __device__ __forceinline__ float dpp_f32(float v) {
     } while (0)
 
 // FUSE (fused LayerNorm, see the header): 0 none - the instantiation every other GEMM runs, its code is untouched by the
-// feature; 1 consumer (statistics + c pieces, one extra MFMA per accumulator block, rstd in the bias fma); 2 producer (row
-// statistics out of the plain epilogue).  Separate instantiations because the kernel sits exactly at its 256-register budget.
+// feature; 1 consumer with the plain epilogue, 9 consumer with the GEGLU epilogue (statistics + c pieces, one extra MFMA per
+// accumulator block, rstd applied to the accumulators / as the multiplier of the bias fma); 4 consumer in the operand-swapped
+// form; 2 producer (row statistics out of the plain epilogue).  Separate instantiations - each compiles only the epilogue it
+// runs - because the kernel sits exactly at its 256-register budget.
 template <typename T, int DBG, int FUSE = 0>  // T: half_t (UNet) or bf16_t (VAE decoder).  DBG: ablation builds only: 1 = no MFMA, 2 = no tile loads, 4 = no fragment reads (garbage results), 8 = no s_setprio, 16 = clock probe written over C[0..15]; 0 in production
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     typedef typename Elt<T>::v8 V8;
@@ -445,8 +447,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
                 for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = Elt<T>::mfma(cf[ni], mf, acc[mi][ni]);
                 asm volatile("" : "+v"(mf));   // keep the blocks in sequence (the scheduler would hoist all four fragment builds)
             }
-            // rstd of the lane's own tile row, applied to the accumulators in place: no register stays live across the
-            // epilogue for it, and the epilogues below are the unfused ones (acc + b')
+            // rstd of the lane's own tile row.  Plain epilogue: applied to the accumulators in place - no register stays live
+            // across the epilogue for it (its transposition overwrites all 4 KiB of `ep`).  GEGLU epilogue: its transposition
+            // only uses the first 2 KiB, so rstd is re-read from ep + 2048 per 32-row piece and is the multiplier of the fma
+            // that is the bias add otherwise (128 v_mul per wave and tile less on the GEMM with the most tiles).
+            if constexpr ((FUSE & 8) == 0) {
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) {
                 const float rs = *reinterpret_cast<const float*>(ep + 2048 + ((mi >> 1) * 64 + (mi & 1) * 32 + l31) * 8 + 4);
@@ -454,6 +459,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
                 for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[mi][ni][r] *= rs;
+            }
             }
         }
         if constexpr ((FUSE & 4) != 0) {
@@ -511,19 +517,28 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
             stage_prologue();
         }
         PP_FENCE();
-        if (FUSE != 2 && fast && geglu) {
+        if (FUSE != 2 && FUSE != 1 && FUSE != 4 && fast && (geglu || FUSE == 9)) {
             const int no = (cn0 >> 1) + wc * 32;
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) {
                 const int mb = cm0 + (mi >> 1) * 128 + wr * 64 + (mi & 1) * 32;
+                float rs = 1.0f;
+                if constexpr ((FUSE & 8) != 0)
+                    rs = *reinterpret_cast<const float*>(ep + 2048 + ((mi >> 1) * 64 + (mi & 1) * 32 + l31) * 8 + 4);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int c = 8 * g + 4 * lhi;
                     V4 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float hq = (float)(T)(acc[mi][0][4 * g + e] + (float)bq[g][e]);
-                        const float gq = (float)(T)(acc[mi][1][4 * g + e] + (float)bq[4 + g][e]);
+                        float hq, gq;
+                        if constexpr ((FUSE & 8) != 0) {
+                            hq = (float)(T)fmaf(acc[mi][0][4 * g + e], rs, (float)bq[g][e]);
+                            gq = (float)(T)fmaf(acc[mi][1][4 * g + e], rs, (float)bq[4 + g][e]);
+                        } else {
+                            hq = (float)(T)(acc[mi][0][4 * g + e] + (float)bq[g][e]);
+                            gq = (float)(T)(acc[mi][1][4 * g + e] + (float)bq[4 + g][e]);
+                        }
                         o[e] = (T)(hq * (float)(T)ds_gelu_erf(gq));
                     }
                     *reinterpret_cast<V4*>(ep + l31 * 64 + ((((c >> 3) ^ (l31 >> 2)) & 3) << 4) + ((c >> 2) & 1) * 8) = o;
@@ -535,7 +550,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
                     *reinterpret_cast<V8*>(Cg + (long)(mb + row) * p.ldc + no + ch * 8) = v;
                 }
             }
-        } else if (fast) {
+        } else if (FUSE != 9 && fast) {
             // two straight-line instances (with / without a residual): one body with `if (Rg)` inside carried the
             // never-written residual registers of the other case around the whole tile loop as spills
             auto plain = [&](auto resc) {
@@ -787,7 +802,8 @@ int ds_launch_gemm_pp(const GemmParams& p0, int batch, hipStream_t stream) {
         {17, gemm_pp_kernel<half_t, 17>}, {18, gemm_pp_kernel<half_t, 18>}, {20, gemm_pp_kernel<half_t, 20>}, {22, gemm_pp_kernel<half_t, 22>},
         {24, gemm_pp_kernel<half_t, 24>}, {32, gemm_pp_kernel<half_t, 32>}, {48, gemm_pp_kernel<half_t, 48>}, {49, gemm_pp_kernel<half_t, 49>}, {64, gemm_pp_kernel<half_t, 64>}, {128, gemm_pp_kernel<half_t, 128>},
 #endif
-        {-2, gemm_pp_kernel<half_t, 0, 1>},  // -2 / -3: fused LayerNorm, consumer / producer
+        {-2, gemm_pp_kernel<half_t, 0, 1>},  // -2 / -5 / -3: fused LayerNorm, consumer (plain / GEGLU epilogue) / producer
+        {-5, gemm_pp_kernel<half_t, 0, 9>},
         {-3, gemm_pp_kernel<half_t, 0, 2>},
         {-4, gemm_pp_kernel<half_t, 0, 4>},  // consumer in the operand-swapped (V^T) form
         {-1, gemm_pp_kernel<bf16_t, 0>}};  // -1: the bf16 build (VAE decoder), no ablation variants
@@ -812,7 +828,7 @@ int ds_launch_gemm_pp(const GemmParams& p0, int batch, hipStream_t stream) {
     dim3 grid(nblk, 1, 1);
     kern_t kern = nullptr;
     for (const auto& e : table)
-        if (e.dbg == (p.dtype == DS_DTYPE_BF16 ? -1 : p.ln_stats ? (p.ln_swapped ? -4 : -2) : p.stats_out ? -3 : (p.debug & 255))) kern = e.k;
+        if (e.dbg == (p.dtype == DS_DTYPE_BF16 ? -1 : p.ln_stats ? (p.ln_swapped ? -4 : p.epi == EPI_GEGLU ? -5 : -2) : p.stats_out ? -3 : (p.debug & 255))) kern = e.k;
     DS_REQUIRE(kern != nullptr, "gemm_pp: no ablation build for gemm_debug=%d", p.debug);
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, p);
     DS_LAUNCH_CHECK();

@@ -106,10 +106,11 @@ def run(nk, tails, ex_first=(EX_TAIL, EX_TAIL), ex_second=(EX_TAIL, 0), ex_top=E
 
 
 @pytest.mark.parametrize("nk", [2, 4, 10, 20, 80])
-@pytest.mark.parametrize("tails", [(8,), (9,), (17,), (29,), (8, 17, 9)])
+@pytest.mark.parametrize("tails", [(8,), (9,), (17,), (29,), (8, 17, 9), (11,), (19,), (33,), (11, 33, 19)])
 def test_handover_counts_hold(nk, tails):
     """EX_TAIL or more instructions behind every prologue (8 GEGLU stores, 8 pad pieces, +1 bias piece, 16 plain stores
-    + bias, 16 stores + 12 residual loads + bias): every read is covered, no slot is restaged under a reader."""
+    + bias, 16 stores + 12 residual loads + bias; round 4, fused LayerNorm: + 2 statistics / c pieces on a consumer -
+    11 GEGLU, 19 plain -, + 4 statistics stores on a producer - 33): every read is covered, no slot is restaged under a reader."""
     run(nk, tails)
 
 
