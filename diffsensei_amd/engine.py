@@ -464,21 +464,25 @@ class UNetEngine:
         # launches of every block are replaced by row statistics out of the producer's epilogue + a finalize launch (a few
         # us instead of 76 at batch 64); smaller batches and the 640-channel level keep the LayerNorm kernel
         lib = _lib.load()
-        fuse = (f"{p}.transformer_blocks.0.attn2.to_q.weight_ln" in w and ln_fusion_enabled()
-                and bool(lib.ds_gemm_ln_fusable(M, Cc, Cc, 0, 1)) and bool(lib.ds_gemm_ln_fusable(M, 8 * Cc, Cc, 1, 1))
-                and bool(lib.ds_gemm_ln_fusable(M, 2 * Cc, Cc, 0, 1)) and bool(lib.ds_gemm_ln_fusable(M, Cc, 4 * Cc, 0, 1))
-                and Np == N and bool(lib.ds_gemm_ln_fusable(Cc, N, Cc, 0, B)))
+        can = lambda m, n, k, epi=0, batch=1: bool(lib.ds_gemm_ln_fusable(m, n, k, epi, batch))
+        have = f"{p}.transformer_blocks.0.attn2.to_q.weight_ln" in w and ln_fusion_enabled()
+        # norm2 / norm3: producers = the two out-projections (N = K = C), consumers = attn2.to_q and the GEGLU projection
+        fuse = have and can(M, Cc, Cc) and can(M, 8 * Cc, Cc, 1)
+        # norm1 as well: producers = proj_in and the FF down-projection, consumers = q|k and the transposed to_v (mid-size
+        # batches run q|k on the 128 x 128 kernels: they keep the LayerNorm launch for norm1 only)
+        fuse1 = fuse and can(M, 2 * Cc, Cc) and can(M, Cc, 4 * Cc) and Np == N and can(Cc, N, Cc, 0, B)
         if fuse:
             part = self._buf32("ln_part", a.level, (Cc // 64) * M * 2)
             st = self._buf32("ln_stats", a.level, M * 2)
         self.ln_fused_blocks = getattr(self, "ln_fused_blocks", 0) + (a.depth if fuse else 0)
+        self.ln_fused_launches = getattr(self, "ln_fused_launches", 0) + a.depth * ((3 if fuse1 else 2) if fuse else 0)
         self._gn(ops, x, None, tn, w[p + ".norm.weight"], w[p + ".norm.bias"], N, Cc, 0, 1e-6, False)
         self._gemm(ops, tn, w[p + ".proj_in.weight"], h, M, Cc, Cc, bias=w[p + ".proj_in.bias"],
-                   stats_out=part if fuse else None)
+                   stats_out=part if fuse1 else None)
         for k in range(a.depth):
             t = f"{p}.transformer_blocks.{k}"
             # ---- attn1 (AttnProcessor2_0): q|k projection, V^T projection, flash attention, out-proj + residual
-            if fuse:     # norm1: statistics of h came out of proj_in / the previous block's FF down-projection
+            if fuse1:    # norm1: statistics of h came out of proj_in / the previous block's FF down-projection
                 ops.append(make_op("LN_FINALIZE", i=(M, Cc // 64, Cc), f=(1e-5,), p=(part, st)))
                 self._gemm(ops, h, w[t + ".attn1.qk.weight_ln"], qk, M, 2 * Cc, Cc, bias=w[t + ".attn1.qk.bias_ln"],
                            ln_stats=st, ln_c=w[t + ".attn1.qk.c_ln"])
@@ -532,7 +536,7 @@ class UNetEngine:
                 self._gemm(ops, tn, w[t + ".ff.net.0.proj.weight"], ff, M, 8 * Cc, Cc, bias=w[t + ".ff.net.0.proj.bias"],
                            geglu=True)
             self._gemm(ops, ff, w[t + ".ff.net.2.weight"], h, M, Cc, 4 * Cc, bias=w[t + ".ff.net.2.bias"], residual=h,
-                       stats_out=part if (fuse and k + 1 < a.depth) else None)
+                       stats_out=part if (fuse1 and k + 1 < a.depth) else None)
         self._gemm(ops, h, w[p + ".proj_out.weight"], out, M, Cc, Cc, bias=w[p + ".proj_out.bias"], residual=x)
 
     def _build_forward(self) -> List[DsOp]:
