@@ -253,6 +253,11 @@ constexpr int NPIECE2 = (HROWS2 + 7) / 8;  // 41 LDS-DMA pieces of 8 rows
 constexpr int PPW2 = (NPIECE2 + 3) / 4;    // 11 per wave
 constexpr int PBYTES2 = PPW2 * 4 * 1024;   // 44 KiB
 
+template <int V>
+struct IC2 {
+    static constexpr int value = V;
+};
+
 template <typename T>
 __global__ __launch_bounds__(256, 2) void conv_halo256_kernel(const GemmParams p) {
     typedef typename Elt<T>::v8 V8;
@@ -309,113 +314,123 @@ __global__ __launch_bounds__(256, 2) void conv_halo256_kernel(const GemmParams p
             __builtin_amdgcn_global_load_lds((glb_void*)(p.W + k0 + woff[j]), (lds_void*)(d + j * 1024), 16, 0, 0);
     };
 
-    int q0[4];  // GEMM row r = 128 wm + 32 mi + l31  <->  patch pixel (r >> 4, r & 15)
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) q0[mi] = (wm * 8 + mi * 2 + (l31 >> 4)) * HWD + (l31 & 15);
+    char* const sC = smem;   // epilogue staging tile (over the patch / W buffers once the k-loop is done)
+    auto body = [&](auto tailc) {
+        // TAIL: the block's channel tile has at most 64 valid columns (Cout = 320: every third tile).  The four waves then split
+        // the 256 pixels four ways over ONE 64-column strip (wave tile 64 x 64, 16 MFMAs per k-tile instead of 32) instead of
+        // two of them computing 64 columns nobody stores: the tile costs half a tile, bit-identical values.
+        constexpr bool TAIL = decltype(tailc)::value != 0;
+        constexpr int MI = TAIL ? 2 : 4;
+        const int rbase = TAIL ? wave * 64 : wm * 128, cbase = TAIL ? 0 : wn * 64;
+        int q0[MI];  // GEMM row r = rbase + 32 mi + l31  <->  patch pixel (r >> 4, r & 15)
+    #pragma unroll
+        for (int mi = 0; mi < MI; ++mi) q0[mi] = ((rbase >> 4) + mi * 2 + (l31 >> 4)) * HWD + (l31 & 15);
 
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        f32x16 acc[MI][2];
+    #pragma unroll
+        for (int i = 0; i < MI; ++i)
+    #pragma unroll
+            for (int j = 0; j < 2; ++j)
+    #pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int slices = p.Cin / 64;
-    const int nkt = slices * 9;
-    issue_patch(0);
-    issue_w(0, 0);
-    int s = 0, tap = 0;
-    for (int kt = 0; kt < nkt; ++kt) {
-        if (tap == 0 && kt > 0) {  // every wave is done with the previous slice's patch once it arrives here
-            __builtin_amdgcn_s_barrier();
+        const int slices = p.Cin / 64;
+        const int nkt = slices * 9;
+        issue_patch(0);
+        issue_w(0, 0);
+        int s = 0, tap = 0;
+        for (int kt = 0; kt < nkt; ++kt) {
+            if (tap == 0 && kt > 0) {  // every wave is done with the previous slice's patch once it arrives here
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                issue_patch(s * 64);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // W(kt) (and a new patch) have landed
+            __builtin_amdgcn_s_barrier();                      // ... everywhere; and buffer (kt+1)&1 has been drained
             asm volatile("" ::: "memory");
-            issue_patch(s * 64);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // W(kt) (and a new patch) have landed
-        __builtin_amdgcn_s_barrier();                      // ... everywhere; and buffer (kt+1)&1 has been drained
-        asm volatile("" ::: "memory");
-        if (kt + 1 < nkt) {
-            const int ntap = tap == 8 ? 0 : tap + 1, ns = tap == 8 ? s + 1 : s;
-            issue_w(ntap * p.Cin + ns * 64, (kt + 1) & 1);
-        }
-        const char* cW = sW + (kt & 1) * (BN * 128);
-        const int ky = tap / 3, kx = tap - 3 * ky;
-        const int shift = ky * HWD + kx;
-        int abase[4];
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            const int q = q0[mi] + shift;
-            abase[mi] = q * 128 + ((lhi ^ (((rowswz ? q : (l31 & 15) + kx) >> 1) & 7)) << 4);
-        }
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            V8 af[4], bf[2];
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi) af[mi] = *reinterpret_cast<const V8*>(sP + (abase[mi] ^ (kk << 5)));
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-                const int r = wn * 64 + ni * 32 + l31;
-                bf[ni] = *reinterpret_cast<const V8*>(cW + r * 128 + swz(r, kk * 2 + lhi));
+            if (kt + 1 < nkt) {
+                const int ntap = tap == 8 ? 0 : tap + 1, ns = tap == 8 ? s + 1 : s;
+                issue_w(ntap * p.Cin + ns * 64, (kt + 1) & 1);
             }
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = Elt<T>::mfma(bf[ni], af[mi], acc[mi][ni]);
-        }
-        if (tap == 8) {
-            tap = 0;
-            ++s;
-        } else {
-            ++tap;
-        }
-    }
-    __syncthreads();
-
-    // ---- epilogue: as the 8 x 16 kernel, 256 rows - but without a branch (and the s_waitcnt vmcnt(0) the compiler puts
-    // behind each conditional load) per 4 values: the bias + per-image bias of the lane's 8 column groups are fetched
-    // once (clamped addresses: masked columns are never stored), and the residual rows are loaded four 16-byte pieces
-    // at a time before they are needed.
-    char* const sC = smem;
-    V4 b0[2][4], b1[2][4];
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) b0[ni][g] = b1[ni][g] = V4{0, 0, 0, 0};
-    if (p.bias) {
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-                b0[ni][g] = *reinterpret_cast<const V4*>(p.bias + min(n0 + wn * 64 + ni * 32 + 8 * g + 4 * lhi, p.N - 4));
-    }
-    if (p.rowbias) {
-        const half_t* rb = p.rowbias + (long)b * p.rowbias_ld;
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-                b1[ni][g] = *reinterpret_cast<const V4*>(rb + min(n0 + wn * 64 + ni * 32 + 8 * g + 4 * lhi, p.N - 4));
-    }
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-        const int ms = wm * 128 + mi * 32 + l31;
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int nl = wn * 64 + ni * 32 + 8 * g + 4 * lhi;
-                V4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float v = acc[mi][ni][4 * g + e];
-                    v += (float)b0[ni][g][e];  // same order as the generic kernels: bias, then the per-image bias
-                    v += (float)b1[ni][g][e];
-                    o[e] = (T)v;
+            const char* cW = sW + (kt & 1) * (BN * 128);
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            const int shift = ky * HWD + kx;
+            int abase[MI];
+    #pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int q = q0[mi] + shift;
+                abase[mi] = q * 128 + ((lhi ^ (((rowswz ? q : (l31 & 15) + kx) >> 1) & 7)) << 4);
+            }
+    #pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                V8 af[MI], bf[2];
+    #pragma unroll
+                for (int mi = 0; mi < MI; ++mi) af[mi] = *reinterpret_cast<const V8*>(sP + (abase[mi] ^ (kk << 5)));
+    #pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const int r = cbase + ni * 32 + l31;
+                    bf[ni] = *reinterpret_cast<const V8*>(cW + r * 128 + swz(r, kk * 2 + lhi));
                 }
-                *reinterpret_cast<V4*>(sC + ms * CS_STRIDE + nl * 2) = o;
+    #pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+    #pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = Elt<T>::mfma(bf[ni], af[mi], acc[mi][ni]);
             }
-    }
+            if (tap == 8) {
+                tap = 0;
+                ++s;
+            } else {
+                ++tap;
+            }
+        }
+        __syncthreads();
+
+        // ---- epilogue: as the 8 x 16 kernel, 256 rows - but without a branch (and the s_waitcnt vmcnt(0) the compiler puts
+        // behind each conditional load) per 4 values: the bias + per-image bias of the lane's 8 column groups are fetched
+        // once (clamped addresses: masked columns are never stored), and the residual rows are loaded four 16-byte pieces
+        // at a time before they are needed.
+        V4 b0[2][4], b1[2][4];
+    #pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+    #pragma unroll
+            for (int g = 0; g < 4; ++g) b0[ni][g] = b1[ni][g] = V4{0, 0, 0, 0};
+        if (p.bias) {
+    #pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+    #pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    b0[ni][g] = *reinterpret_cast<const V4*>(p.bias + min(n0 + cbase + ni * 32 + 8 * g + 4 * lhi, p.N - 4));
+        }
+        if (p.rowbias) {
+            const half_t* rb = p.rowbias + (long)b * p.rowbias_ld;
+    #pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+    #pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    b1[ni][g] = *reinterpret_cast<const V4*>(rb + min(n0 + cbase + ni * 32 + 8 * g + 4 * lhi, p.N - 4));
+        }
+    #pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int ms = rbase + mi * 32 + l31;
+    #pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+    #pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int nl = cbase + ni * 32 + 8 * g + 4 * lhi;
+                    V4 o;
+    #pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc[mi][ni][4 * g + e];
+                        v += (float)b0[ni][g][e];  // same order as the generic kernels: bias, then the per-image bias
+                        v += (float)b1[ni][g][e];
+                        o[e] = (T)v;
+                    }
+                    *reinterpret_cast<V4*>(sC + ms * CS_STRIDE + nl * 2) = o;
+                }
+        }
+    };
+    if (p.N - n0 <= 64 && (p.debug & 2048) == 0) body(IC2<1>{});   // gemm_debug bit 11: A/B, tail tiles as full tiles
+    else body(IC2<0>{});
     __syncthreads();
     const T* const Rp = reinterpret_cast<const T*>(p.residual);
 #pragma unroll 1
