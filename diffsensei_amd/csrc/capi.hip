@@ -577,6 +577,7 @@ int ds_op_describe(const ds_op* op, char* name, int name_len, double* flops, dou
             GemmParams g;
             g.M = i[0]; g.N = i[1]; g.K = i[2];
             g.ln_stats = reinterpret_cast<const float*>(op->p[7]); g.stats_out = reinterpret_cast<float*>(op->p[9]);
+            g.ln_swapped = i[8]; g.epi = i[4];
             const int batch = i[5] > 0 ? i[5] : 1;
             nm = ds_gemm_kernel_name(g, batch);
             fl = 2.0 * i[0] * (double)i[1] * i[2] * batch;

@@ -700,11 +700,13 @@ bool ds_gemm_pp_fast_path(int M, int N, int K, int batch, int epi) {
 }
 
 const char* ds_gemm_kernel_name(const GemmParams& p, int batch) {
-    if (p.ln_stats || p.stats_out) return "gemm_pp_kernel<0>";
+    // the fused-LayerNorm instantiations of gemm_pp_kernel are kernels of their own in a rocprofv3 trace (template argument FUSE)
+    if (p.ln_stats) return p.ln_swapped ? "gemm_pp_kernel<0,4>" : p.epi == EPI_GEGLU ? "gemm_pp_kernel<0,9>" : "gemm_pp_kernel<0,1>";
+    if (p.stats_out) return "gemm_pp_kernel<0,2>";
     const Choice c = choose(p, batch);
     const bool conv = p.conv != 0;
     switch (c.kind) {
-        case K_PP: return "gemm_pp_kernel<0>";
+        case K_PP: return "gemm_pp_kernel<0,0>";
         case K_HALO: return "conv_halo_kernel";
         case K_RING: return c.bm == 4 ? "gemm_glds_kernel<64,false,4>" : "gemm_glds_kernel<64,false,3>";
         case K_GLDS1:

@@ -7,12 +7,13 @@ import json, re, sys
 
 path, M, N, K = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 epi = sys.argv[5] if len(sys.argv) > 5 else "geglu"
+fused = epi.endswith("_ln")
 vals = {}
 for line in open(path):
     m = re.match(r"\s+(\w+)\s+([0-9.]+)\s+\(avg over", line)
     if m:
         vals[m.group(1)] = float(m.group(2))
-n_out = N // 2 if epi == "geglu" else N
+n_out = N // 2 if epi.startswith("geglu") else N
 alg = 2 * (M * K + N * K + M * n_out)                       # A + W read once, C written once (f16)
 fetch_kb, write_kb = vals["FETCH_SIZE"], vals["WRITE_SIZE"]
 traffic = int(fetch_kb * 1024 * 2 + write_kb * 1024)
@@ -20,7 +21,7 @@ hit = vals.get("TCC_HIT_sum", 0.0) / max(vals.get("TCC_HIT_sum", 0.0) + vals.get
 # GRBM_GUI_ACTIVE is summed over the 8 XCDs, each with 32 CUs x 4 SIMDs (the round-1/2 definition of the figure)
 busy = vals.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / max(128.0 * vals.get("GRBM_GUI_ACTIVE", 0.0), 1.0)
 print(json.dumps({
-    "kernel": "gemm_pp_kernel<0>",
+    "kernel": "gemm_pp_kernel" + ("<half,0,9> (fused-LayerNorm consumer, GEGLU epilogue)" if fused else "<half,0,0>"),
     "command": f"bash tools/gpu_pmc_pp.sh (SHAPE='{M} {N} {K}'; rocprofv3 --pmc <counters> --kernel-trace, one pass per counter group; "
                f"target: tools/one_gemm.py {M} {N} {K} 0 3 {epi}); JSON by tools/pmc_pp_json.py",
     "shape": {"M": M, "N": N, "K": K, "epilogue": epi},
