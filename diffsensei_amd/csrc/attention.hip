@@ -710,18 +710,20 @@ int ds_launch_ip_attn(const IPAttnParams& p0, hipStream_t stream) {
     DS_REQUIRE(p.n_dummy + p.max_ips * p.tok_per_ip == p.Li, "ip_attn: Li (%d) != n_dummy + max_ips*tok_per_ip", p.Li);
     DS_REQUIRE(p.mask_h * p.mask_w == p.N, "ip_attn: mask grid %dx%d != N %d", p.mask_h, p.mask_w, p.N);
     // walk several query tiles per block once there are plenty of blocks (amortises the K/V panel staging)
-    // Large grids (>= 4 blocks per CU of the 8-wave form, i.e. the benchmark's batches): the LDS-DMA ring variant, 256 query rows
-    // per block and tile; g_ip_variant 1 / 2 force the plain / the ring kernel (A/B, tests).
+    // The 8-wave LDS-DMA ring variant, 256 query rows per block and tile: g_ip_variant 2 only (see below).
     {
         const int tiles8 = (p.N + 255) / 256;
         int qt8 = 1;
         while (qt8 < 8 && qt8 * 2 <= tiles8 && (long)((tiles8 + 2 * qt8 - 1) / (2 * qt8)) * p.B * p.heads >= g_ip_min_blocks) qt8 *= 2;
         const long blocks8 = (long)((tiles8 + qt8 - 1) / qt8) * p.B * p.heads;
-        // Measured (profiles/r04_ipattn_ring_ab.txt, interleaved rounds): B = 64 N = 1024 163 -> 154 us, N = 4096 269 -> 246 us (four
-        // and eight tiles per block); with two tiles per block (B = 32 N = 1024, B = 8 N = 4096) the ring has nothing to run ahead
-        // of and the larger block loses 15-20 %: automatic only from four tiles per block on.
-        if (p.N % 256 == 0 && p.ldo % 8 == 0 && p.ldq % 8 == 0 &&
-            (g_ip_variant == 2 || (g_ip_variant == 0 && blocks8 >= g_ip_min_blocks && qt8 >= 4))) {
+        // Measured (profiles/r04_ipattn_ring_ab.txt): back to back on its own, B = 64 N = 1024 163 -> 154 us, N = 4096 269 -> 246 us (four
+        // and eight tiles per block; with two tiles per block the ring has nothing to run ahead of and the larger block loses
+        // 15-20 %) - but INSIDE the UNet forward, where Q has just been written by the to_q GEMM, the same launches take 0.35 ms
+        // per forward LONGER than the register-staged kernel (in-situ A/B, three interleaved rounds; the rocprofv3 trace of a
+        // whole call agrees: 214 vs 188 us per launch).  The kernel is VALU-bound, not bound by its loads and stores: the
+        // variant is kept for A/B (ip_attn_variant 2, bit-identical) and never chosen automatically.
+        (void)blocks8;
+        if (p.N % 256 == 0 && p.ldo % 8 == 0 && p.ldq % 8 == 0 && g_ip_variant == 2) {
             const size_t lds = IP_PANEL_BYTES + 8 * 3 * IP_SLOT;
             auto kern = ip_attn_kernel<8, true>;
             static unsigned long long attr_devs = 0;
