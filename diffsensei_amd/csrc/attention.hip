@@ -275,10 +275,12 @@ constexpr int VSTR = 200;  // bytes per V^T row in LDS (96 keys * 2 B + 8 pad): 
 // (202 VGPRs -> two blocks per CU.  A build limited to 168 VGPRs for three blocks per CU spills 63 registers and is 20 %
 // slower: 128 vs 106 us at B = 32, heads 20, N = 1024 - profiles/r02_ipattn_occupancy.txt.)
 //
-// RING (round 4; large grids): the kernel's arithmetic is tiny (192 keys per query row) and what it was actually waiting for
-// was its own input and output - PMC (profiles/r03_pmc_conv_attn_ip_summary.txt): 45 % of the wave cycles in s_waitcnt, 2.2 TB/s.
-// Row-per-lane Q loads and O stores touch 32 cache lines per instruction for 32 bytes each (every 128-byte row slice took four
-// load and eight store instructions), and Q was requested only one tile (~1.4 us) ahead of its use with two waves per SIMD.
+// RING (round 4; an experiment kept for A/B - ip_attn_variant 2 - and never chosen automatically: see ds_launch_ip_attn).
+// Hypothesis: the kernel's arithmetic is tiny (192 keys per query row) and what it waits for is its own input and output - PMC
+// (profiles/r03_pmc_conv_attn_ip_summary.txt): 45 % of the wave cycles in s_waitcnt, 2.2 TB/s; row-per-lane Q loads and O stores
+// touch 32 cache lines per instruction for 32 bytes each (every 128-byte row slice took four load and eight store instructions),
+// and Q was requested only one tile (~1.4 us) ahead of its use with two waves per SIMD.  Outcome: +6-9 % back to back, 0.35 ms
+// per forward SLOWER inside the UNet forward - the kernel is VALU-bound (96 scores per lane and tile), not I/O-bound.
 // RING = true: eight waves share the panels (one block per CU, same two waves per SIMD), and every wave owns a ring of three
 // 4-KiB LDS slots: Q tiles arrive by LDS-DMA as WHOLE rows (8 lanes x 16 B per 128-byte row, 8 rows per instruction,
 // chunk-swizzled on the source address), two tiles ahead, with counted vmcnt waits and no barrier (the slots are wave-private);
