@@ -193,7 +193,7 @@ def test_committed_bench_line_follows_the_contract():
     """The round-end bench line kept under profiles/ carries every key the driver's contract names."""
     import json
     import os
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r03_bench_default_ns32_final.json")
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r04_bench_default_ns32_final.json")
     line = json.loads(open(path).read().strip().splitlines()[-1])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "parity"):
@@ -206,6 +206,11 @@ def test_committed_bench_line_follows_the_contract():
     assert "workload" in line["config"] and "model" not in line["config"]
     r = line["roofline"]
     assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["traffic"]
+    inst = r["instantiations"]          # round 4: the dominant kernel has five instantiations; their launches add up to the kernel's
+    assert sum(v["launches"] for v in inst.values()) == r["launches_per_forward"] and all(k.startswith(r["kernel"]) for k in inst)
+    vp = line["config"]["vae_precision"]
+    assert vp["engine"] == "fp16-scaled" and vp["reference"].startswith("fp32") and \
+        0 < vp["fp32_decode_exposure"]["value_lower_bound_if_fp32_decode"] < line["value"]
     c = line["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
 
