@@ -52,11 +52,6 @@ int ds_set_option(const char* key, int value) {
         ds_ip_attn_set_min_blocks(value);
         return 0;
     }
-    if (strcmp(key, "gemm_row_variant") == 0) {
-        DS_REQUIRE(value >= 0 && value <= 2, "gemm_row_variant must be 0 (auto), 1 (never) or 2 (always where applicable)");
-        ds_gemm_row_set_variant(value);
-        return 0;
-    }
     if (strcmp(key, "gn_variant") == 0) {
         DS_REQUIRE(value >= 0 && value <= 1, "gn_variant must be 0 (auto) or 1 (round-3 geometry)");
         ds_groupnorm_set_variant(value);

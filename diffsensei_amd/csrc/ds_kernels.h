@@ -39,10 +39,6 @@ struct GemmParams {
 int ds_launch_gemm(const GemmParams& p, int batch, hipStream_t stream);
 bool ds_gemm_pp_applicable(const GemmParams& p);  // gemm_pp.hip: 256 x 256 ping-pong kernel takes this shape
 int ds_launch_gemm_pp(const GemmParams& p, int batch, hipStream_t stream);
-bool ds_gemm_row_applicable(const GemmParams& p, int batch);  // gemm_row.hip: 128 rows x all 640 columns per block (N == 640)
-bool ds_gemm_row_preferred(const GemmParams& p, int batch);   //   ... and the dispatch rule says it is the faster choice
-int ds_launch_gemm_row(const GemmParams& p, hipStream_t stream);
-void ds_gemm_row_set_variant(int v);  // 0 auto, 1 never, 2 always where applicable
 bool ds_conv_halo_applicable(const GemmParams& p);  // conv_halo.hip: halo-patch 3x3 convolution takes this shape
 int ds_launch_conv_halo(const GemmParams& p, hipStream_t stream);
 void ds_conv_halo_set_variant(int v);  // 0 auto, 1 8x16-pixel blocks, 2 16x16-pixel blocks

@@ -604,7 +604,7 @@ int launch_ring(const GemmParams& p0, int batch, hipStream_t stream) {
     return 0;
 }
 
-enum Kind { K_REG, K_GLDS2, K_GLDS1, K_PP, K_HALO, K_RING, K_ROW };
+enum Kind { K_REG, K_GLDS2, K_GLDS1, K_PP, K_HALO, K_RING };
 struct Choice {
     Kind kind;
     int bm;   // rows of the block tile
@@ -645,11 +645,6 @@ Choice choose(const GemmParams& p, int batch) {
     }
     if (g_gemm_variant != 0) {  // forced family did not apply to this shape
         c.kind = K_GLDS2;
-        return c;
-    }
-    if (!conv && ds_gemm_row_preferred(p, batch)) {   // N = 640, large M: 128 rows x all 640 columns per block (gemm_row.hip)
-        c.kind = K_ROW;
-        c.bm = 128;
         return c;
     }
     if (conv) {
@@ -712,7 +707,6 @@ const char* ds_gemm_kernel_name(const GemmParams& p, int batch) {
     const bool conv = p.conv != 0;
     switch (c.kind) {
         case K_PP: return "gemm_pp_kernel<0,0>";
-        case K_ROW: return "gemm_row640_kernel";
         case K_HALO: return "conv_halo_kernel";
         case K_RING: return c.bm == 4 ? "gemm_glds_kernel<64,false,4>" : "gemm_glds_kernel<64,false,3>";
         case K_GLDS1:
@@ -759,7 +753,6 @@ int ds_launch_gemm(const GemmParams& p_in, int batch, hipStream_t stream) {
     }
     switch (c.kind) {
         case K_PP: return ds_launch_gemm_pp(p, batch, stream);
-        case K_ROW: return ds_launch_gemm_row(p, stream);
         case K_HALO: return ds_launch_conv_halo(p, stream);
         case K_RING: return c.bm == 4 ? launch_ring<4>(p, batch, stream) : launch_ring<3>(p, batch, stream);
         case K_GLDS1:

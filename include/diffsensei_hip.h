@@ -47,9 +47,6 @@ int ds_device_info(int* cu_count, int* lds_bytes, char* arch_name, int arch_name
  *   "ip_attn_variant"    0 / 1 the register-staged ip_attn_kernel<4,false> | 2 force the 8-wave LDS-DMA ring kernel
  *                        ip_attn_kernel<8,true> where N % 256 == 0 - bit-identical results; faster back to back, slower inside the
  *                        UNet forward, so never automatic (A/B: profiles/r04_ipattn_ring_ab.txt, r04_forward_option_ab.txt)
- *   "gemm_row_variant"   0 auto (N == 640, M >= 65536: gemm_row640_kernel, 128 rows x all 640 columns per block) | 1 never |
- *                        2 always where the shape allows (M % 128 == 0, K % 32 == 0, plain epilogue) - bit-identical results
- *                        (A/B: profiles/r04_gemm_row640_ab.txt)
  *   "gn_variant"         0 (default) GroupNorm on 512-thread blocks with >= 64 rows per block | 1 the round-3 geometry
  *                        (256 threads, 8-row chunks; A/B: profiles/r04_gn_geometry_ab.txt)
  *   "llm_gemv_variant"   0 auto (software-pipelined persistent GEMV) | 1 one column per wavefront | 2 un-pipelined streaming GEMV

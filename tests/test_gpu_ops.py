@@ -233,45 +233,6 @@ def test_gemm_ring_buffered_small_grid_kernel(hip_lib, M, N, K):
         assert torch.equal(a, c), "ring-buffered and one-buffer kernels differ"
 
 
-@pytest.mark.parametrize("M,K,bias,res", [(256, 64, True, False), (512, 640, True, True), (1024, 2560, True, True),
-                                          (384, 640, False, False), (2048, 1280, False, True)])
-def test_gemm_row640_kernel(hip_lib, M, K, bias, res):
-    """`gemm_row640_kernel` (round 4: one block = 128 rows x ALL 640 columns, A streamed once, three-stage LDS-DMA ring with
-    k-tiles of 32) forced on small problems - two k-tiles up to eighty, with / without bias and residual - vs the fp32
-    reference, bit-identical to the 128 x 128 kernel (same MFMA order per output element), and 10 back-to-back launches keep
-    giving the same bits; shapes it does not take (N != 640, ragged M) fall back silently to the other kernels."""
-    from diffsensei_amd import _lib
-    ops = _ops(hip_lib)
-    lib = _lib.load()
-    g = torch.Generator().manual_seed(M + K)
-    N = 640
-    x, w = _r((M, K), g), _r((N, K), g, 1 / math.sqrt(K))
-    b = _r((N,), g) if bias else None
-    r = _r((M, N), g) if res else None
-    dv = lambda t: None if t is None else t.to(DEV)
-    ref = x.float() @ w.float().t()
-    if bias:
-        ref = ref + b.float()
-    if res:
-        ref = ref.half().float() + r.float()
-    try:
-        lib.ds_set_option(b"gemm_row_variant", 1)
-        lib.ds_set_option(b"gemm_variant", 8)
-        y0 = ops.gemm(dv(x), dv(w), dv(b), dv(r)).clone()
-        lib.ds_set_option(b"gemm_variant", 0)
-        lib.ds_set_option(b"gemm_row_variant", 2)
-        for _ in range(10):
-            y = ops.gemm(dv(x), dv(w), dv(b), dv(r))
-            assert torch.equal(y, y0), "gemm_row640_kernel differs from the 128 x 128 kernel"
-        # shapes outside the kernel's domain: served by the other kernels, same API
-        y2 = ops.gemm(dv(x[: M - 16]), dv(w), dv(b), None if r is None else dv(r[: M - 16]))
-        assert torch.equal(y2, y0[: M - 16])
-    finally:
-        lib.ds_set_option(b"gemm_row_variant", 0)
-        lib.ds_set_option(b"gemm_variant", 0)
-    _close(y0, ref, what="row640")
-
-
 @pytest.mark.parametrize("M,C", [(256, 128), (2048, 640), (777, 256)])
 def test_gemm_geglu(hip_lib, M, C):
     from diffsensei_amd.engine import pack_geglu
