@@ -115,6 +115,17 @@ int ds_gemm_ln_f16(const void* x, int64_t ldx, const void* gw, int64_t ldw, cons
     return ds_launch_gemm(p, 1, S(stream));
 }
 
+int ds_gemm_ln_partial_f16(const void* x, int64_t ldx, const void* gw, int64_t ldw, const void* bias_ln, const float* ln_partial,
+                           float eps, const void* ln_c, const void* residual, int64_t ldr, void* y, int64_t ldy, float* stats_out,
+                           int M, int N, int K, int epilogue, void* stream) {
+    GemmParams p;
+    p.A = H(x); p.lda = ldx; p.K1 = K; p.W = H(gw); p.ldw = ldw; p.bias = H(bias_ln); p.residual = H(residual); p.ldr = ldr;
+    p.C = HM(y); p.ldc = ldy; p.M = M; p.N = N; p.K = K; p.epi = epilogue;
+    p.ln_stats = ln_partial; p.ln_partial = 1; p.ln_eps = eps; p.ln_c = H(ln_c); p.stats_out = stats_out;
+    DS_REQUIRE(ln_partial && ln_c, "ds_gemm_ln_partial_f16: the partial sums and c are required");
+    return ds_launch_gemm(p, 1, S(stream));
+}
+
 int ds_ln_finalize(const float* partial, float* stats, int M, int strips, int C, float eps, void* stream) {
     return ds_launch_ln_finalize(partial, stats, M, strips, C, eps, S(stream));
 }
@@ -130,7 +141,7 @@ int ds_gemm_ln_swapped_f16(const void* a, int64_t lda, const void* x, int64_t ld
     return ds_launch_gemm(p, batch, S(stream));
 }
 
-int ds_gemm_ln_fusable(int M, int N, int K, int epilogue, int batch) { return ds_gemm_pp_fast_path(M, N, K, batch, epilogue) ? 1 : 0; }
+int ds_gemm_ln_fusable(int M, int N, int K, int epilogue, int batch) { return ds_gemm_ln_kind(M, N, K, batch, epilogue); }
 
 int ds_gemm_f16_batched(const void* x, int64_t ldx, int64_t sx, const void* w, int64_t ldw, int64_t sw, void* y,
                         int64_t ldy, int64_t sy, int M, int N, int K, int batch, void* stream) {
@@ -466,6 +477,7 @@ static int run_op(const ds_op& o, hipStream_t st) {
             g.rowbias_ld = i[6]; g.rows_per_group = i[7] > 0 ? i[7] : 1;
             g.ln_stats = reinterpret_cast<const float*>(p[7]); g.ln_c = H(p[8]); g.stats_out = reinterpret_cast<float*>(p[9]);
             g.ln_swapped = i[8]; g.ln_bstride = l[10];
+            g.ln_partial = i[9]; g.ln_eps = i[9] ? o.f[0] : g.ln_eps;
             return ds_launch_gemm(g, i[5] > 0 ? i[5] : 1, st);
         }
         case DS_OP_LN_FINALIZE:
@@ -577,7 +589,8 @@ int ds_op_describe(const ds_op* op, char* name, int name_len, double* flops, dou
             GemmParams g;
             g.M = i[0]; g.N = i[1]; g.K = i[2];
             g.ln_stats = reinterpret_cast<const float*>(op->p[7]); g.stats_out = reinterpret_cast<float*>(op->p[9]);
-            g.ln_swapped = i[8]; g.epi = i[4];
+            g.ln_swapped = i[8]; g.epi = i[4]; g.ln_partial = i[9];
+            g.lda = g.ldw = g.K1 = g.K; g.ldc = g.N;
             const int batch = i[5] > 0 ? i[5] : 1;
             nm = ds_gemm_kernel_name(g, batch);
             fl = 2.0 * i[0] * (double)i[1] * i[2] * batch;

@@ -82,25 +82,61 @@ inline bool ds_first_on_device(unsigned long long& seen) {
 
 // ---- device helpers ------------------------------------------------------------------------------
 __device__ __forceinline__ float ds_silu(float x) { return x / (1.0f + __expf(-x)); }
-// Exact (erf) GELU, branch-free: gelu(x) = x * Phi(x) with Phi(-|x|) = erfc(z)/2, z = |x|/sqrt(2), and
-// erfc(z) = t P(t) exp(-z^2), t = 1/(1 + 0.37 z) - degree-7 fit of erfc(z) exp(z^2), max relative error 3.9e-7 on
-// z in [0, 8] (tools/fit_gelu.py prints these coefficients and the error statistics).  Half the instructions of
-// 0.5 x (1 + erff(x/sqrt 2)) (ocml's erff is two divergent branches), and no 1 + erf cancellation in the negative
-// tail: after rounding to f16 it differs from the exact value in 4e-5 of cases (that form: 1.6e-2).  In the 256 x 256
-// GEGLU GEMM the erf was 13-20 % of the kernel (profiles/r01_gemm_pp_microbench.txt).
+// Exact (erf) GELU, branch-free, ONE transcendental: gelu(x) = max(x, 0) - |x| Phi(-|x|), and
+// log2 Phi(-a) = log2(erfcx(a / sqrt 2) / 2) - a^2 log2(e) / 2 is smooth enough on a in [0, 5.75] for one degree-10 polynomial
+// (max error 5e-7 in the exponent = 3.5e-7 RELATIVE in Phi(-a), so the negative tail keeps its relative accuracy - no
+// 1 + erf cancellation; beyond 5.75 |gelu - max(x, 0)| is below half an f16 subnormal, |x| is clamped at 8 and the fit is only
+// kept monotone).  tools/fit_gelu.py derives the coefficients and checks the f32 evaluation order below on ALL finite f16
+// inputs (tests/test_gelu_fit.py repeats it on the constants parsed from this file): after rounding to f16 it differs from
+// the exact value on 3e-4 of them (1.1e-4 / 5.7e-5 of N(0,1) / N(0,2) samples), always by one ulp;
+// 0.5 x (1 + erff(x / sqrt 2)) - what torch's fp32 kernel computes - differs on 5e-3 of them (1.6e-2 of N(0,2)), by up to two.
+// Round 4: replaces the round-1 form t P(t) exp(-z^2), t = 1 / (1 + 0.37 z) (same accuracy class: 4e-5) - v_rcp_f32 and
+// v_exp_f32 are both quarter-rate, and in the 256 x 256 GEGLU GEMM the 64 evaluations per lane were ~4 us of every
+// 41-us tile with the matrix pipe idle: 10 fma (5 v_pk_fma_f32 per pair) + v_exp_f32 + 3 instead of
+// ~15 + v_rcp_f32 + v_exp_f32.  A NaN gate comes out as 0 (v_max / v_min drop it); the hidden value it multiplies in GEGLU
+// is NaN then anyway (same input row).
 __device__ __forceinline__ float ds_gelu_erf(float x) {
-    const float ax = fabsf(x);
-    const float t = __builtin_amdgcn_rcpf(fmaf(ax, 0.26162950903902255f, 1.0f));
-    float P = -7.287154991e-02f;
-    P = fmaf(P, t, 2.236382245e-01f);
-    P = fmaf(P, t, -1.017244238e-01f);
-    P = fmaf(P, t, 1.651046857e-01f);
-    P = fmaf(P, t, 7.372602999e-02f);
-    P = fmaf(P, t, 1.079816715e-01f);
-    P = fmaf(P, t, 1.041452194e-01f);
-    const float u = ax * 0.8493218002880191f;                  // u^2 = z^2 log2(e)
-    const float r = (P * t) * __builtin_amdgcn_exp2f(-(u * u));  // erfc(z) / 2 = Phi(-|x|)
-    return x * (x < 0.f ? r : 1.0f - r);
+    const float a = fminf(fabsf(x), 8.0f);
+    float q = -9.521883721e-09f;
+    q = fmaf(q, a, 3.357761849e-07f);
+    q = fmaf(q, a, -4.994478671e-06f);
+    q = fmaf(q, a, 3.903887141e-05f);
+    q = fmaf(q, a, -1.394536987e-04f);
+    q = fmaf(q, a, -3.214741642e-04f);
+    q = fmaf(q, a, 7.390159313e-03f);
+    q = fmaf(q, a, -5.278805848e-02f);
+    q = fmaf(q, a, -4.590846261e-01f);
+    q = fmaf(q, a, -1.151124720e+00f);
+    q = fmaf(q, a, -9.999994968e-01f);
+    float y = fmaf(-a, __builtin_amdgcn_exp2f(q), fmaxf(x, 0.f));  // q = log2 Phi(-a)
+    // The f32 result is pinned in a register: callers round it to f16, and a compiler free to fold that rounding into this fma
+    // (v_fma_mixlo_f16 rounds the exact sum once; fma + convert rounds twice) does so for some call sites and not for others
+    // - the bits of an element would then depend on where in a tile it sits (profiles/r04_determinism_bisect.txt).
+    asm("" : "+v"(y));
+    return y;
+}
+// Two values at once, the Horner chain spelled as <2 x float> fmas: left to itself the compiler evaluates the scalar form with
+// v_fmaak_f32 (literal addend, one element per instruction); as vector fmas the chain is 10 v_pk_fma_f32 per PAIR with the
+// coefficients splat from registers.  Bit-identical to ds_gelu_erf per element (same operations in the same order).
+__device__ __forceinline__ f32x2 ds_gelu_erf2(f32x2 x) {
+    const f32x2 a = {fminf(fabsf(x[0]), 8.0f), fminf(fabsf(x[1]), 8.0f)};
+    auto k = [](float c) { return f32x2{c, c}; };
+    f32x2 q = k(-9.521883721e-09f);
+    q = __builtin_elementwise_fma(q, a, k(3.357761849e-07f));
+    q = __builtin_elementwise_fma(q, a, k(-4.994478671e-06f));
+    q = __builtin_elementwise_fma(q, a, k(3.903887141e-05f));
+    q = __builtin_elementwise_fma(q, a, k(-1.394536987e-04f));
+    q = __builtin_elementwise_fma(q, a, k(-3.214741642e-04f));
+    q = __builtin_elementwise_fma(q, a, k(7.390159313e-03f));
+    q = __builtin_elementwise_fma(q, a, k(-5.278805848e-02f));
+    q = __builtin_elementwise_fma(q, a, k(-4.590846261e-01f));
+    q = __builtin_elementwise_fma(q, a, k(-1.151124720e+00f));
+    q = __builtin_elementwise_fma(q, a, k(-9.999994968e-01f));
+    const f32x2 r = {__builtin_amdgcn_exp2f(q[0]), __builtin_amdgcn_exp2f(q[1])};
+    const f32x2 relu = {fmaxf(x[0], 0.f), fmaxf(x[1], 0.f)};
+    f32x2 y = __builtin_elementwise_fma(-a, r, relu);
+    asm("" : "+v"(y));  // as in ds_gelu_erf: the rounding to f16 stays a separate instruction
+    return y;
 }
 
 // Source index of nearest-neighbour resizing exactly as ATen computes it (F.interpolate(mode="nearest"), the op behind
@@ -109,6 +145,13 @@ __device__ __forceinline__ float ds_gelu_erf(float x) {
 // diffusers then resizes to the skip tensor's size (forward_upsample_size).
 __device__ __forceinline__ int nearest_src(int dst, float scale, int in_size) {
     return min((int)floorf((float)dst * scale), in_size - 1);
+}
+
+// v_mov_b32 with a DPP control: 0xB1 = quad_perm [1,0,3,2] (lane ^ 1), 0x4E = quad_perm [2,3,0,1] (lane ^ 2),
+// 0x141 = row_half_mirror (lane j of every 8 <-> lane 7 - j)
+template <int CTRL>
+__device__ __forceinline__ float ds_dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -33,10 +33,13 @@ struct GemmParams {
     int ln_swapped = 0;                // consumer, operand-swapped form (V^T = Wv X_b^T): the normalised rows are the rows of W
                                        // (tile columns): ln_stats[b * ln_bstride + n], ln_c = [M][4] f16 (-c hi, -c lo, b' hi, b' lo)
     long ln_bstride = 0;               //   rows of the normalised matrix per batch item
+    int ln_partial = 0;                // consumer on the 128-wide LDS-DMA kernels (gemm.hip, "Fused LayerNorm"): ln_stats points at the
+    float ln_eps = 1e-5f;              //   producer's PARTIALS [K/64][M] float2 and the epilogue finalises its own rows (eps = ln_eps)
     int dtype = DS_DTYPE_F16;  // element type of A / W / C / bias / residual (the pointers are 2-byte opaque): bf16 = VAE path
     int debug = 0;  // ablation only (ds_set_option "gemm_debug"): 1 skip MFMA, 2 skip tile loads — results are garbage
 };
 int ds_launch_gemm(const GemmParams& p, int batch, hipStream_t stream);
+int ds_gemm_ln_kind(int M, int N, int K, int batch, int epi);  // fused LayerNorm: 1 = gemm_pp_kernel, 2 = 128-wide kernels, 0 = none
 bool ds_gemm_pp_applicable(const GemmParams& p);  // gemm_pp.hip: 256 x 256 ping-pong kernel takes this shape
 int ds_launch_gemm_pp(const GemmParams& p, int batch, hipStream_t stream);
 bool ds_conv_halo_applicable(const GemmParams& p);  // conv_halo.hip: halo-patch 3x3 convolution takes this shape

@@ -69,7 +69,18 @@ __device__ __forceinline__ void mma_tile(const char* cA, const char* cB, f32x16 
 // stage 1: bias / row-group bias, round to f16, park the tile in LDS as [m][n] (BM > 128 goes in 128-row halves);
 // stage 2: coalesced 16-byte rows out of LDS (+ activation, + residual, or GEGLU pairing).
 // D layout (operands swapped): lane holds row m_local = ..+(lane&31); regs r -> n = (r&3)+8*(r>>2)+4*(lane>>5)
-template <int BM, int WR, int NT>  // block rows, rows per wave, threads per block
+//
+// Fused LayerNorm (LNF; the plain GEMMs of the LDS-DMA kernels; gemm_pp.hip's header has the algebra): the small-batch and
+// 640-channel counterpart of gemm_pp_kernel's producer / consumer pair, in the SAME statistics format, so producers and
+// consumers of either family combine.
+//   producer (p.stats_out): stage 2 holds the final f16 values (residual added) as 8 columns per thread, 16 threads per row:
+//     (sum, sum of squares) per row and 64-column strip - a 3-step butterfly over the 8 lanes of a strip - go to
+//     stats_out[(n / 64) * M + m] (float2).  Needs N % 128 == 0 (every strip complete).
+//   consumer (p.ln_stats with p.ln_partial): the lane owns tile ROW m in stage 1, so it sums the row's K / 64 partials itself
+//     (the order of ln_finalize_kernel: four interleaved chains, then (0 + 1) + (2 + 3) - the same bits as the finalize
+//     launch the 256 x 256 consumers use) and applies y = rstd (acc - mean c_n) + b'_n in fp32 where the bias add was:
+//     no finalize launch, no LayerNorm launch.  c_n comes as the negated f16 (hi, lo) pair the 256 x 256 kernel uses.
+template <int BM, int WR, int NT, bool LNF = false>  // block rows, rows per wave, threads per block, fused-LayerNorm code compiled in
 __device__ __forceinline__ void epilogue(const GemmParams& p, f32x16 (&acc)[WR / 32][2], char* smem, int m0, int n0,
                                          long bz, int wm, int wn, int l31, int lhi, int tid) {
     constexpr int MI = WR / 32;
@@ -92,6 +103,67 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x16 (&acc)[WR /
             for (int g = 0; g < 4; ++g)
                 bq[ni][g] = *reinterpret_cast<const h4*>(p.bias + min(n0 + wn * 64 + ni * 32 + 8 * g + 4 * lhi, p.N - 4));
     }
+    const bool ln_in = LNF && p.ln_stats != nullptr;
+    // consumer: (mean, rstd) of the lane's rows from the producer's partial sums.  Every load of every row is in flight at
+    // once - ONE round trip to L2 (a chain of loads per row, row after row, cost 15 us per launch: ten round trips in the
+    // epilogue of every block).  The two half-waves hold the same rows: lanes 0..31 sum chains 0 and 1 of ln_finalize_kernel's
+    // four interleaved chains, lanes 32..63 chains 2 and 3, and one cross-half exchange gives (0 + 1) + (2 + 3) - the very
+    // bits of the finalize launch (fp32 addition commutes).
+    float ln_mean[MI], ln_rstd[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) ln_mean[mi] = 0.f, ln_rstd[mi] = 1.f;
+    if constexpr (LNF) {
+        if (ln_in) {
+            const int strips = p.K >> 6;
+            float sa[MI][2], qa[MI][2];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) sa[mi][0] = sa[mi][1] = qa[mi][0] = qa[mi][1] = 0.f;
+            constexpr int JJ = MI == 1 ? 5 : 3;   // strips per chain and round: 20 (K = 1280 in one round) or, with two rows per lane, 12
+            for (int base = 0; base < strips; base += 4 * JJ) {
+                f32x2 t[MI][2][JJ];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    const int m = min(m0 + wm * WR + mi * 32 + l31, p.M - 1);
+                    const f32x2* part = reinterpret_cast<const f32x2*>(p.ln_stats) + m;
+#pragma unroll
+                    for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+                        for (int jj = 0; jj < JJ; ++jj) {
+                            const int j = base + 2 * lhi + cc + 4 * jj;
+                            t[mi][cc][jj] = part[(long)min(j, strips - 1) * p.M];
+                        }
+                }
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+                        for (int jj = 0; jj < JJ; ++jj) {
+                            const bool in = base + 2 * lhi + cc + 4 * jj < strips;
+                            sa[mi][cc] += in ? t[mi][cc][jj][0] : 0.f;
+                            qa[mi][cc] += in ? t[mi][cc][jj][1] : 0.f;
+                        }
+            }
+            const float inv_c = 1.0f / (float)p.K;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const float s2 = sa[mi][0] + sa[mi][1], q2 = qa[mi][0] + qa[mi][1];
+                const float s = s2 + __shfl_xor(s2, 32, 64), q = q2 + __shfl_xor(q2, 32, 64);
+                ln_mean[mi] = s * inv_c;
+                ln_rstd[mi] = rsqrtf(fmaxf(fmaf(-ln_mean[mi], ln_mean[mi], q * inv_c), 0.f) + p.ln_eps);
+            }
+        }
+    }
+    h8 cq[2][4];  // fused LayerNorm, consumer: (-c hi, -c lo) of the lane's 4 columns per (ni, g)
+    if constexpr (LNF) {
+        if (ln_in) {
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    cq[ni][g] = *reinterpret_cast<const h8*>(p.ln_c + 2 * min(n0 + wn * 64 + ni * 32 + 8 * g + 4 * lhi, p.N - 4));
+        }
+    }
 #pragma unroll
     for (int half = 0; half < HALVES; ++half) {
         if (half) __syncthreads();
@@ -102,6 +174,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x16 (&acc)[WR /
             const int ms = ml - half * HR;
             const int m = m0 + ml;
             const int grp = p.rowbias ? ((m < p.M ? m : p.M - 1) / p.rows_per_group) : 0;
+            const float mean = ln_mean[mi], rstd = ln_rstd[mi];
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
 #pragma unroll
@@ -111,6 +184,15 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x16 (&acc)[WR /
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][4 * g + e] + (float)bq[ni][g][e];
+                    if constexpr (LNF) {
+                        if (ln_in) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float nc = (float)cq[ni][g][2 * e] + (float)cq[ni][g][2 * e + 1];   // -c_n
+                                v[e] = fmaf(fmaf(mean, nc, acc[mi][ni][4 * g + e]), rstd, (float)bq[ni][g][e]);
+                            }
+                        }
+                    }
                     if (n < p.N) {
                         if (p.rowbias) {
                             const h4 bv = *reinterpret_cast<const h4*>(p.rowbias + (long)grp * p.rowbias_ld + n);
@@ -140,9 +222,10 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x16 (&acc)[WR /
                     const h8 gv = *reinterpret_cast<const h8*>(sC + row * CS_STRIDE + 128 + c * 16);
                     h8 o;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const half_t ge = (half_t)ds_gelu_erf((float)gv[e]);
-                        o[e] = (half_t)((float)hv[e] * (float)ge);
+                    for (int e = 0; e < 8; e += 2) {
+                        const f32x2 ge = ds_gelu_erf2(f32x2{(float)gv[e], (float)gv[e + 1]});
+                        o[e] = (half_t)((float)hv[e] * (float)(half_t)ge[0]);
+                        o[e + 1] = (half_t)((float)hv[e + 1] * (float)(half_t)ge[1]);
                     }
                     *reinterpret_cast<h8*>(Cg + (long)m * p.ldc + n) = o;
                 }
@@ -165,11 +248,16 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x16 (&acc)[WR /
                 const int id = tid + NT * j;
                 const int row = id >> 4, c = id & 15;
                 const int m = mh + row, n = n0 + c * 8;
+                float sv = 0.f, qv = 0.f;
                 if (m < p.M && n < p.N) {
                     h8 v = *reinterpret_cast<const h8*>(sC + row * CS_STRIDE + c * 16);
                     if (p.epi == EPI_GELU) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = (half_t)ds_gelu_erf((float)v[e]);
+                        for (int e = 0; e < 8; e += 2) {
+                            const f32x2 ge = ds_gelu_erf2(f32x2{(float)v[e], (float)v[e + 1]});
+                            v[e] = (half_t)ge[0];
+                            v[e + 1] = (half_t)ge[1];
+                        }
                     } else if (p.epi == EPI_QUICK_GELU) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
@@ -183,6 +271,33 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x16 (&acc)[WR /
                         for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rv[e]);
                     }
                     *reinterpret_cast<h8*>(Cg + (long)m * p.ldc + n) = v;
+                    if constexpr (LNF) {
+                        if (p.stats_out) {
+                            float s1 = 0.f, q1 = 0.f;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                const float f = (float)v[e];
+                                s1 += f;
+                                q1 = fmaf(f, f, q1);
+                            }
+                            sv = s1, qv = q1;
+                        }
+                    }
+                }
+                if constexpr (LNF) {
+                    // the 8 lanes c & 7 of a row's 64-column strip: every lane of the wave takes part (rows past M carry zeros)
+                    if (p.stats_out) {
+                        sv += ds_dpp_f32<0xB1>(sv);   // lane ^ 1, lane ^ 2, then lane j <-> 7 - j of every 8
+                        qv += ds_dpp_f32<0xB1>(qv);
+                        sv += ds_dpp_f32<0x4E>(sv);
+                        qv += ds_dpp_f32<0x4E>(qv);
+                        sv += ds_dpp_f32<0x141>(sv);
+                        qv += ds_dpp_f32<0x141>(qv);
+                        if ((c & 7) == 0 && m < p.M && n < p.N) {
+                            f32x2 o2 = {sv, qv};
+                            *reinterpret_cast<f32x2*>(p.stats_out + 2 * ((long)(n >> 6) * p.M + m)) = o2;
+                        }
+                    }
                 }
             }
         }
@@ -360,7 +475,7 @@ __global__ __launch_bounds__(256, (BM > 128 ? 1 : (STAGES >= 4 ? 1 : (STAGES == 
             fill = fill + 1 == STAGES ? 0 : fill + 1;
         }
         __syncthreads();
-        epilogue<BM, BM / 2, 256>(p, acc, smem, m0, n0, bz, wm, wn, l31, lhi, tid);
+        epilogue<BM, BM / 2, 256, !CONV>(p, acc, smem, m0, n0, bz, wm, wn, l31, lhi, tid);
         return;
     }
     const bool deep = STAGES == 2 && !(p.debug & 8);  // debug 8: one barrier per tile, DMA one tile ahead (A/B switch)
@@ -419,7 +534,7 @@ __global__ __launch_bounds__(256, (BM > 128 ? 1 : (STAGES >= 4 ? 1 : (STAGES == 
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[kk][ni], af[kk][mi], acc[mi][ni], 0, 0, 0);
     }
     __syncthreads();
-    epilogue<BM, BM / 2, 256>(p, acc, smem, m0, n0, bz, wm, wn, l31, lhi, tid);
+    epilogue<BM, BM / 2, 256, !CONV>(p, acc, smem, m0, n0, bz, wm, wn, l31, lhi, tid);
 }
 
 // ---------------------------------------------------------------------------------------------- register staging
@@ -689,20 +804,31 @@ Choice choose(const GemmParams& p, int batch) {
 }  // namespace
 
 // Would ds_launch_gemm run this plain f16 GEMM on gemm_pp_kernel with every tile on a branch-free epilogue?  (The launch-plan
-// builder asks before it replaces a LayerNorm launch by the fused producer / consumer pair; small batches keep the LayerNorm.)
+// builder asks before it replaces a LayerNorm launch by the fused producer / consumer pair.)
 bool ds_gemm_pp_fast_path(int M, int N, int K, int batch, int epi) {
+    return ds_gemm_ln_kind(M, N, K, batch, epi) == 1;
+}
+
+// Which fused-LayerNorm implementation would ds_launch_gemm use for this plain f16 GEMM: 1 = gemm_pp_kernel (every tile on
+// a branch-free epilogue: M, N multiples of 256; consumers read the (mean, rstd) of ds_launch_ln_finalize), 2 = the 128-wide
+// LDS-DMA kernels (their shared epilogue; consumers finalise the partial sums themselves: GemmParams::ln_partial), 0 = neither
+// (register-staged fallback, ragged N, a forced A/B family).
+int ds_gemm_ln_kind(int M, int N, int K, int batch, int epi) {
     GemmParams p;
     p.M = M; p.N = N; p.K = K; p.lda = K; p.ldw = K; p.ldc = N; p.epi = epi; p.K1 = K;
-    if (M <= 0 || N <= 0 || K <= 0 || M % 256 || N % 256 || batch < 1 || (epi != EPI_NONE && epi != EPI_GEGLU)) return false;
-    if (g_gemm_variant != 0 && g_gemm_variant != 3) return false;
-    if (!ds_gemm_pp_applicable(p)) return false;
-    return g_gemm_variant == 3 || choose(p, batch).kind == K_PP;
+    if (M <= 0 || N <= 0 || K <= 0 || batch < 1 || (epi != EPI_NONE && epi != EPI_GEGLU)) return 0;
+    if (g_gemm_variant == 3) return (M % 256 == 0 && N % 256 == 0 && ds_gemm_pp_applicable(p)) ? 1 : 0;
+    if (g_gemm_variant != 0) return 0;
+    const Kind k = choose(p, batch).kind;
+    if (k == K_PP) return (M % 256 == 0 && N % 256 == 0) ? 1 : 0;
+    if ((k == K_GLDS1 || k == K_GLDS2 || k == K_RING) && batch == 1 && N % 128 == 0 && K % 64 == 0) return 2;
+    return 0;
 }
 
 const char* ds_gemm_kernel_name(const GemmParams& p, int batch) {
     // the fused-LayerNorm instantiations of gemm_pp_kernel are kernels of their own in a rocprofv3 trace (template argument FUSE)
-    if (p.ln_stats) return p.ln_swapped ? "gemm_pp_kernel<0,4>" : p.epi == EPI_GEGLU ? "gemm_pp_kernel<0,9>" : "gemm_pp_kernel<0,1>";
-    if (p.stats_out) return "gemm_pp_kernel<0,2>";
+    if (p.ln_stats && !p.ln_partial) return p.ln_swapped ? "gemm_pp_kernel<0,4>" : p.epi == EPI_GEGLU ? "gemm_pp_kernel<0,9>" : "gemm_pp_kernel<0,1>";
+    if (p.stats_out && ds_gemm_ln_kind(p.M, p.N, p.K, batch, p.epi) == 1) return "gemm_pp_kernel<0,2>";
     const Choice c = choose(p, batch);
     const bool conv = p.conv != 0;
     switch (c.kind) {
@@ -738,9 +864,35 @@ int ds_launch_gemm(const GemmParams& p_in, int batch, hipStream_t stream) {
     }
     if (p.epi == EPI_GEGLU) DS_REQUIRE(p.N % 128 == 0, "geglu: packed N (%d) must be a multiple of 128", p.N);
     Choice c = choose(p, batch);
-    if (p.ln_stats || p.ln_c || p.stats_out) {  // fused LayerNorm exists in gemm_pp_kernel only (the caller asked ds_gemm_ln_fusable)
-        DS_REQUIRE(!conv && ds_gemm_pp_applicable(p), "gemm: fused LayerNorm needs the 256 x 256 kernel (M=%d N=%d K=%d)", p.M, p.N, p.K);
-        c.kind = K_PP;
+    if (p.ln_stats || p.ln_c || p.stats_out) {
+        // Fused LayerNorm.  The planner asks ds_gemm_ln_fusable which form the dispatch gives a shape and builds the pair
+        // accordingly; a direct call is served by whichever family implements the role it names:
+        //   consumer of finalised statistics, operand-swapped consumer: gemm_pp_kernel (whole 256 x 256 tiles);
+        //   consumer of partial sums: the 128-wide kernels (shared epilogue of this file);
+        //   producer: the consumer's family if the call is both, else what the dispatch picks, else whichever can.
+        DS_REQUIRE(!conv && p.dtype == DS_DTYPE_F16 && !p.A2 && !p.rowbias, "gemm: fused LayerNorm is a plain f16 GEMM feature");
+        const bool pp_ok = ds_gemm_pp_applicable(p) && (p.ln_swapped || (p.M % 256 == 0 && p.N % 256 == 0));
+        const bool wide_ok = batch == 1 && p.N % 128 == 0 && p.K % 64 == 0;
+        const bool wide_kind = c.kind == K_GLDS1 || c.kind == K_GLDS2 || c.kind == K_RING;
+        auto force_wide = [&]() {
+            if (!wide_kind) { c.kind = K_GLDS1; c.bm = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) < 384 ? 64 : 128; }
+        };
+        if (p.ln_stats && p.ln_partial) {
+            DS_REQUIRE(wide_ok && p.ln_c && !p.ln_swapped, "gemm: a consumer of partial LayerNorm sums needs N %% 128 == 0, K %% 64 == 0, no batch (M=%d N=%d K=%d)", p.M, p.N, p.K);
+            force_wide();
+        } else if (p.ln_stats) {
+            DS_REQUIRE(pp_ok && p.ln_c, "gemm: a consumer of finalised LayerNorm statistics needs the 256 x 256 kernel (M=%d N=%d K=%d)", p.M, p.N, p.K);
+            c.kind = K_PP;
+        }
+        if (p.stats_out) {
+            DS_REQUIRE(p.epi == EPI_NONE && !p.ln_swapped, "gemm: LayerNorm statistics come out of the plain epilogue only");
+            if (p.ln_stats) {
+                DS_REQUIRE(c.kind == K_PP || wide_ok, "gemm: LayerNorm statistics cannot be emitted for M=%d N=%d K=%d", p.M, p.N, p.K);
+            } else if (c.kind == K_PP ? !pp_ok : !(wide_kind && wide_ok)) {
+                DS_REQUIRE(pp_ok || wide_ok, "gemm: LayerNorm statistics cannot be emitted for M=%d N=%d K=%d", p.M, p.N, p.K);
+                if (pp_ok) c.kind = K_PP; else force_wide();
+            }
+        }
     }
     if (p.dtype != DS_DTYPE_F16) {  // bf16 (VAE decoder): only the two kernels that are templated on the element type
         if (conv) {

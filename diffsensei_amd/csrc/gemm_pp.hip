@@ -519,9 +519,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
         PP_FENCE();
         if (FUSE != 2 && FUSE != 1 && FUSE != 4 && fast && (geglu || FUSE == 9)) {
             const int no = (cn0 >> 1) + wc * 32;
+            // store addresses = (uniform 64-bit base of the piece's rows) + zext(32-bit lane offset): the SGPR-base form of
+            // global_store - per-lane 64-bit row * ldc products were 40 % of the branch-free epilogues' VALU instructions
+            char* const Cw = reinterpret_cast<char*>(Cg) + ((long)(cm0 + wr * 64) * p.ldc + no) * 2;
+            const unsigned vC = (unsigned)(((lane_e >> 2) * p.ldc + (lane_e & 3) * 8) * 2);
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) {
-                const int mb = cm0 + (mi >> 1) * 128 + wr * 64 + (mi & 1) * 32;
                 float rs = 1.0f;
                 if constexpr ((FUSE & 8) != 0)
                     rs = *reinterpret_cast<const float*>(ep + 2048 + ((mi >> 1) * 64 + (mi & 1) * 32 + l31) * 8 + 4);
@@ -529,17 +532,34 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
                 for (int g = 0; g < 4; ++g) {
                     const int c = 8 * g + 4 * lhi;
                     V4 o;
+                    float hq[4], gq[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float hq, gq;
+                    for (int e = 0; e < 4; e += 2) {
+                        // The sums are formed in f32 and rounded to f16 in a SEPARATE instruction, pair by pair: left alone, the
+                        // compiler folds some of these (not all - it depends on the registers at hand) into v_fma_mixlo_f16,
+                        // which rounds the exact sum once, and a row's bits then depend on the accumulator slot it sits in -
+                        // found by tools/replicate_determinism.py (profiles/r04_determinism_bisect.txt).  The empty asm pins
+                        // the f32 pair in registers between the two steps.
+                        f32x2 hs, gs;
                         if constexpr ((FUSE & 8) != 0) {
-                            hq = (float)(T)fmaf(acc[mi][0][4 * g + e], rs, (float)bq[g][e]);
-                            gq = (float)(T)fmaf(acc[mi][1][4 * g + e], rs, (float)bq[4 + g][e]);
+                            const f32x2 r2 = {rs, rs};
+                            hs = __builtin_elementwise_fma(f32x2{acc[mi][0][4 * g + e], acc[mi][0][4 * g + e + 1]}, r2,
+                                                           f32x2{(float)bq[g][e], (float)bq[g][e + 1]});
+                            gs = __builtin_elementwise_fma(f32x2{acc[mi][1][4 * g + e], acc[mi][1][4 * g + e + 1]}, r2,
+                                                           f32x2{(float)bq[4 + g][e], (float)bq[4 + g][e + 1]});
                         } else {
-                            hq = (float)(T)(acc[mi][0][4 * g + e] + (float)bq[g][e]);
-                            gq = (float)(T)(acc[mi][1][4 * g + e] + (float)bq[4 + g][e]);
+                            hs = f32x2{acc[mi][0][4 * g + e], acc[mi][0][4 * g + e + 1]} + f32x2{(float)bq[g][e], (float)bq[g][e + 1]};
+                            gs = f32x2{acc[mi][1][4 * g + e], acc[mi][1][4 * g + e + 1]} + f32x2{(float)bq[4 + g][e], (float)bq[4 + g][e + 1]};
                         }
-                        o[e] = (T)(hq * (float)(T)ds_gelu_erf(gq));
+                        asm("" : "+v"(hs), "+v"(gs));
+                        hq[e] = (float)(T)hs[0], hq[e + 1] = (float)(T)hs[1];
+                        gq[e] = (float)(T)gs[0], gq[e + 1] = (float)(T)gs[1];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; e += 2) {
+                        const f32x2 ge = ds_gelu_erf2(f32x2{gq[e], gq[e + 1]});
+                        o[e] = (T)(hq[e] * (float)(T)ge[0]);
+                        o[e + 1] = (T)(hq[e + 1] * (float)(T)ge[1]);
                     }
                     *reinterpret_cast<V4*>(ep + l31 * 64 + ((((c >> 3) ^ (l31 >> 2)) & 3) << 4) + ((c >> 2) & 1) * 8) = o;
                 }
@@ -547,7 +567,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
                 for (int i = 0; i < 2; ++i) {
                     const int row = i * 16 + (lane_e >> 2), ch = lane_e & 3;
                     const V8 v = *reinterpret_cast<const V8*>(ep + row * 64 + (((ch ^ (row >> 2)) & 3) << 4));
-                    *reinterpret_cast<V8*>(Cg + (long)(mb + row) * p.ldc + no + ch * 8) = v;
+                    char* const Cr = Cw + (long)((mi >> 1) * 128 + (mi & 1) * 32 + i * 16) * p.ldc * 2;
+                    *reinterpret_cast<V8*>(Cr + (size_t)vC) = v;
                 }
             }
         } else if (FUSE != 9 && fast) {
@@ -556,11 +577,17 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
             auto plain = [&](auto resc) {
                 constexpr bool RES = decltype(resc)::value != 0;
                 V8 rv[4];
+                // addresses = (uniform 64-bit base of the rows) + zext(32-bit lane offset), as in the GEGLU epilogue above
+                char* const Cw = reinterpret_cast<char*>(Cg) + ((long)(cm0 + wr * 64) * p.ldc + nwp) * 2;
+                const char* const Rw = RES ? reinterpret_cast<const char*>(Rg) + ((long)(cm0 + wr * 64) * p.ldr + nwp) * 2 : nullptr;
+                const unsigned vC = (unsigned)(((lane_e >> 3) * p.ldc + (lane_e & 7) * 8) * 2);
+                const unsigned vR = (unsigned)(((lane_e >> 3) * p.ldr + (lane_e & 7) * 8) * 2);
                 auto load_res = [&](int mi) {
-                    const int mb = cm0 + (mi >> 1) * 128 + wr * 64 + (mi & 1) * 32;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        rv[i] = *reinterpret_cast<const V8*>(Rg + (long)(mb + i * 8 + (lane_e >> 3)) * p.ldr + nwp + (lane_e & 7) * 8);
+                    for (int i = 0; i < 4; ++i) {
+                        const char* const Rr = Rw + (long)((mi >> 1) * 128 + (mi & 1) * 32 + i * 8) * p.ldr * 2;
+                        rv[i] = *reinterpret_cast<const V8*>(Rr + (size_t)vR);
+                    }
                 };
                 if constexpr (RES) load_res(0);
 #pragma unroll
@@ -621,8 +648,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
                     }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const int row = i * 8 + (lane_e >> 3), ch = lane_e & 7;
-                        *reinterpret_cast<V8*>(Cg + (long)(mb + row) * p.ldc + nwp + ch * 8) = v[i];
+                        char* const Cr = Cw + (long)((mi >> 1) * 128 + (mi & 1) * 32 + i * 8) * p.ldc * 2;
+                        *reinterpret_cast<V8*>(Cr + (size_t)vC) = v[i];
                     }
                 }
             };
@@ -720,7 +747,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
                     if (m < p.M && n < p.N) {
                         if (p.epi == EPI_GELU) {
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) v[e] = (T)ds_gelu_erf((float)v[e]);
+                            for (int e = 0; e < 8; e += 2) {
+                                const f32x2 ge = ds_gelu_erf2(f32x2{(float)v[e], (float)v[e + 1]});
+                                v[e] = (T)ge[0];
+                                v[e + 1] = (T)ge[1];
+                            }
                         } else if (p.epi == EPI_QUICK_GELU) {
 #pragma unroll
                             for (int e = 0; e < 8; ++e) {

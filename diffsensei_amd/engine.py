@@ -65,6 +65,23 @@ def ln_fusion_enabled() -> bool:
     return os.environ.get("DIFFSENSEI_LN_FUSION", "1") != "0"
 
 
+# Where the fused LayerNorm pays (tools/ln_fusion_sweep.py, profiles/r04_ln_fusion_sweep.txt: every UNet batch 2..64, each
+# kernel family alone and both).  Fusing every level whose GEMMs implement it wins or ties at every batch, with ONE exception:
+# a level whose producers AND consumers all run gemm_pp_kernel on few rows (UNet batch 8: M = 8192 at the 1280-channel level,
+# 160 tiles on 256 CUs) - its longer epilogues and the finalize launches cost more than three 15-us LayerNorm launches
+# (+0.45 ms per forward); from M = 32768 on the same level gains 3.3 ms.  Break-even by interpolation: ~13 000 rows.
+# In elements (rows x channels) of the normalised tensor; the environment overrides exist for the sweep.
+LN_FUSION_ALL_PP_MIN_ELEMS = 12288 * 1280
+
+
+def ln_fusion_limits() -> Tuple[int, int, int]:
+    """(smallest tensor a gemm_pp_kernel member may fuse at, largest a 128-wide member may, smallest for an all-gemm_pp level)"""
+    import os
+    return (int(os.environ.get("DIFFSENSEI_LN_FUSION_PP_MIN_ELEMS", 0)),
+            int(os.environ.get("DIFFSENSEI_LN_FUSION_WIDE_MAX_ELEMS", 1 << 62)),
+            int(os.environ.get("DIFFSENSEI_LN_FUSION_ALL_PP_MIN_ELEMS", LN_FUSION_ALL_PP_MIN_ELEMS)))
+
+
 class PackedUNet:
     """Device-resident fp16 weights in kernel layout.  `names` follow the diffusers state dict."""
 
@@ -159,11 +176,11 @@ class PackedUNet:
                 wp, bp = pack_geglu(sd[f"{t}.ff.net.0.proj.weight"].to(device), sd[f"{t}.ff.net.0.proj.bias"].to(device))
                 put(f"{t}.ff.net.0.proj.weight", wp)
                 put(f"{t}.ff.net.0.proj.bias", bp)
+                dv = lambda n: sd[n].to(device)
                 if a.channels % 256 == 0 and ln_fusion_enabled():
-                    # fused-LayerNorm copies (norm2 -> attn2.to_q, norm3 -> GEGLU projection): only widths whose GEMMs can
-                    # run whole 256 x 256 tiles (SDXL: the 1280-channel level, 60 of 70 blocks, +1.8 GB)
-                    dv = lambda n: sd[n].to(device)
-                    # norm1 -> q|k (row form) and -> to_v, produced transposed (operand-swapped form: (-c, b') per output row)
+                    # fused-LayerNorm copies for norm1 -> q|k (row form) and -> to_v, produced transposed (operand-swapped form:
+                    # (-c, b') per output row): gemm_pp_kernel only, i.e. widths whose GEMMs run whole 256 x 256 tiles (SDXL: the
+                    # 1280-channel level, 60 of 70 blocks)
                     gw, c2, b2 = pack_ln_fused(self.w[f"{t}.attn1.qk.weight"], None, dv(f"{t}.norm1.weight"), dv(f"{t}.norm1.bias"))
                     put(f"{t}.attn1.qk.weight_ln", gw)
                     put(f"{t}.attn1.qk.c_ln", c2)
@@ -174,6 +191,9 @@ class PackedUNet:
                     bl = (bf - bh.float()).to(torch.float16)
                     put(f"{t}.attn1.to_v.weight_ln", gw)
                     put(f"{t}.attn1.to_v.cb_ln", torch.cat([c2, torch.stack([bh, bl], dim=1)], dim=1).contiguous())
+                if a.channels % 128 == 0 and ln_fusion_enabled():
+                    # norm2 -> attn2.to_q, norm3 -> GEGLU projection: both kernel families implement the row form (the 128-wide
+                    # kernels need whole 64-column strips in a 128-column tile), so every SDXL block gets the copies (+1.9 GB)
                     gw, c2, b2 = pack_ln_fused(dv(f"{t}.attn2.to_q.weight"), None, dv(f"{t}.norm2.weight"), dv(f"{t}.norm2.bias"))
                     put(f"{t}.attn2.to_q.weight_ln", gw)
                     put(f"{t}.attn2.to_q.c_ln", c2)
@@ -410,11 +430,12 @@ class UNetEngine:
                            p=(x, w[wname + ".weight"], y, w[wname + ".bias"], rowbias, residual)))
 
     def _gemm(self, ops, x, wt, y, M, N, K, bias=None, residual=None, geglu=False, x2=None, K1=0, ln_stats=None, ln_c=None,
-              stats_out=None):
+              stats_out=None, ln_partial=False):
         """ln_stats / ln_c: this GEMM consumes a fused LayerNorm (x is the raw residual stream, wt / bias the `_ln` copies);
-        stats_out: it emits the row statistics of what it stores (csrc/gemm_pp.hip, "LayerNorm")."""
+        ln_partial: ln_stats are the producer's partial sums and the kernel finalises its own rows (the 128-wide kernels);
+        stats_out: it emits the row statistics of what it stores (csrc/gemm_pp.hip, "LayerNorm"; csrc/gemm.hip, "Fused LayerNorm")."""
         n_out = N // 2 if geglu else N
-        ops.append(make_op("GEMM", i=(M, N, K, K1 if x2 is not None else K, int(geglu), 1, 0, 1),
+        ops.append(make_op("GEMM", i=(M, N, K, K1 if x2 is not None else K, int(geglu), 1, 0, 1, 0, int(ln_partial)), f=(1e-5,),
                            l=(K1 if x2 is not None else K, (K - K1) if x2 is not None else 0, K, n_out, n_out),
                            p=(x, x2, wt, y, bias, None, residual, ln_stats, ln_c, stats_out)))
 
@@ -463,19 +484,29 @@ class UNetEngine:
         # GEMM that writes h and every consumer runs gemm_pp_kernel's branch-free epilogues at this batch, the three LayerNorm
         # launches of every block are replaced by row statistics out of the producer's epilogue + a finalize launch (a few
         # us instead of 76 at batch 64); smaller batches and the 640-channel level keep the LayerNorm kernel
+        # Two implementations share one statistics format (ds_gemm_ln_fusable: 1 = gemm_pp_kernel, whose consumers read the
+        # (mean, rstd) of a finalize launch; 2 = the 128-wide kernels of small batches and of the 640-channel level, whose
+        # consumers sum the partials of their own rows in the epilogue - no launch at all), so every producer / consumer mix works.
         lib = _lib.load()
-        can = lambda m, n, k, epi=0, batch=1: bool(lib.ds_gemm_ln_fusable(m, n, k, epi, batch))
+        kind = lambda m, n, k, epi=0, batch=1: int(lib.ds_gemm_ln_fusable(m, n, k, epi, batch))
+        can = lambda m, n, k, epi=0, batch=1: kind(m, n, k, epi, batch) == 1
         have = f"{p}.transformer_blocks.0.attn2.to_q.weight_ln" in w and ln_fusion_enabled()
         # norm2 / norm3: producers = the two out-projections (N = K = C), consumers = attn2.to_q and the GEGLU projection
-        fuse = have and can(M, Cc, Cc) and can(M, 8 * Cc, Cc, 1)
-        # norm1 as well: producers = proj_in and the FF down-projection, consumers = q|k and the transposed to_v (mid-size
-        # batches run q|k on the 128 x 128 kernels: they keep the LayerNorm launch for norm1 only)
-        fuse1 = fuse and can(M, 2 * Cc, Cc) and can(M, Cc, 4 * Cc) and Np == N and can(Cc, N, Cc, 0, B)
+        k_proj, k_ff = kind(M, Cc, Cc), kind(M, 8 * Cc, Cc, 1)
+        pp_min, wide_max, all_pp_min = ln_fusion_limits()
+        pays = lambda k: (k == 1 and M * Cc >= pp_min) or (k == 2 and M * Cc <= wide_max)
+        fuse = have and pays(k_proj) and pays(k_ff) and not (k_proj == 1 and k_ff == 1 and M * Cc < all_pp_min)
+        # norm1 as well: producers = proj_in and the FF down-projection, consumers = q|k and the transposed to_v, which exists in
+        # gemm_pp_kernel only (mid-size and small batches keep the LayerNorm launch for norm1)
+        fuse1 = (fuse and f"{p}.transformer_blocks.0.attn1.qk.weight_ln" in w and k_proj == 1 and k_ff == 1 and can(M, 2 * Cc, Cc)
+                 and can(M, Cc, 4 * Cc) and Np == N and can(Cc, N, Cc, 0, B))
         if fuse:
             part = self._buf32("ln_part", a.level, (Cc // 64) * M * 2)
             st = self._buf32("ln_stats", a.level, M * 2)
         self.ln_fused_blocks = getattr(self, "ln_fused_blocks", 0) + (a.depth if fuse else 0)
         self.ln_fused_launches = getattr(self, "ln_fused_launches", 0) + a.depth * ((3 if fuse1 else 2) if fuse else 0)
+        self.ln_finalize_launches = getattr(self, "ln_finalize_launches", 0) + a.depth * (
+            ((1 if fuse1 else 0) + (k_proj == 1) + (k_ff == 1)) if fuse else 0)
         self._gn(ops, x, None, tn, w[p + ".norm.weight"], w[p + ".norm.bias"], N, Cc, 0, 1e-6, False)
         self._gemm(ops, tn, w[p + ".proj_in.weight"], h, M, Cc, Cc, bias=w[p + ".proj_in.bias"],
                    stats_out=part if fuse1 else None)
@@ -510,9 +541,10 @@ class UNetEngine:
                        residual=h, stats_out=part if fuse else None)
             # ---- attn2 (MaskedIPAttnProcessor2_0): q projection, fused text+masked-IP attention, out-proj + residual
             if fuse:
-                ops.append(make_op("LN_FINALIZE", i=(M, Cc // 64, Cc), f=(1e-5,), p=(part, st)))
+                if k_proj == 1:
+                    ops.append(make_op("LN_FINALIZE", i=(M, Cc // 64, Cc), f=(1e-5,), p=(part, st)))
                 self._gemm(ops, h, w[t + ".attn2.to_q.weight_ln"], q2, M, Cc, Cc, bias=w[t + ".attn2.to_q.bias_ln"],
-                           ln_stats=st, ln_c=w[t + ".attn2.to_q.c_ln"])
+                           ln_stats=st if k_proj == 1 else part, ln_c=w[t + ".attn2.to_q.c_ln"], ln_partial=k_proj == 2)
             else:
                 ops.append(make_op("LAYERNORM", i=(M, Cc), f=(1e-5,), p=(h, tn, w[t + ".norm2.weight"], w[t + ".norm2.bias"])))
                 self._gemm(ops, tn, w[t + ".attn2.to_q.weight"], q2, M, Cc, Cc)
@@ -528,9 +560,10 @@ class UNetEngine:
                        residual=h, stats_out=part if fuse else None)
             # ---- GEGLU feed-forward + residual
             if fuse:
-                ops.append(make_op("LN_FINALIZE", i=(M, Cc // 64, Cc), f=(1e-5,), p=(part, st)))
+                if k_ff == 1:
+                    ops.append(make_op("LN_FINALIZE", i=(M, Cc // 64, Cc), f=(1e-5,), p=(part, st)))
                 self._gemm(ops, h, w[t + ".ff.net.0.proj.weight_ln"], ff, M, 8 * Cc, Cc, bias=w[t + ".ff.net.0.proj.bias_ln"],
-                           geglu=True, ln_stats=st, ln_c=w[t + ".ff.net.0.proj.c_ln"])
+                           geglu=True, ln_stats=st if k_ff == 1 else part, ln_c=w[t + ".ff.net.0.proj.c_ln"], ln_partial=k_ff == 2)
             else:
                 ops.append(make_op("LAYERNORM", i=(M, Cc), f=(1e-5,), p=(h, tn, w[t + ".norm3.weight"], w[t + ".norm3.bias"])))
                 self._gemm(ops, tn, w[t + ".ff.net.0.proj.weight"], ff, M, 8 * Cc, Cc, bias=w[t + ".ff.net.0.proj.bias"],

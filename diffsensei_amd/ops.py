@@ -100,8 +100,30 @@ def ln_finalize(partial: Tensor, C: int, eps: float = 1e-5) -> Tensor:
     return st
 
 
-def gemm_ln_fusable(M: int, N: int, K: int, geglu: bool = False, batch: int = 1) -> bool:
-    return bool(_lib.load().ds_gemm_ln_fusable(M, N, K, 1 if geglu else 0, batch))
+def gemm_ln_fusable(M: int, N: int, K: int, geglu: bool = False, batch: int = 1) -> int:
+    """Which fused-LayerNorm form the dispatch gives this GEMM: 1 = the 256 x 256 kernel (`gemm_ln` with finalised statistics),
+    2 = the 128-wide kernels (`gemm_ln_partial` consumers, `gemm_ln` producers), 0 = none."""
+    return int(_lib.load().ds_gemm_ln_fusable(M, N, K, 1 if geglu else 0, batch))
+
+
+def gemm_ln_partial(x: Tensor, gw: Tensor, bias_ln: Optional[Tensor], ln_c: Tensor, partial: Tensor, eps: float = 1e-5,
+                    residual: Optional[Tensor] = None, geglu: bool = False, emit_stats: bool = False,
+                    out: Optional[Tensor] = None):
+    """Consumer of a fused LayerNorm on the 128-wide kernels (ds_gemm_ln_partial_f16): `partial` [K/64, M, 2] fp32 is what a
+    producer emitted; every block sums the partials of its own rows, no finalize launch.  y = rstd (x gw^T - mean c) + b'."""
+    _chk(x, gw, bias_ln, ln_c, residual)
+    _chk(partial, dtype=torch.float32)
+    M, K = x.shape
+    N = gw.shape[0]
+    assert tuple(partial.shape) == (K // 64, M, 2), (tuple(partial.shape), (K // 64, M, 2))
+    n_out = N // 2 if geglu else N
+    if out is None:
+        out = torch.empty((M, n_out), dtype=torch.float16, device=x.device)
+    part = torch.empty((N // 64, M, 2), dtype=torch.float32, device=x.device) if emit_stats else None
+    check(_lib.load().ds_gemm_ln_partial_f16(_p(x), K, _p(gw), K, _p(bias_ln), _p(partial), eps, _p(ln_c), _p(residual), n_out,
+                                             _p(out), n_out, _p(part), M, N, K, 1 if geglu else 0, _stream()),
+          "ds_gemm_ln_partial_f16")
+    return (out, part) if emit_stats else out
 
 
 def gemm_ln_swapped(a: Tensor, x: Tensor, ln_stats: Tensor, ln_cb: Tensor, out: Optional[Tensor] = None) -> Tensor:

@@ -79,11 +79,18 @@ int ds_gemm_f16(const void* x, int64_t ldx, const void* x2, int64_t ldx2, int k1
  *   consumer  y = rstd_m (x_m . gw_n - mean_m c_n) + b'_n on the RAW x, with gw = gamma (.) w (f16), ln_c [N][2] f16 =
  *             (-c hi, -c lo), c_n = sum_k gw_nk, bias_ln = bias + w beta - all packed once at load time (GEGLU: in the packed
  *             row order).  epilogue 0 or 1 (GEGLU).  Either role may be absent (null pointers), both may be combined.
- * Only the 256 x 256 persistent kernel implements it: M, N multiples of 256, K of 128; ds_gemm_ln_fusable says whether
- * ds_gemm_f16 would pick that kernel for the shape (callers keep ds_layernorm_f16 + ds_gemm_f16 otherwise). */
+ * Two implementations, one statistics format.  ds_gemm_ln_fusable(M, N, K, epilogue, batch) says which one ds_gemm_f16's
+ * dispatch gives the shape: 1 = the 256 x 256 persistent kernel (M, N multiples of 256, K of 128; consumers take the
+ * finalised ln_stats of ds_ln_finalize through ds_gemm_ln_f16), 2 = the 128-wide kernels of small batches and of the
+ * 640-channel level (N a multiple of 128, K of 64; producers through ds_gemm_ln_f16 with ln_stats = NULL, consumers through
+ * ds_gemm_ln_partial_f16, which sums the K/64 partials of its own rows in the epilogue - no finalize launch), 0 = neither
+ * (callers keep ds_layernorm_f16 + ds_gemm_f16).  Producers and consumers of either kind combine. */
 int ds_gemm_ln_f16(const void* x, int64_t ldx, const void* gw, int64_t ldw, const void* bias_ln, const float* ln_stats,
                    const void* ln_c, const void* residual, int64_t ldr, void* y, int64_t ldy, float* stats_out, int M, int N,
                    int K, int epilogue, void* stream);
+int ds_gemm_ln_partial_f16(const void* x, int64_t ldx, const void* gw, int64_t ldw, const void* bias_ln, const float* ln_partial,
+                           float eps, const void* ln_c, const void* residual, int64_t ldr, void* y, int64_t ldy, float* stats_out,
+                           int M, int N, int K, int epilogue, void* stream);
 int ds_ln_finalize(const float* partial, float* stats, int M, int strips, int C, float eps, void* stream);
 /* operand-swapped consumer (norm1 -> attn1.to_v, produced transposed: y[b] = a @ LN(x[b])^T, a = gamma (.) Wv [M,K] shared,
  * x[b] the raw rows [N,K] of batch item b): the normalised rows index the OUTPUT COLUMNS, so ln_stats is read at
@@ -324,7 +331,7 @@ int ds_resize_v_norm_u8(const uint8_t* tmp, int Ht, int Wt, const int32_t* first
  * and replayed with zero host arithmetic — optionally as a captured hipGraph.
  * ---------------------------------------------------------------------------------------------- */
 enum ds_opcode {
-    DS_OP_GEMM = 1,          /* p: x, x2, w, y, bias, rowbias, residual, ln_stats, ln_c, stats_out (fused LayerNorm, see ds_gemm_ln_f16; i[8] = operand-swapped form, l[10] = ln_bstride)   l: ldx ldx2 ldw ldy ldr sx sx2 sw sy sr
+    DS_OP_GEMM = 1,          /* p: x, x2, w, y, bias, rowbias, residual, ln_stats, ln_c, stats_out (fused LayerNorm, see ds_gemm_ln_f16; i[8] = operand-swapped form, l[10] = ln_bstride; i[9] = ln_stats holds PARTIAL sums, f[0] = eps: ds_gemm_ln_partial_f16)   l: ldx ldx2 ldw ldy ldr sx sx2 sw sy sr
                                 i: M N K K1 epilogue batch rowbias_ld rows_per_group */
     DS_OP_CONV3X3 = 2,       /* p: x, w, y, bias, rowbias, residual       i: B H W Cin Cout stride upsample rowbias_ld
                                                                            Hout Wout (upsample only; 0 0 = 2H x 2W) */
