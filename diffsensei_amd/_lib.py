@@ -39,6 +39,7 @@ SIGNATURES = {
     "ds_gemm_ln_fusable": (i32, [i32, i32, i32, i32, i32]),
     "ds_gemm_ln_partial_f16": (i32, [vp, i64, vp, i64, vp, vp, f32, vp, vp, i64, vp, i64, vp, i32, i32, i32, i32, vp]),
     "ds_gemm_ln_swapped_f16": (i32, [vp, i64, vp, i64, i64, vp, i64, vp, vp, i64, i64, i32, i32, i32, i32, vp]),
+    "ds_gemm_ln_swapped_partial_f16": (i32, [vp, i64, vp, i64, i64, vp, f32, i64, i64, vp, vp, i64, i64, i32, i32, i32, i32, vp]),
     "ds_gemm_f16_batched": (i32, [vp, i64, i64, vp, i64, i64, vp, i64, i64, i32, i32, i32, i32, vp]),
     "ds_conv3x3_f16": (i32, [vp, vp, vp, vp, i64, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "ds_conv3x3_resize_f16": (i32, [vp, vp, vp, vp, i64, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),

@@ -141,6 +141,18 @@ int ds_gemm_ln_swapped_f16(const void* a, int64_t lda, const void* x, int64_t ld
     return ds_launch_gemm(p, batch, S(stream));
 }
 
+int ds_gemm_ln_swapped_partial_f16(const void* a, int64_t lda, const void* x, int64_t ldx, int64_t sx, const float* ln_partial,
+                                   float eps, int64_t ln_rows, int64_t ln_bstride, const void* ln_cb, void* y, int64_t ldy,
+                                   int64_t sy, int M, int N, int K, int batch, void* stream) {
+    GemmParams p;
+    p.A = H(a); p.lda = lda; p.sA = 0; p.K1 = K; p.W = H(x); p.ldw = ldx; p.sW = sx;
+    p.C = HM(y); p.ldc = ldy; p.sC = sy; p.M = M; p.N = N; p.K = K;
+    p.ln_stats = ln_partial; p.ln_partial = 1; p.ln_eps = eps; p.ln_rows = ln_rows; p.ln_c = H(ln_cb); p.ln_swapped = 1;
+    p.ln_bstride = ln_bstride;
+    DS_REQUIRE(ln_partial && ln_cb, "ds_gemm_ln_swapped_partial_f16: partial sums and (c, b') are required");
+    return ds_launch_gemm(p, batch, S(stream));
+}
+
 int ds_gemm_ln_fusable(int M, int N, int K, int epilogue, int batch) { return ds_gemm_ln_kind(M, N, K, batch, epilogue); }
 
 int ds_gemm_f16_batched(const void* x, int64_t ldx, int64_t sx, const void* w, int64_t ldw, int64_t sw, void* y,
@@ -477,7 +489,7 @@ static int run_op(const ds_op& o, hipStream_t st) {
             g.rowbias_ld = i[6]; g.rows_per_group = i[7] > 0 ? i[7] : 1;
             g.ln_stats = reinterpret_cast<const float*>(p[7]); g.ln_c = H(p[8]); g.stats_out = reinterpret_cast<float*>(p[9]);
             g.ln_swapped = i[8]; g.ln_bstride = l[10];
-            g.ln_partial = i[9]; g.ln_eps = i[9] ? o.f[0] : g.ln_eps;
+            g.ln_partial = i[9]; g.ln_eps = i[9] ? o.f[0] : g.ln_eps; g.ln_rows = l[11];
             return ds_launch_gemm(g, i[5] > 0 ? i[5] : 1, st);
         }
         case DS_OP_LN_FINALIZE:

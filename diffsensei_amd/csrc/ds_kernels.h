@@ -34,7 +34,8 @@ struct GemmParams {
                                        // (tile columns): ln_stats[b * ln_bstride + n], ln_c = [M][4] f16 (-c hi, -c lo, b' hi, b' lo)
     long ln_bstride = 0;               //   rows of the normalised matrix per batch item
     int ln_partial = 0;                // consumer on the 128-wide LDS-DMA kernels (gemm.hip, "Fused LayerNorm"): ln_stats points at the
-    float ln_eps = 1e-5f;              //   producer's PARTIALS [K/64][M] float2 and the epilogue finalises its own rows (eps = ln_eps)
+    float ln_eps = 1e-5f;              //   producer's PARTIALS [K/64][rows] float2 and the epilogue finalises its own rows (eps = ln_eps)
+    long ln_rows = 0;                  //   operand-swapped form only: rows of the normalised matrix over all batch items (stride of the partials)
     int dtype = DS_DTYPE_F16;  // element type of A / W / C / bias / residual (the pointers are 2-byte opaque): bf16 = VAE path
     int debug = 0;  // ablation only (ds_set_option "gemm_debug"): 1 skip MFMA, 2 skip tile loads — results are garbage
 };

@@ -103,7 +103,9 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x16 (&acc)[WR /
             for (int g = 0; g < 4; ++g)
                 bq[ni][g] = *reinterpret_cast<const h4*>(p.bias + min(n0 + wn * 64 + ni * 32 + 8 * g + 4 * lhi, p.N - 4));
     }
-    const bool ln_in = LNF && p.ln_stats != nullptr;
+    const bool ln_any = LNF && p.ln_stats != nullptr;
+    const bool ln_in = ln_any && !p.ln_swapped;    // row form: the normalised rows are the tile rows (one per lane)
+    const bool ln_col = ln_any && p.ln_swapped;    // operand-swapped form (V^T = Wv X_b^T): they are the tile COLUMNS
     // consumer: (mean, rstd) of the lane's rows from the producer's partial sums.  Every load of every row is in flight at
     // once - ONE round trip to L2 (a chain of loads per row, row after row, cost 15 us per launch: ten round trips in the
     // epilogue of every block).  The two half-waves hold the same rows: lanes 0..31 sum chains 0 and 1 of ln_finalize_kernel's
@@ -154,6 +156,39 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x16 (&acc)[WR /
             }
         }
     }
+    // operand-swapped form: the statistics of the block's 128 columns = rows bz * ln_bstride + n0 .. of the normalised matrix are
+    // finalised once by threads 0..127 (one L2 round trip per 20 strips) into a table behind the staging tile
+    f32x2* const ln_tab = reinterpret_cast<f32x2*>(smem + HR * CS_STRIDE);
+    if constexpr (LNF) {
+        if (ln_col) {
+            if (tid < BN) {
+                const int strips = p.K >> 6;
+                const long row = min(bz * p.ln_bstride + n0 + tid, p.ln_rows - 1);
+                const f32x2* part = reinterpret_cast<const f32x2*>(p.ln_stats) + row;
+                float sa[4] = {0.f, 0.f, 0.f, 0.f}, qa[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int base = 0; base < strips; base += 20) {
+                    f32x2 t[4][5];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int jj = 0; jj < 5; ++jj) t[q][jj] = part[(long)min(base + q + 4 * jj, strips - 1) * p.ln_rows];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int jj = 0; jj < 5; ++jj) {
+                            const bool in = base + q + 4 * jj < strips;
+                            sa[q] += in ? t[q][jj][0] : 0.f;
+                            qa[q] += in ? t[q][jj][1] : 0.f;
+                        }
+                }
+                const float inv_c = 1.0f / (float)p.K;
+                const float mean = ((sa[0] + sa[1]) + (sa[2] + sa[3])) * inv_c;
+                const float var = fmaxf(fmaf(-mean, mean, ((qa[0] + qa[1]) + (qa[2] + qa[3])) * inv_c), 0.f);
+                ln_tab[tid] = f32x2{mean, rsqrtf(var + p.ln_eps)};
+            }
+            __syncthreads();
+        }
+    }
     h8 cq[2][4];  // fused LayerNorm, consumer: (-c hi, -c lo) of the lane's 4 columns per (ni, g)
     if constexpr (LNF) {
         if (ln_in) {
@@ -175,6 +210,14 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x16 (&acc)[WR /
             const int m = m0 + ml;
             const int grp = p.rowbias ? ((m < p.M ? m : p.M - 1) / p.rows_per_group) : 0;
             const float mean = ln_mean[mi], rstd = ln_rstd[mi];
+            float nc_row = 0.f, bp_row = 0.f;   // operand-swapped form: -c and b' of the lane's ROW
+            if constexpr (LNF) {
+                if (ln_col) {
+                    const h4 cb = *reinterpret_cast<const h4*>(p.ln_c + 4 * (long)(m < p.M ? m : p.M - 1));
+                    nc_row = (float)cb[0] + (float)cb[1];
+                    bp_row = (float)cb[2] + (float)cb[3];
+                }
+            }
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
 #pragma unroll
@@ -191,6 +234,13 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x16 (&acc)[WR /
                                 const float nc = (float)cq[ni][g][2 * e] + (float)cq[ni][g][2 * e + 1];   // -c_n
                                 v[e] = fmaf(fmaf(mean, nc, acc[mi][ni][4 * g + e]), rstd, (float)bq[ni][g][e]);
                             }
+                        }
+                        if (ln_col) {
+                            const f32x4 t0 = *reinterpret_cast<const f32x4*>(ln_tab + nl), t1 = *reinterpret_cast<const f32x4*>(ln_tab + nl + 2);
+                            v[0] = fmaf(fmaf(t0[0], nc_row, acc[mi][ni][4 * g + 0]), t0[1], bp_row);
+                            v[1] = fmaf(fmaf(t0[2], nc_row, acc[mi][ni][4 * g + 1]), t0[3], bp_row);
+                            v[2] = fmaf(fmaf(t1[0], nc_row, acc[mi][ni][4 * g + 2]), t1[1], bp_row);
+                            v[3] = fmaf(fmaf(t1[2], nc_row, acc[mi][ni][4 * g + 3]), t1[3], bp_row);
                         }
                     }
                     if (n < p.N) {
@@ -691,7 +741,7 @@ int launch_glds1(const GemmParams& p0, int batch, hipStream_t stream) {
     GemmParams p = p0;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
-    const size_t lds = 128 * CS_STRIDE;  // >= (BM + BN) * 128: the epilogue staging tile is the larger tenant
+    const size_t lds = 128 * CS_STRIDE + 1024;  // >= (BM + BN) * 128: the epilogue staging tile is the larger tenant (+ the column statistics of the fused LayerNorm's operand-swapped form)
     dim3 grid(p.tiles_m * p.tiles_n, 1, batch);
     hipLaunchKernelGGL((gemm_glds_kernel<BM, CONV, 1>), grid, dim3(256), lds, stream, p);
     DS_LAUNCH_CHECK();
@@ -821,7 +871,7 @@ int ds_gemm_ln_kind(int M, int N, int K, int batch, int epi) {
     if (g_gemm_variant != 0) return 0;
     const Kind k = choose(p, batch).kind;
     if (k == K_PP) return (M % 256 == 0 && N % 256 == 0) ? 1 : 0;
-    if ((k == K_GLDS1 || k == K_GLDS2 || k == K_RING) && batch == 1 && N % 128 == 0 && K % 64 == 0) return 2;
+    if ((k == K_GLDS1 || k == K_GLDS2 || k == K_RING) && K % 64 == 0) return 2;   // (a PRODUCER also needs N % 128 == 0 and no batch)
     return 0;
 }
 
@@ -878,7 +928,8 @@ int ds_launch_gemm(const GemmParams& p_in, int batch, hipStream_t stream) {
             if (!wide_kind) { c.kind = K_GLDS1; c.bm = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) < 384 ? 64 : 128; }
         };
         if (p.ln_stats && p.ln_partial) {
-            DS_REQUIRE(wide_ok && p.ln_c && !p.ln_swapped, "gemm: a consumer of partial LayerNorm sums needs N %% 128 == 0, K %% 64 == 0, no batch (M=%d N=%d K=%d)", p.M, p.N, p.K);
+            DS_REQUIRE(p.K % 64 == 0 && p.ln_c && (p.ln_swapped ? (p.ln_rows > 0 && p.ln_bstride > 0 && !p.bias) : batch == 1),
+                       "gemm: a consumer of partial LayerNorm sums needs K %% 64 == 0 (M=%d N=%d K=%d)", p.M, p.N, p.K);
             force_wide();
         } else if (p.ln_stats) {
             DS_REQUIRE(pp_ok && p.ln_c, "gemm: a consumer of finalised LayerNorm statistics needs the 256 x 256 kernel (M=%d N=%d K=%d)", p.M, p.N, p.K);

@@ -66,12 +66,11 @@ def ln_fusion_enabled() -> bool:
 
 
 # Where the fused LayerNorm pays (tools/ln_fusion_sweep.py, profiles/r04_ln_fusion_sweep.txt: every UNet batch 2..64, each
-# kernel family alone and both).  Fusing every level whose GEMMs implement it wins or ties at every batch, with ONE exception:
-# a level whose producers AND consumers all run gemm_pp_kernel on few rows (UNet batch 8: M = 8192 at the 1280-channel level,
-# 160 tiles on 256 CUs) - its longer epilogues and the finalize launches cost more than three 15-us LayerNorm launches
-# (+0.45 ms per forward); from M = 32768 on the same level gains 3.3 ms.  Break-even by interpolation: ~13 000 rows.
-# In elements (rows x channels) of the normalised tensor; the environment overrides exist for the sweep.
-LN_FUSION_ALL_PP_MIN_ELEMS = 12288 * 1280
+# kernel family alone, both, twice on two boxes): fusing every level whose GEMMs implement it wins at every batch - 0.9 ms of
+# 32.4 at batch 2 (963 -> 763 launches), 1.3 of 73.5 at batch 8, 2.2 of 132 at 16, 4.2 of 242 at 32, 9.5 of 467 at 64 - and
+# no family alone does better anywhere.  The three limits (in elements = rows x channels of the normalised tensor) therefore
+# default to "no limit"; they exist for the sweep.
+LN_FUSION_ALL_PP_MIN_ELEMS = 0
 
 
 def ln_fusion_limits() -> Tuple[int, int, int]:
@@ -177,10 +176,9 @@ class PackedUNet:
                 put(f"{t}.ff.net.0.proj.weight", wp)
                 put(f"{t}.ff.net.0.proj.bias", bp)
                 dv = lambda n: sd[n].to(device)
-                if a.channels % 256 == 0 and ln_fusion_enabled():
+                if a.channels % 128 == 0 and ln_fusion_enabled():
                     # fused-LayerNorm copies for norm1 -> q|k (row form) and -> to_v, produced transposed (operand-swapped form:
-                    # (-c, b') per output row): gemm_pp_kernel only, i.e. widths whose GEMMs run whole 256 x 256 tiles (SDXL: the
-                    # 1280-channel level, 60 of 70 blocks)
+                    # (-c, b') per output row)
                     gw, c2, b2 = pack_ln_fused(self.w[f"{t}.attn1.qk.weight"], None, dv(f"{t}.norm1.weight"), dv(f"{t}.norm1.bias"))
                     put(f"{t}.attn1.qk.weight_ln", gw)
                     put(f"{t}.attn1.qk.c_ln", c2)
@@ -191,9 +189,8 @@ class PackedUNet:
                     bl = (bf - bh.float()).to(torch.float16)
                     put(f"{t}.attn1.to_v.weight_ln", gw)
                     put(f"{t}.attn1.to_v.cb_ln", torch.cat([c2, torch.stack([bh, bl], dim=1)], dim=1).contiguous())
-                if a.channels % 128 == 0 and ln_fusion_enabled():
-                    # norm2 -> attn2.to_q, norm3 -> GEGLU projection: both kernel families implement the row form (the 128-wide
-                    # kernels need whole 64-column strips in a 128-column tile), so every SDXL block gets the copies (+1.9 GB)
+                    # norm2 -> attn2.to_q, norm3 -> GEGLU projection.  Both kernel families implement every form (the 128-wide
+                    # producers need whole 64-column strips in a 128-column tile), so every SDXL block gets the copies (+2.1 GB)
                     gw, c2, b2 = pack_ln_fused(dv(f"{t}.attn2.to_q.weight"), None, dv(f"{t}.norm2.weight"), dv(f"{t}.norm2.bias"))
                     put(f"{t}.attn2.to_q.weight_ln", gw)
                     put(f"{t}.attn2.to_q.c_ln", c2)
@@ -496,17 +493,19 @@ class UNetEngine:
         pp_min, wide_max, all_pp_min = ln_fusion_limits()
         pays = lambda k: (k == 1 and M * Cc >= pp_min) or (k == 2 and M * Cc <= wide_max)
         fuse = have and pays(k_proj) and pays(k_ff) and not (k_proj == 1 and k_ff == 1 and M * Cc < all_pp_min)
-        # norm1 as well: producers = proj_in and the FF down-projection, consumers = q|k and the transposed to_v, which exists in
-        # gemm_pp_kernel only (mid-size and small batches keep the LayerNorm launch for norm1)
-        fuse1 = (fuse and f"{p}.transformer_blocks.0.attn1.qk.weight_ln" in w and k_proj == 1 and k_ff == 1 and can(M, 2 * Cc, Cc)
-                 and can(M, Cc, 4 * Cc) and Np == N and can(Cc, N, Cc, 0, B))
+        # norm1 as well: producers = proj_in and the FF down-projection, consumers = q|k and the transposed to_v (operand-swapped
+        # form: gemm_pp_kernel needs whole tiles of tokens, the 128-wide kernels take any count)
+        k_qk, k_ffd, k_v = kind(M, 2 * Cc, Cc), kind(M, Cc, 4 * Cc), kind(Cc, Np, Cc, 0, B)
+        fuse1 = (fuse and f"{p}.transformer_blocks.0.attn1.qk.weight_ln" in w and pays(k_qk) and pays(k_ffd) and pays(k_v)
+                 and (k_v == 2 or (Np == N and can(Cc, N, Cc, 0, B))))
         if fuse:
             part = self._buf32("ln_part", a.level, (Cc // 64) * M * 2)
             st = self._buf32("ln_stats", a.level, M * 2)
         self.ln_fused_blocks = getattr(self, "ln_fused_blocks", 0) + (a.depth if fuse else 0)
         self.ln_fused_launches = getattr(self, "ln_fused_launches", 0) + a.depth * ((3 if fuse1 else 2) if fuse else 0)
+        fin1 = fuse1 and (k_qk == 1 or k_v == 1)     # a finalize launch only where a gemm_pp_kernel consumer reads (mean, rstd)
         self.ln_finalize_launches = getattr(self, "ln_finalize_launches", 0) + a.depth * (
-            ((1 if fuse1 else 0) + (k_proj == 1) + (k_ff == 1)) if fuse else 0)
+            ((1 if fin1 else 0) + (k_proj == 1) + (k_ff == 1)) if fuse else 0)
         self._gn(ops, x, None, tn, w[p + ".norm.weight"], w[p + ".norm.bias"], N, Cc, 0, 1e-6, False)
         self._gemm(ops, tn, w[p + ".proj_in.weight"], h, M, Cc, Cc, bias=w[p + ".proj_in.bias"],
                    stats_out=part if fuse1 else None)
@@ -514,11 +513,13 @@ class UNetEngine:
             t = f"{p}.transformer_blocks.{k}"
             # ---- attn1 (AttnProcessor2_0): q|k projection, V^T projection, flash attention, out-proj + residual
             if fuse1:    # norm1: statistics of h came out of proj_in / the previous block's FF down-projection
-                ops.append(make_op("LN_FINALIZE", i=(M, Cc // 64, Cc), f=(1e-5,), p=(part, st)))
+                if fin1:
+                    ops.append(make_op("LN_FINALIZE", i=(M, Cc // 64, Cc), f=(1e-5,), p=(part, st)))
                 self._gemm(ops, h, w[t + ".attn1.qk.weight_ln"], qk, M, 2 * Cc, Cc, bias=w[t + ".attn1.qk.bias_ln"],
-                           ln_stats=st, ln_c=w[t + ".attn1.qk.c_ln"])
-                ops.append(make_op("GEMM", i=(Cc, Np, Cc, Cc, 0, B, 0, 1, 1), l=(Cc, 0, Cc, Np, 0, 0, 0, N * Cc, Cc * Np, 0, N),
-                                   p=(w[t + ".attn1.to_v.weight_ln"], None, h, vt, None, None, None, st,
+                           ln_stats=st if k_qk == 1 else part, ln_c=w[t + ".attn1.qk.c_ln"], ln_partial=k_qk == 2)
+                ops.append(make_op("GEMM", i=(Cc, Np, Cc, Cc, 0, B, 0, 1, 1, int(k_v == 2)), f=(1e-5,),
+                                   l=(Cc, 0, Cc, Np, 0, 0, 0, N * Cc, Cc * Np, 0, N, M),
+                                   p=(w[t + ".attn1.to_v.weight_ln"], None, h, vt, None, None, None, st if k_v == 1 else part,
                                       w[t + ".attn1.to_v.cb_ln"], None)))
             else:
                 ops.append(make_op("LAYERNORM", i=(M, Cc), f=(1e-5,), p=(h, tn, w[t + ".norm1.weight"], w[t + ".norm1.bias"])))

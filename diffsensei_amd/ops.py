@@ -126,6 +126,22 @@ def gemm_ln_partial(x: Tensor, gw: Tensor, bias_ln: Optional[Tensor], ln_c: Tens
     return (out, part) if emit_stats else out
 
 
+def gemm_ln_swapped_partial(a: Tensor, x: Tensor, partial: Tensor, ln_cb: Tensor, eps: float = 1e-5,
+                            out: Optional[Tensor] = None) -> Tensor:
+    """`gemm_ln_swapped` on the 128-wide kernels (ds_gemm_ln_swapped_partial_f16): partial [K/64, Z*N, 2] fp32 as a producer
+    emitted them for the rows of x.view(Z*N, K); no finalize launch."""
+    _chk(a, x, ln_cb)
+    _chk(partial, dtype=torch.float32)
+    Z, N, K = x.shape
+    M = a.shape[0]
+    assert tuple(partial.shape) == (K // 64, Z * N, 2), tuple(partial.shape)
+    if out is None:
+        out = torch.empty((Z, M, N), dtype=torch.float16, device=x.device)
+    check(_lib.load().ds_gemm_ln_swapped_partial_f16(_p(a), K, _p(x), K, N * K, _p(partial), eps, Z * N, N, _p(ln_cb), _p(out), N,
+                                                     M * N, M, N, K, Z, _stream()), "ds_gemm_ln_swapped_partial_f16")
+    return out
+
+
 def gemm_ln_swapped(a: Tensor, x: Tensor, ln_stats: Tensor, ln_cb: Tensor, out: Optional[Tensor] = None) -> Tensor:
     """out[z] = a @ LN(x[z])^T with the LayerNorm folded in (ds_gemm_ln_swapped_f16): a = gamma (.) W [M,K], x [Z,N,K] raw,
     ln_stats [Z*N,2] fp32 (mean, rstd), ln_cb [M,4] f16 (-c hi, -c lo, b' hi, b' lo) -> [Z,M,N]."""

@@ -98,6 +98,11 @@ int ds_ln_finalize(const float* partial, float* stats, int M, int strips, int C,
 int ds_gemm_ln_swapped_f16(const void* a, int64_t lda, const void* x, int64_t ldx, int64_t sx, const float* ln_stats,
                            int64_t ln_bstride, const void* ln_cb, void* y, int64_t ldy, int64_t sy, int M, int N, int K,
                            int batch, void* stream);
+/* the same on the 128-wide kernels: ln_partial = the producer's partial sums [K/64][ln_rows] float2 (ln_rows = rows of the
+ * normalised matrix over all batch items); every block finalises the statistics of its 128 output columns itself. */
+int ds_gemm_ln_swapped_partial_f16(const void* a, int64_t lda, const void* x, int64_t ldx, int64_t sx, const float* ln_partial,
+                                   float eps, int64_t ln_rows, int64_t ln_bstride, const void* ln_cb, void* y, int64_t ldy,
+                                   int64_t sy, int M, int N, int K, int batch, void* stream);
 int ds_gemm_ln_fusable(int M, int N, int K, int epilogue, int batch);
 
 /* batched variant: grid.z = batch with element strides (0 = shared operand); used for V^T = Wv @ X_b^T */
@@ -331,7 +336,7 @@ int ds_resize_v_norm_u8(const uint8_t* tmp, int Ht, int Wt, const int32_t* first
  * and replayed with zero host arithmetic — optionally as a captured hipGraph.
  * ---------------------------------------------------------------------------------------------- */
 enum ds_opcode {
-    DS_OP_GEMM = 1,          /* p: x, x2, w, y, bias, rowbias, residual, ln_stats, ln_c, stats_out (fused LayerNorm, see ds_gemm_ln_f16; i[8] = operand-swapped form, l[10] = ln_bstride; i[9] = ln_stats holds PARTIAL sums, f[0] = eps: ds_gemm_ln_partial_f16)   l: ldx ldx2 ldw ldy ldr sx sx2 sw sy sr
+    DS_OP_GEMM = 1,          /* p: x, x2, w, y, bias, rowbias, residual, ln_stats, ln_c, stats_out (fused LayerNorm, see ds_gemm_ln_f16; i[8] = operand-swapped form, l[10] = ln_bstride; i[9] = ln_stats holds PARTIAL sums, f[0] = eps, l[11] = ln_rows: ds_gemm_ln_partial_f16 / ds_gemm_ln_swapped_partial_f16)   l: ldx ldx2 ldw ldy ldr sx sx2 sw sy sr
                                 i: M N K K1 epilogue batch rowbias_ld rows_per_group */
     DS_OP_CONV3X3 = 2,       /* p: x, w, y, bias, rowbias, residual       i: B H W Cin Cout stride upsample rowbias_ld
                                                                            Hout Wout (upsample only; 0 0 = 2H x 2W) */

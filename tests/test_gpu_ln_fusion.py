@@ -134,7 +134,9 @@ def test_fused_chain_producer_finalize_consumer_and_refusals(hip_lib):
     # what the dispatch gives a shape: 1 = the 256 x 256 kernel, 2 = the 128-wide kernels (small batches, 640 channels), 0 = none
     assert ops.gemm_ln_fusable(65536, 1280, 1280) == 1 and ops.gemm_ln_fusable(65536, 10240, 1280, geglu=True) == 1
     assert ops.gemm_ln_fusable(2048, 1280, 1280) == 2 and ops.gemm_ln_fusable(65536, 640, 640) == 2
-    assert ops.gemm_ln_fusable(2048, 1288, 1280) == 0 and ops.gemm_ln_fusable(2048, 1280, 1288) == 0
+    assert ops.gemm_ln_fusable(2048, 1280, 1288) == 0                # K not a multiple of 64: the register-staged fallback
+    with pytest.raises(_lib.DiffSenseiHipError):          # a producer needs whole 64-column strips per 128-column tile
+        ops.gemm_ln(dv(a), dv(wo[:1160]), dv(bo[:1160]), residual=dv(h0[:, :1160].contiguous()), emit_stats=True)
     with pytest.raises(_lib.DiffSenseiHipError):          # ragged M: the generic epilogue has no fused form
         ops.gemm_ln(dv(a[:2000]), gw, b2, c2, st[:2000].contiguous())
     with pytest.raises(_lib.DiffSenseiHipError):          # consumer without its b'
@@ -248,3 +250,32 @@ def test_wide_consumer_geglu_and_chain(hip_lib):
     with pytest.raises(Exception):                         # partial sums of the wrong width
         ops.gemm_ln_partial(h, gwp, b2p, c2p, part[:5].contiguous(), geglu=True)
 
+
+
+@pytest.mark.parametrize("Z,N,C", [(2, 1024, 1280), (3, 296, 640), (2, 4096, 640), (1, 72, 128)])
+def test_wide_consumer_swapped_vs_layernorm_linear(hip_lib, Z, N, C):
+    """norm1 -> attn1.to_v on the 128-wide kernels (small batches; any token count, e.g. 296):
+    every block finalises the statistics of its 128 output columns from the producer's partial sums.  vs fp32, and vs the
+    256 x 256 form where that one takes the shape."""
+    from diffsensei_amd import ops
+    from diffsensei_amd.engine import pack_ln_fused
+    g = torch.Generator().manual_seed(Z * 7 + N + C)
+    x = ((torch.randn((Z, N, C), generator=g) + 0.4) * (1.0 + torch.rand((Z, N, 1), generator=g) * 3)).half()
+    wv, gamma, beta = _r((C, C), g, 1 / math.sqrt(C)), (1 + 0.2 * torch.randn(C, generator=g)).half(), _r((C,), g, 0.3)
+    ref = torch.einsum("ck,znk->zcn", wv.float(), F.layer_norm(x.float(), (C,), gamma.float(), beta.float(), 1e-5))
+    gw, c2, _ = pack_ln_fused(wv.to(DEV), None, gamma.to(DEV), beta.to(DEV))
+    bf = (wv.double() @ beta.double()).float()
+    bh = bf.half()
+    cb = torch.cat([c2.cpu(), torch.stack([bh, (bf - bh.float()).half()], dim=1)], dim=1).contiguous().to(DEV)
+    xs = x.float().view(Z * N, C // 64, 64)
+    part = torch.stack([xs.sum(-1).t(), (xs * xs).sum(-1).t()], dim=-1).contiguous().to(DEV)
+    got = ops.gemm_ln_swapped_partial(gw, x.to(DEV), part, cb)
+    e = _relmax(got, ref)
+    line = f"LN -> V^T (swapped, 128-wide kernels) Z={Z} N={N} C={C}: {e:.2e}"
+    if N % 256 == 0 and C % 256 == 0:
+        pp = ops.gemm_ln_swapped(gw, x.to(DEV), ops.ln_finalize(part, C, 1e-5), cb)
+        d = (got.float() - pp.float()).abs().max().item()
+        line += f"; vs the 256 x 256 form: max |diff| {d:.2e}"
+        assert d <= 2e-3 * ref.abs().max().item()
+    print(line)
+    assert got.shape == (Z, C, N) and e <= 3e-3, e
