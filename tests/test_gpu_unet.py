@@ -261,11 +261,12 @@ def test_unet_sdxl_forward_vs_oracle_1024(sdxl_model):
 
 def test_unet_sdxl_partial_layernorm_fusion_768(sdxl_model, monkeypatch):
     """The launch-plan builder fuses per norm and per kernel family: at 768 x 768 (96 x 96 latents, 576 tokens at the
-    1280-channel level) and UNet batch 16 the out-projections and their consumers reach gemm_pp_kernel's branch-free epilogues
-    at the 1280-channel level (M = 9216 = 36 row tiles) and the 128-wide kernels' fused epilogue at the 640-channel level, but
-    the transposed to_v reaches neither (576 columns), so norm2 / norm3 are fused and norm1 keeps its LayerNorm launch.  Rows of
-    that forward vs the batch-2 forward of the same inputs built with DIFFSENSEI_LN_FUSION=0 (every LayerNorm a launch of its
-    own): <= 4e-3, bit-equal inside the batch - whatever tile, wave and lane a row lands in; the plan must really be the mixed one."""
+    1280-channel level) and UNet batch 16 the out-projections, q|k and the GEGLU projections of the 1280-channel level reach
+    gemm_pp_kernel's branch-free epilogues (M = 9216 = 36 row tiles), the transposed to_v (576 columns per image: no whole
+    256-column tile) and the out-projections of the 640-channel level run the 128-wide kernels' fused epilogue - every norm is
+    fused, through a mix of the two families.  Rows of that forward vs the batch-2 forward of the same inputs built with
+    DIFFSENSEI_LN_FUSION=0 (every LayerNorm a launch of its own): <= 4e-3, bit-equal inside the batch - whatever tile, wave and
+    lane a row lands in (images start at offsets 576 r mod 256 inside the row tiles); the plan must really be the mixed one."""
     cfg, m = sdxl_model
     x, enc, te, tid, bbox, db = _inputs(cfg, 2, 96, 96, seed=17)
     m._attn_processors = {"x": type("P", (), {"scale": 0.6})()}
@@ -276,17 +277,12 @@ def test_unet_sdxl_partial_layernorm_fusion_768(sdxl_model, monkeypatch):
         y = m(x.to(DEV), 801.0, enc.to(DEV), **kw(bbox, te, tid, db)).sample
         assert getattr(m._engines[next(k for k in m._engines if k[0] == 2 and k[1] == 96)], "ln_fused_launches", 0) == 0
     rep = lambda t: torch.cat([t[:1].repeat(8, *([1] * (t.dim() - 1))), t[1:].repeat(8, *([1] * (t.dim() - 1)))])
-    with monkeypatch.context() as mp:
-        # 9216 rows are below the size at which an all-gemm_pp level pays (engine.LN_FUSION_ALL_PP_MIN_ELEMS): fuse it anyway,
-        # the mixed plan is what this test is about
-        mp.setenv("DIFFSENSEI_LN_FUSION_ALL_PP_MIN_ELEMS", "0")
-        y16 = m(rep(x).to(DEV), 801.0, rep(enc).to(DEV), **kw(rep(bbox), rep(te), rep(tid), rep(db))).sample
+    y16 = m(rep(x).to(DEV), 801.0, rep(enc).to(DEV), **kw(rep(bbox), rep(te), rep(tid), rep(db))).sample
     eng = m._engines[next(k for k in m._engines if k[0] == 16)]
     fused = getattr(eng, "ln_fused_launches", 0)
     print(f"768x768 batch 16: {getattr(eng, 'ln_fused_blocks', 0)} blocks with fused LayerNorms, {fused} LayerNorm launches replaced")
-    # norm2 / norm3 of all 70 blocks: the 60 of the 1280-channel level through gemm_pp_kernel, the 10 of the 640-channel level
-    # through the 128-wide kernels (their out-projections; the N = 5120 GEGLU consumer there is a gemm_pp_kernel launch again)
-    assert getattr(eng, "ln_fused_blocks", 0) == 70 and fused == 140, "expected norm2 / norm3 of every transformer block fused"
+    assert getattr(eng, "ln_fused_blocks", 0) == 70 and fused == 210, "expected every LayerNorm of every transformer block fused"
+    assert 0 < eng.ln_finalize_launches < 210, "expected a mix of gemm_pp_kernel consumers (finalize launch) and 128-wide ones (none)"
     for r in range(16):
         assert torch.equal(y16[r], y16[0 if r < 8 else 8])
     d0, d1 = _rel(y16[0], y[0]), _rel(y16[8], y[1])

@@ -5,6 +5,10 @@ set -u
 out=gpurun_out
 mkdir -p "$out"
 export TMPDIR=/tmp
+if [[ -n "${RETEST:-}" ]]; then
+  timeout 600 python -m pytest $RETEST -q -m gpu -p no:cacheprovider > "$out/r04_pytest_gpu_retest.log" 2>&1
+  echo "retest rc=$?"; tail -3 "$out/r04_pytest_gpu_retest.log"
+fi
 timeout 1500 python bench.py --steps 3 --warmup 1 > "$out/r04_bench_default_ns32_final.json" 2> "$out/r04_bench_default_ns32_final.err"
 echo "bench rc=$?"; tail -1 "$out/r04_bench_default_ns32_final.json" | python -c "
 import sys,json
