@@ -176,7 +176,9 @@ class PackedUNet:
                 put(f"{t}.ff.net.0.proj.weight", wp)
                 put(f"{t}.ff.net.0.proj.bias", bp)
                 dv = lambda n: sd[n].to(device)
-                if a.channels % 128 == 0 and ln_fusion_enabled():
+                if a.channels % 128 == 0:
+                    # (packed whatever DIFFSENSEI_LN_FUSION says: the switch belongs to the plan builder, and a plan built later
+                    # with fusion on must find the copies)
                     # fused-LayerNorm copies for norm1 -> q|k (row form) and -> to_v, produced transposed (operand-swapped form:
                     # (-c, b') per output row)
                     gw, c2, b2 = pack_ln_fused(self.w[f"{t}.attn1.qk.weight"], None, dv(f"{t}.norm1.weight"), dv(f"{t}.norm1.bias"))
