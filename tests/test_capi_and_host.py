@@ -189,6 +189,41 @@ def test_plan_builds_on_host_for_tiny_config(hip_lib):
         UNetEngine(pk, 2, 0, 16)
 
 
+def test_plan_folds_every_layernorm_into_the_gemms_around_it(hip_lib, monkeypatch):
+    """Host logic of the fused LayerNorm (engine._transformer, csrc/gemm.hip ds_gemm_ln_kind): on the tiny config every GEMM of a
+    transformer block runs the 128-wide kernels, so the plan carries no LAYERNORM and no LN_FINALIZE op - each block's two
+    out-projections and its FF down-projection (or proj_in) emit statistics, q|k, the transposed to_v, attn2.to_q and the GEGLU
+    projection consume the partial sums; DIFFSENSEI_LN_FUSION=0 brings the three launches per block back.  The dispatch query
+    itself is pinned for the SDXL shapes of both operating points."""
+    from collections import Counter
+    from diffsensei_amd.engine import PackedUNet, UNetEngine
+    from diffsensei_amd.unet_config import random_state_dict, tiny_config
+    cfg = tiny_config()
+    pk = PackedUNet(cfg, random_state_dict(cfg, 0), torch.device("cpu"))
+    blocks = sum(a.depth for a in pk.attns)
+    eng = UNetEngine(pk, 2, 16, 16)
+    codes = Counter(op.code for op in eng.forward_ops)
+    gemms = [op for op in eng.forward_ops if op.code == 1]
+    assert codes[4] == 0 and codes[27] == 0 and eng.ln_fused_launches == 3 * blocks and eng.ln_finalize_launches == 0
+    assert sum(1 for op in gemms if op.p[9]) == 3 * blocks                       # producers: one per fused norm
+    assert sum(1 for op in gemms if op.p[7] and op.i[9]) == 4 * blocks           # consumers of partial sums: q|k, V^T, to_q, GEGLU
+    assert sum(1 for op in gemms if op.i[8]) == blocks                           # ... of which the operand-swapped V^T
+    assert all(op.l[11] == op.l[10] * op.i[5] for op in gemms if op.i[8])        # ln_rows = tokens per image x images
+    with monkeypatch.context() as mp:
+        mp.setenv("DIFFSENSEI_LN_FUSION", "0")
+        off = UNetEngine(pk, 2, 16, 16)
+    assert Counter(op.code for op in off.forward_ops)[4] == 3 * blocks and len(off.forward_ops) == len(eng.forward_ops) + 3 * blocks
+    assert not any(op.p[7] or op.p[9] for op in off.forward_ops if op.code == 1)
+    kind = lambda *a: hip_lib.ds_gemm_ln_fusable(*a)
+    # SDXL at UNet batch 2 (BASELINE configs[1]): everything on the 128-wide kernels except the 64 x 64-token GEGLU projections
+    assert [kind(2048, 1280, 1280, 0, 1), kind(2048, 2560, 1280, 0, 1), kind(2048, 1280, 5120, 0, 1), kind(2048, 10240, 1280, 1, 1),
+            kind(1280, 1024, 1280, 0, 2), kind(8192, 640, 640, 0, 1), kind(8192, 5120, 640, 1, 1)] == [2, 2, 2, 2, 2, 2, 1]
+    # ... and at batch 64 (the metric line): the 1280-channel level on gemm_pp_kernel, the 640-channel out-projections 128-wide
+    assert [kind(65536, 1280, 1280, 0, 1), kind(65536, 10240, 1280, 1, 1), kind(1280, 1024, 1280, 0, 64), kind(262144, 640, 640, 0, 1),
+            kind(262144, 5120, 640, 1, 1)] == [1, 1, 1, 2, 1]
+    assert kind(2048, 1280, 1288, 0, 1) == 0 and kind(0, 1280, 1280, 0, 1) == 0 and kind(2048, 1280, 1280, 2, 1) == 0
+
+
 def test_committed_bench_line_follows_the_contract():
     """The round-end bench line kept under profiles/ carries every key the driver's contract names."""
     import json
