@@ -288,3 +288,21 @@ def test_unet_sdxl_partial_layernorm_fusion_768(sdxl_model, monkeypatch):
     d0, d1 = _rel(y16[0], y[0]), _rel(y16[8], y[1])
     print(f"768x768: batch-16 rows (partial LayerNorm fusion) vs batch-2 rows rel-L2 {d0:.3e} / {d1:.3e}")
     assert d0 <= 4e-3 and d1 <= 4e-3, (d0, d1)
+
+
+def test_unet_sdxl_small_batch_rows_are_position_independent(sdxl_model):
+    """72 x 72 latents (324 / 1296 tokens per image at the two attention levels: images start at every offset inside the 64- and
+    128-row tiles of the small-batch GEMMs), three copies each of two inputs = UNet batch 6: every LayerNorm of the plan is folded
+    into the 128-wide kernels' epilogues (row form, operand-swapped form, statistics producers), and the copies must come out
+    bit-identical - the check that caught a slot-dependent f16 rounding in round 4 (profiles/r04_determinism_bisect.txt)."""
+    cfg, m = sdxl_model
+    x, enc, te, tid, bbox, db = _inputs(cfg, 2, 72, 72, seed=23)
+    m._attn_processors = {"x": type("P", (), {"scale": 0.6})()}
+    rep = lambda t: torch.cat([t[:1].repeat(3, *([1] * (t.dim() - 1))), t[1:].repeat(3, *([1] * (t.dim() - 1)))])
+    y = m(rep(x).to(DEV), 801.0, rep(enc).to(DEV), cross_attention_kwargs={"bbox": rep(bbox), "aspect_ratio": 1.0},
+          added_cond_kwargs={"text_embeds": rep(te), "time_ids": rep(tid)}, dialog_bbox=rep(db)).sample
+    eng = m._engines[next(k for k in m._engines if k[0] == 6 and k[1] == 72)]
+    assert eng.ln_fused_launches >= 140, eng.ln_fused_launches
+    for r in range(6):
+        assert torch.equal(y[r], y[0 if r < 3 else 3]), r
+    assert _rel(y[3], y[0]) > 1e-3
