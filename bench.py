@@ -12,7 +12,7 @@ images are 224x224 uint8 that go through the reference's CPU image processors). 
 SDXL / CLIP-H / ViT-MAE / Resampler shapes (no checkpoint is reachable offline; throughput is value independent).
 The timed region also runs both SDXL text encoders (CLIP-L + OpenCLIP bigG shapes, HIP engine) on the prompt and the
 negative prompt (token ids from a synthetic tokenizer: no vocabulary files offline) and ends, like the reference's
-`__call__` (pipeline_diffsensei.py:339-367), with the SDXL VAE decode + denormalisation on the bf16 HIP decoder and the
+`__call__` (pipeline_diffsensei.py:339-367), with the SDXL VAE decode + denormalisation on the scaled-fp16 HIP decoder (config.vae_precision) and the
 conversion to PIL images on the host (uint8 conversion on the device, 3 bytes per pixel over PCIe); `--output pt` stops
 at [0,1] fp32 images on the device (round-1 region), `--no-vae` at the latents.
 
@@ -312,6 +312,47 @@ def profile_forward_ops(pipe, reps=3):
     return table, sum(acc) / reps
 
 
+def spawn_ranks(n: int) -> int:
+    """Re-run this command line as `python -m torch.distributed.run --nnodes=1 --nproc-per-node n ... bench.py <same flags>`
+    on a free local port (rendezvous on 127.0.0.1: the container hostname may not resolve) and return its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    log("bench.py: no torchrun environment, starting", n, "ranks:", " ".join(cmd[1:8]), "...")
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args, rank: int, world: int) -> None:
+    """The launcher / process-group / timing skeleton of main() with a sleep for a step (no GPU, no kernels)."""
+    for _ in range(args.warmup):
+        time.sleep(0.01)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.01)
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt])
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (no kernels)", "value": None, "unit": "panels/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dry_run": True}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -344,11 +385,22 @@ def main():
                          "region and feed its ip_image_embeds to the sampler (scripts/demo/gradio.py:85-129); "
                          "not part of the default metric line (round 1: every stage GPU-tested and the pre-pass "
                          "measured on its own by tools/mllm_bench.py; the combined full-size run is still to be taken)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="control flow only (launcher, process group, barriers, max-over-ranks timing, the JSON line): the "
+                         "step is a 10 ms sleep, no kernels, runs without a GPU - tests/test_distributed_gloo.py uses it")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` without a torchrun environment: start the N ranks ourselves (the plain form
+    # used to die on the WORLD_SIZE assert).  Under torchrun (RANK / WORLD_SIZE exported) this is skipped.
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
+
     from diffsensei_amd.distributed import init_from_env
-    rank, world, local = init_from_env("nccl" if args.gpus > 1 else None)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    rank, world, local = init_from_env(("nccl" if torch.cuda.is_available() else "gloo") if args.gpus > 1 else None)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher exported WORLD_SIZE={world}")
+    if args.dry_run:
+        return dry_run(args, rank, world)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     from diffsensei_amd import build as _build

@@ -18,11 +18,11 @@
 #include "ds_common.h"
 #include "ds_kernels.h"
 
-static int g_attn_variant = 0;  // 0 auto, 1 force 32 query rows per wave (QB = 1), 2 force 64 rows per wave (QB = 2)
+static thread_local int g_attn_variant = 0;  // 0 auto, 1 force 32 query rows per wave (QB = 1), 2 force 64 rows per wave (QB = 2)
 void ds_attn_set_variant(int v) { g_attn_variant = v; }
-static long g_ip_min_blocks = 1024;  // ip_attn: double the query tiles per block while the grid keeps this many blocks
+static thread_local long g_ip_min_blocks = 1024;  // ip_attn: double the query tiles per block while the grid keeps this many blocks
 void ds_ip_attn_set_min_blocks(int v) { g_ip_min_blocks = v; }
-static int g_ip_variant = 0;  // ip_attn: 0 auto, 1 force the 4-wave register-staged kernel, 2 force the 8-wave LDS-DMA ring kernel
+static thread_local int g_ip_variant = 0;  // ip_attn: 0 auto, 1 force the 4-wave register-staged kernel, 2 force the 8-wave LDS-DMA ring kernel
 void ds_ip_attn_set_variant(int v) { g_ip_variant = v; }
 
 namespace {

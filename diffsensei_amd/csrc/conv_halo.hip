@@ -463,7 +463,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo256_kernel(const GemmParams p
     }
 }
 
-int g_halo_variant = 0;  // 0 auto, 1 force the 8 x 16 kernel, 2 force the 16 x 16 kernel (where its shape rule holds)
+static thread_local int g_halo_variant = 0;  // 0 auto, 1 force the 8 x 16 kernel, 2 force the 16 x 16 kernel (where its shape rule holds)
 
 }  // namespace
 

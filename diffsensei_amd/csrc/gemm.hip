@@ -21,11 +21,11 @@
 #include "ds_common.h"
 #include "ds_kernels.h"
 
-static int g_gemm_variant = 0;  // 0 auto; A/B: 1 register staging, 2 two-buffer glds, 3 ping-pong 256x256, 7 two-buffer BM 64, 8/9 one-buffer glds (BM 128/64), 10 halo conv
+static thread_local int g_gemm_variant = 0;  // 0 auto; A/B: 1 register staging, 2 two-buffer glds, 3 ping-pong 256x256, 7 two-buffer BM 64, 8/9 one-buffer glds (BM 128/64), 10 halo conv
 void ds_gemm_set_variant(int v) { g_gemm_variant = v; }
-static int g_gemm_ring = 0;  // 0 auto, 1 never use the ring-buffered small-grid kernel (A/B)
+static thread_local int g_gemm_ring = 0;  // 0 auto, 1 never use the ring-buffered small-grid kernel (A/B)
 void ds_gemm_set_ring(int v) { g_gemm_ring = v; }
-static int g_gemm_debug = 0;  // ablation switches, see GemmParams::debug
+static thread_local int g_gemm_debug = 0;  // ablation switches, see GemmParams::debug
 void ds_gemm_set_debug(int v) { g_gemm_debug = v; }
 
 namespace {

@@ -791,7 +791,7 @@ int g_pp_blocks = 0;  // persistent grid size: one block per CU
 // TF/s; the N = K = 1280 projections 137 -> 126 us); shapes with whole rounds are unchanged.  A half-empty last round
 // leaves the stragglers' operand panels without the sharers the XCD-chunked walk counts on, and on this power-limited
 // part the idle CUs buy nothing.  Knob "gemm_pp_even" 0 restores one block per CU (A/B).
-int g_pp_even = 1;
+thread_local int g_pp_even = 1;
 
 }  // namespace
 

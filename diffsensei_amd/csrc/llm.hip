@@ -609,7 +609,7 @@ __global__ __launch_bounds__(256) void llm_gemv_pipe_kernel(LlmGemvParams p) {
     }
 }
 
-int g_llm_gemv_variant = 0;  // 0 auto (pipelined), 1 one-column-per-wavefront kernel, 2 un-pipelined streaming kernel
+static thread_local int g_llm_gemv_variant = 0;  // 0 auto (pipelined), 1 one-column-per-wavefront kernel, 2 un-pipelined streaming kernel
 
 template <int MC, int SWIGLU>
 int launch_gemv_stream(const LlmGemvParams& p, hipStream_t stream) {

@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict
 
 }  // namespace
 
-static int g_gn_variant = 0;  // 0: 512-thread blocks, >= 64 rows per block; 1: the round-3 geometry (256 threads, 8-row chunks)
+static thread_local int g_gn_variant = 0;  // 0: 512-thread blocks, >= 64 rows per block; 1: the round-3 geometry (256 threads, 8-row chunks)
 void ds_groupnorm_set_variant(int v) { g_gn_variant = v; }
 
 size_t ds_groupnorm_ws_floats(int B, int C) { return (size_t)B * GN_MAX_CHUNKS * C * 2 + (size_t)B * C * 2; }

@@ -92,10 +92,11 @@ class WeightArena:
                     owner_of[skey] = t
                     groups.setdefault((t.device, t.dtype), []).append(t)
                     self.payload_bytes += t.numel() * t.element_size()
-                elif first.dtype == t.dtype:
-                    aliases.append((t, first))  # same memory, maybe another shape: one slot
                 else:
-                    self.loose.append(t)
+                    # same memory, maybe another shape - or another element type (a uint8 / int32 reinterpretation of a
+                    # packed weight, ADVICE r4: sent "loose" it kept the OLD storage and the aliasing broke silently): one
+                    # slot, re-pointed below through the owner's new storage
+                    aliases.append((t, first))
             elif owns:                          # empty tensor: nothing to move or send
                 continue
             else:
@@ -129,7 +130,11 @@ class WeightArena:
                     torch.cuda.empty_cache()    # hand the freed originals back before the next segment is allocated
             self.buffers[(dev, dtype)] = segs
         for t, first in aliases:
-            t.set_(first.untyped_storage(), first.storage_offset(), t.size(), t.stride())
+            # storage offsets count ELEMENTS of the aliasing tensor's own type: the owner's byte offset (a multiple of ALIGN)
+            # divides by any element size
+            off_bytes = first.storage_offset() * first.element_size()
+            assert off_bytes % t.element_size() == 0
+            t.set_(first.untyped_storage(), off_bytes // t.element_size(), t.size(), t.stride())
         for t, skey, off in views:
             base = owner_of.get(skey)
             if base is not None and base.dtype == t.dtype:
@@ -305,30 +310,52 @@ def shard_requests(requests: Sequence[PanelRequest], world_size: int) -> List[Li
     return shards
 
 
+class _WirePil:
+    """A PIL image on the wire: its pixels as ONE contiguous uint8 array (3 bytes per pixel) instead of a pickled PIL object."""
+    __slots__ = ("px",)
+
+    def __init__(self, px):
+        self.px = px
+
+
 def _to_wire(x):
-    """What crosses the process boundary in a result gather: uint8 / float arrays, not pickled PIL objects (3 bytes per pixel,
-    one contiguous buffer per image; rank 0 wraps them back into PIL images only if the caller asks for it)."""
+    """What crosses the process boundary in a result gather: uint8 / float arrays, not pickled PIL objects; what was a PIL
+    image stays marked as one so that rank 0 can hand back the worker's own types."""
     import numpy as np
     if isinstance(x, (list, tuple)):
         return [_to_wire(v) for v in x]
     if isinstance(x, Tensor):
         return x.detach().cpu().numpy()
     if hasattr(x, "mode") and hasattr(x, "size") and hasattr(x, "tobytes"):   # a PIL image
-        return np.asarray(x)
+        return _WirePil(np.ascontiguousarray(np.asarray(x)))
     return x
 
 
-def _from_wire(x, as_pil: bool):
+def _from_wire(x, as_pil: Optional[bool]):
+    """`as_pil` None: what the worker produced (PIL stays PIL, arrays stay arrays); True: every uint8 [H,W,1|3|4] array
+    becomes a PIL image; False: every image is a uint8 array."""
     import numpy as np
     if isinstance(x, list):
         return [_from_wire(v, as_pil) for v in x]
-    if as_pil and isinstance(x, np.ndarray) and x.dtype == np.uint8 and x.ndim == 3 and x.shape[2] in (1, 3, 4):
+    was_pil = isinstance(x, _WirePil)
+    if was_pil:
+        x = x.px
+    img_like = isinstance(x, np.ndarray) and x.dtype == np.uint8 and (x.ndim == 2 or (x.ndim == 3 and x.shape[2] in (1, 3, 4)))
+    if img_like and (as_pil is True or (as_pil is None and was_pil)):
         from PIL import Image
-        return Image.fromarray(x if x.shape[2] != 1 else x[:, :, 0])
+        return Image.fromarray(x[:, :, 0] if x.ndim == 3 and x.shape[2] == 1 else x)
     return x
 
 
-def _gather_results(results: dict, rank: int, world: int, as_pil: bool):
+def _normalise_local(results: dict, as_pil: Optional[bool]) -> dict:
+    """The world_size-1 / gather=False path returns the same TYPES a gather would (the result type used to depend
+    on the world size); with as_pil None that is the worker's own objects, untouched."""
+    if as_pil is None:
+        return results
+    return {k: _from_wire(_to_wire(v), as_pil) for k, v in results.items()}
+
+
+def _gather_results(results: dict, rank: int, world: int, as_pil: Optional[bool]):
     wire = {k: _to_wire(v) for k, v in results.items()}
     gathered: List[Optional[dict]] = [None] * world if rank == 0 else None
     dist.gather_object(wire, gathered, dst=0)
@@ -341,24 +368,26 @@ def _gather_results(results: dict, rank: int, world: int, as_pil: bool):
 
 
 def run_sharded(requests: Sequence[PanelRequest], worker: Callable[[PanelRequest], object], gather: bool = True,
-                as_pil: bool = False):
+                as_pil: Optional[bool] = None):
     """Every rank runs `worker` on its shard; rank 0 optionally receives all results keyed by request_id.  Gathered images
-    travel as uint8 arrays ([H,W,3]); `as_pil` re-wraps them on rank 0."""
+    travel as uint8 arrays ([H,W,3]); by default (`as_pil` None) rank 0 gets back what the workers produced - PIL images
+    stay PIL images - whatever the world size; `as_pil` False asks for the uint8 arrays, True for PIL everywhere."""
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
     mine = shard_requests(requests, world)[rank]
     results = {r.request_id: worker(r) for r in mine}
     if not gather or world == 1:
-        return results
+        return _normalise_local(results, as_pil)
     return _gather_results(results, rank, world, as_pil)
 
 
 def run_sharded_batched(requests: Sequence[PanelRequest], pipe, max_panels: int = 16, max_pixels: Optional[int] = None,
-                        output_type: str = "pil", gather: bool = True, as_pil: bool = False):
+                        output_type: str = "pil", gather: bool = True, as_pil: Optional[bool] = None):
     """`run_sharded` for a whole queue: every rank pushes its shard through a `serving.BucketBatcher`, so requests of
     one (size, steps, guidance) bucket share UNet batches on that rank (BASELINE.json configs[3]: mixed-resolution
     queue over the GPUs of a node).  `PanelRequest.payload` holds the other `__call__` keyword arguments.  With
-    `gather`, rank 0 receives every request's images as uint8 arrays (`as_pil`: re-wrapped into PIL images there)."""
+    `gather`, rank 0 receives every request's images (moved as uint8 arrays; `as_pil` as in `run_sharded`: by default the
+    result has the types `output_type` asked for, on one rank or on eight)."""
     from .serving import BucketBatcher
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
@@ -370,5 +399,5 @@ def run_sharded_batched(requests: Sequence[PanelRequest], pipe, max_panels: int 
     outs = batcher.run(output_type=output_type)
     results = {r.request_id: o for r, o in zip(mine, outs)}
     if not gather or world == 1:
-        return results
+        return _normalise_local(results, as_pil)
     return _gather_results(results, rank, world, as_pil)

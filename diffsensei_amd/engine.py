@@ -176,9 +176,10 @@ class PackedUNet:
                 put(f"{t}.ff.net.0.proj.weight", wp)
                 put(f"{t}.ff.net.0.proj.bias", bp)
                 dv = lambda n: sd[n].to(device)
-                if a.channels % 128 == 0:
-                    # (packed whatever DIFFSENSEI_LN_FUSION says: the switch belongs to the plan builder, and a plan built later
-                    # with fusion on must find the copies)
+                if a.channels % 128 == 0 and ln_fusion_enabled():
+                    # (with DIFFSENSEI_LN_FUSION=0 in the environment at LOAD time the +2.1 GB of copies are not made
+                    # at all; a plan built later simply finds none and keeps the LayerNorm launches.  With the default - on -
+                    # they are packed once here and the plan builder decides per level and batch which set it uses.)
                     # fused-LayerNorm copies for norm1 -> q|k (row form) and -> to_v, produced transposed (operand-swapped form:
                     # (-c, b') per output row)
                     gw, c2, b2 = pack_ln_fused(self.w[f"{t}.attn1.qk.weight"], None, dv(f"{t}.norm1.weight"), dv(f"{t}.norm1.bias"))
@@ -470,7 +471,10 @@ class UNetEngine:
         # and the attention kernel masks those keys; nothing is copied or padded per call.
         Np = (N + 7) // 8 * 8
         tn = self._buf("t_norm", a.level, M + 8, Cc, zero=True)
-        h = self._buf("t_hidden", a.level, M, Cc)
+        # h gets the same 8 rows of zeroed slack as tn: with fused norm1 the transposed to_v GEMM reads the RAW stream h at
+        # Np = ceil8(N) rows per image, i.e. up to 7 rows behind the last image (with N % 8 != 0 these became the
+        # V^T pad columns, and 0 x NaN of stale bytes would poison the P V MFMA).  Producers only ever write rows < M.
+        h = self._buf("t_hidden", a.level, M + 8, Cc, zero=True)
         qk = self._buf("t_qk", a.level, M, 2 * Cc)
         vt = self._buf("t_vt", a.level, B * Np, Cc)
         ao = self._buf("t_attn", a.level, M, Cc)

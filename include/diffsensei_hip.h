@@ -28,7 +28,10 @@ const char* ds_last_error(void);
 int ds_version(void);
 /* number of HIP devices visible / properties of the current one (sanity for loaders) */
 int ds_device_info(int* cu_count, int* lds_bytes, char* arch_name, int arch_name_len);
-/* Tuning / test knobs (process-wide; every one defaults to 0 = automatic dispatch, which is what production runs).
+/* Tuning / test knobs.  THREAD-LOCAL since round 5 (no global mutable state beside the last-error slot - which is
+ * thread-local too): a value set here changes only the launches the CALLING THREAD issues afterwards; other threads, and so
+ * other serving handles of the process, keep the automatic dispatch.  Every knob defaults to 0 = automatic, which is what
+ * production runs.
  * They exist so that A/B runs and the parity tests can force a kernel variant the automatic rule would only pick at
  * large problem sizes; every variant of an operator computes the same result (the tests assert torch.equal between them).
  *   "gemm_variant"       0 auto | 1 register-staged only | 2, 7 two-buffer LDS-DMA | 8, 9 one-buffer LDS-DMA |

@@ -36,6 +36,27 @@ def test_missing_library_is_loud(monkeypatch, tmp_path):
         _lib.load()
 
 
+def test_option_knobs_are_thread_local(hip_lib):
+    """"no global mutable state except the last-error TLS slot".  The A/B knobs of `ds_set_option` are
+    thread-local since round 5: a kernel family forced on one thread does not change what another
+    thread - another serving handle of the same process - dispatches.  `ds_gemm_ln_fusable` is a pure host query of the
+    dispatch rule (no GPU needed): it answers 0 while the calling thread forces the register-staged GEMM family."""
+    import threading
+    q = lambda: hip_lib.ds_gemm_ln_fusable(65536, 1280, 1280, 0, 1)
+    auto = q()
+    assert auto == 1
+    other = []
+    try:
+        assert hip_lib.ds_set_option(b"gemm_variant", 1) == 0
+        assert q() == 0
+        t = threading.Thread(target=lambda: other.append(q()))
+        t.start()
+        t.join()
+    finally:
+        hip_lib.ds_set_option(b"gemm_variant", 0)
+    assert other == [auto] and q() == auto
+
+
 def test_ops_refuse_cpu_tensors(hip_lib):
     from diffsensei_amd import _lib, ops
     with pytest.raises(_lib.DiffSenseiHipError):

@@ -285,6 +285,23 @@ def test_weight_arena_rehomes_tensors_in_place():
     assert sum(x.numel() * x.element_size() for x in sl) == arena.bytes and all(x.is_contiguous() for x in sl)
 
 
+def test_weight_arena_keeps_aliases_of_another_element_type():
+    """a tensor that shares a listed owner's storage under a DIFFERENT dtype (the int16 / uint8 reinterpretation of a
+    packed f16 weight) used to go to `loose` with its old storage while the owner was re-homed - the aliasing broke silently.
+    It now follows the owner into its slot and costs no message of its own."""
+    from diffsensei_amd.distributed import WeightArena
+    w = torch.arange(96, dtype=torch.float32).half().view(8, 12)
+    first = torch.randn(5, 3).half()                              # pushes w's slot to a non-zero offset of the segment
+    as_i16, as_u8 = w.view(torch.int16), w.view(-1).view(torch.uint8)
+    bits = as_i16.clone()
+    arena = WeightArena([first, w, as_i16, as_u8])
+    assert arena.loose == [] and arena.payload_bytes == (15 + 96) * 2
+    assert as_i16.data_ptr() == w.data_ptr() == as_u8.data_ptr() and w.storage_offset() > 0
+    assert torch.equal(as_i16, bits) and as_u8.shape == (192,) and as_i16.shape == (8, 12)
+    w[3, 4] = 1.0
+    assert int(as_i16[3, 4]) == 0x3C00 and int(as_u8[2 * (3 * 12 + 4) + 1]) == 0x3C
+
+
 def test_weight_arena_segments_bound_the_transient_copy():
     """Segments: the arena is filled in pieces of at most `segment_bytes` (1 GiB in production), so re-homing never holds a
     second copy of all weights; a tensor larger than a segment gets a segment of its own."""
@@ -371,3 +388,35 @@ def test_broadcast_pipeline_requires_weights_changed_of_every_engine():
     for cls in (encoders.ViTEncoderEngine, encoders.ClipTextEngine, resampler.Resampler, unet.UNetMangaModel,
                 vae.VaeDecoderEngine, mllm.LlamaDecodeEngine, mllm.QwenResampler, mllm.ContinuousLVLM):
         assert callable(getattr(cls, "weights_changed", None)) and callable(getattr(cls, "tensors", None)), cls
+
+
+def _run_bench(args, env_extra=None, drop=("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")):
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in drop}
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *args], env=env, capture_output=True, text=True,
+                       timeout=300)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, [json.loads(ln) for ln in lines]
+
+
+def test_bench_gpus2_without_torchrun_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with NO torchrun environment (the form the driver uses at N = 1) used to
+    die on `assert world == args.gpus`; it now re-launches itself under torch.distributed.run on a free 127.0.0.1 port.
+    `--dry-run` keeps the launcher, the process group (gloo here: no GPU), both barriers, the max-over-ranks reduction and the
+    one JSON line from rank 0, and replaces the step by a sleep."""
+    r, lines = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1, r.stdout            # ONE line, from rank 0 only
+    ln = lines[0]
+    assert ln["n_gpus"] == 2 and ln["steps"] == 3 and ln["warmup"] == 1 and ln["dry_run"] is True
+    assert ln["ms_per_step"] >= 10.0 and ln["scaling"] == "weak"
+
+
+def test_bench_under_torchrun_env_mismatch_is_an_error_not_a_hang():
+    """Under a launcher whose WORLD_SIZE disagrees with --gpus the script exits with a message (no spawn, no assert)."""
+    r, lines = _run_bench(["--gpus", "2", "--dry-run"], env_extra={"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"}, drop=())
+    assert r.returncode != 0 and not lines
+    assert "WORLD_SIZE=1" in r.stderr
