@@ -24,9 +24,13 @@
 //     WAR  a half-tile is restaged >= 2 phases after its last ds_read; B0 is restaged ONE phase after its read,
 //          which is legal only because P1 issues the B0 reads first and retires them (lgkmcnt(8)) before P1's
 //          first barrier.
-//   * persistent: a block walks tiles id = round * grid + chunk-of-its-XCD; the operand loads of the NEXT output
-//     tile's first k-tiles are issued before the epilogue of the current one, so the pipeline fill hides under it.
-//     For that to be true no wait of the epilogue may cover the prologue (vmcnt retires in issue order): the tile's
+//   * persistent: a block walks tiles id = round * grid + chunk-of-its-XCD, and the k-loop never drains between two of
+//     them (round 5): the stages of a tile's last two k-tiles, which used to re-fetch the last k-tile into slots nobody
+//     reads, fetch k-tiles 0 and 1 of the NEXT output tile instead - they ARE the next tile's pipeline fill, in the
+//     steady-state order, slots and hazards, so a tile boundary issues no prologue, no extra wait and no extra barrier; the
+//     next tile's coordinates and operand addresses (~190 scalar instructions with three integer divisions, on the critical
+//     path of every boundary until round 4) are computed under the first k-tile of the current one, where the scalar unit idles.
+//     For the fill to hide under the epilogue no wait of the epilogue may cover it (vmcnt retires in issue order): the tile's
 //     bias slice is staged into LDS with the tile's first k-tiles and read from there, the residual rows of a 32-row
 //     piece are requested before the previous piece's stores, and the C stores themselves keep draining under the next
 //     tile's first k-tiles (EX_TAIL).  Measured (profiles/r02_pp_epilogue_ab.txt): M = 32768, N = 2560, K = 1280
@@ -52,6 +56,8 @@
 //     pairs: the product is exact to 2^-22) and the row factor is the multiplier of the fma that used to be the bias add -
 //     in this kernel a lane owns a tile ROW, so rstd is a per-lane scalar.  The tile's statistics / c slices are LDS-DMA
 //     pieces staged with the tile's first k-tiles, like the bias.
+#include <type_traits>
+
 #include "ds_common.h"
 #include "ds_kernels.h"
 
@@ -146,51 +152,70 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     // tile columns of this wave's staging rows, per B half (see the header): first column of its 16
     const int cb0 = geglu ? (wave >> 2) * 128 + (wave & 3) * 16 : (wave >> 1) * 64 + (wave & 1) * 16;
     const int cbh = geglu ? 64 : 32;
-    const half_t* gA[2];
+    const half_t* gA[2];   // current tile: first row of the wave's 16 staged rows per half-tile
     const half_t* gB[2];
-    int krot = 0;
-    auto set_tile = [&](int id, int& m0, int& n0, int& bz) {
-        krot = (id & 31) % nk;
+    const half_t* nA[2];   // next tile of this block (the current one again when there is none: a harmless re-fetch)
+    const half_t* nB[2];
+    // tile id -> coordinates -> operand rows, in three pieces: at a tile boundary they are issued one piece per MFMA cluster of
+    // k-tile 0 (`hide_next` below), a handful of scalar instructions between every two MFMAs
+    auto tile_origin = [&](int id, int& m0, int& n0, int& bz) {
         int tm, tn;
-        bz = p.nbatch > 1 ? id / per_item : 0;
+        bz = id / per_item;   // (0 for an unbatched problem; unconditional: a branch here would split the MFMA cluster it is issued in)
         tile_coords(id - bz * per_item, p.tiles_m, p.tiles_n, tm, tn);
         if constexpr ((DBG & 32) != 0) tm = tn = 0;  // ablation: every block works on tile (0,0): all operand loads hit L2
         m0 = tm * 256;
         n0 = tn * 256;
+    };
+    // ragged edges: a wave's 16 rows are all inside or all outside (M, N multiples of 16); outside rows re-read the
+    // tile's first row - their products are never stored
+    auto rows_a = [&](int m0, int bz, const half_t* (&a)[2]) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            // ragged edges: a wave's 16 rows are all inside or all outside (M, N multiples of 16); outside rows
-            // re-read the tile's first row - their products are never stored
             const int ra = m0 + h * 128 + wave * 16;
-            const int rb = n0 + cb0 + h * cbh;
-            gA[h] = p.A + (long)bz * p.sA + (long)(ra < p.M ? ra : m0) * p.lda;
-            gB[h] = p.W + (long)bz * p.sW + (long)(rb < p.N ? rb : n0) * p.ldw;
+            a[h] = p.A + (long)bz * p.sA + (long)(ra < p.M ? ra : m0) * p.lda;
         }
     };
-    char* const sdst = smem + wave * 2048;
-    auto stage = [&](int op, int half, int buf, int kt) {
-        char* d = sdst + ((op * 2 + half) * 2 + buf) * HT;
-        int kp = kt;
-        if constexpr ((DBG & 128) != 0) {  // experiment: rotate the k order per tile so the tiles sharing a panel de-phase
-            kp = kt + krot;
-            kp -= kp >= nk ? nk : 0;
+    auto rows_b = [&](int n0, int bz, const half_t* (&b)[2]) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int rb = n0 + cb0 + h * cbh;
+            b[h] = p.W + (long)bz * p.sW + (long)(rb < p.N ? rb : n0) * p.ldw;
         }
-        const char* s = reinterpret_cast<const char*>((op == 0 ? gA[half] : gB[half]) + kp * 64);
+    };
+    auto set_tile = [&](int id, int& m0, int& n0, int& bz, const half_t* (&a)[2], const half_t* (&b)[2]) {
+        tile_origin(id, m0, n0, bz);
+        rows_a(m0, bz, a);
+        rows_b(n0, bz, b);
+    };
+    char* const sdst = smem + wave * 2048;
+    // crossc = IC<1>: kt may be nk or nk + 1 = k-tiles 0, 1 of the NEXT output tile (wave-uniform: scalar selects, no branch);
+    // IC<0>: the caller knows kt < nk (the first two k-tiles of a tile with nk >= 4, whose stages must not depend on the
+    // next tile's rows: those are still being computed beside them)
+    auto stage = [&](int op, int half, int buf, int kt, auto crossc) {
+        char* d = sdst + ((op * 2 + half) * 2 + buf) * HT;
+        const char* s;
+        if constexpr (decltype(crossc)::value != 0) {
+            const bool nx = kt >= nk;
+            const half_t* const base = op == 0 ? (nx ? nA[half] : gA[half]) : (nx ? nB[half] : gB[half]);
+            s = reinterpret_cast<const char*>(base + (nx ? kt - nk : kt) * 64);
+        } else {
+            s = reinterpret_cast<const char*>((op == 0 ? gA[half] : gB[half]) + kt * 64);
+        }
         const unsigned o0 = op == 0 ? oA[0] : oB[0], o1 = op == 0 ? oA[1] : oB[1];
         if constexpr ((DBG & 2) != 0) return;
         __builtin_amdgcn_global_load_lds((glb_void*)(s + (size_t)o0), (lds_void*)d, 16, 0, 0);
         __builtin_amdgcn_global_load_lds((glb_void*)(s + (size_t)o1), (lds_void*)(d + 1024), 16, 0, 0);
     };
-    auto stage_prologue = [&]() {  // all of k-tile 0, and B0/A0/B1 of k-tile 1 (its A1 is staged by tile 0's P1)
-        stage(0, 0, 0, 0);
-        stage(1, 0, 0, 0);
-        stage(1, 1, 0, 0);
-        stage(0, 1, 0, 0);
-        if (nk > 1) {
-            stage(1, 0, 1, 1);
-            stage(0, 0, 1, 1);
-            stage(1, 1, 1, 1);
-        }
+    // The block's FIRST tile only: all of k-tile 0 and B0/A0/B1 of k-tile 1 (its A1 is staged by k-tile 0's P1), in the
+    // order the last two k-tiles of a tile stage them for every later one
+    auto stage_prologue = [&]() {
+        stage(1, 0, 0, 0, IC<0>{});
+        stage(0, 0, 0, 0, IC<0>{});
+        stage(1, 1, 0, 0, IC<0>{});
+        stage(0, 1, 0, 0, IC<0>{});
+        stage(1, 0, 1, 1, IC<0>{});   // nk >= 2: K is a multiple of 128
+        stage(0, 0, 1, 1, IC<0>{});
+        stage(1, 1, 1, 1, IC<0>{});
     };
 
     // Interior tiles without a per-row bias or activation take the branch-free epilogues (all tiles of the UNet's shapes)
@@ -275,11 +300,25 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 
     f32x16 acc[4][2];
     constexpr bool mma_on = (DBG & 1) == 0;
-    // No branch anywhere in a k-tile (a taken scalar branch costs more than the slack a phase has): past the end of K
-    // the stages simply re-fetch the last k-tile into a buffer nobody reads, so the counted waits never change.
-    auto ktile = [&](auto bufc, auto exa, auto exb, int kt) {  // exa: EX of the P1 wait, exb: of the P2 / P4 waits
+    // No branch anywhere in a k-tile (a taken scalar branch costs more than the slack a phase has): past the end of K the
+    // stages fetch the next output tile's first two k-tiles (`stage`), so neither the counted waits nor the slot schedule
+    // ever change - the last k-tile of one tile and the first of the next are two ordinary neighbours.
+    // `beside(IC<phase>)`: scalar work issued INSIDE the phase's MFMA cluster, six scalar instructions behind every MFMA
+    // (sched_group_barrier): the next tile's coordinates in k-tile 0, nothing anywhere else.
+    auto nothing = [](auto) {};
+    auto ktile = [&](auto bufc, auto exa, auto exb, auto crossc, int kt, auto beside) {  // exa: EX of the P1 wait, exb: of the P2 / P4 waits
         constexpr int B = decltype(bufc)::value;
-        const int kt1 = min(kt + 1, nk - 1), kt2 = min(kt + 2, nk - 1);
+        constexpr bool BESIDE = !std::is_same<decltype(beside), decltype(nothing)>::value;
+        auto interleave = [&]() {
+            if constexpr (BESIDE) {
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x004, 6, 0);   // SALU
+                }
+            }
+        };
+        const int kt1 = kt + 1, kt2 = kt + 2;
         V8 bl[4], br[4], a0[4][2], a1[4][2];
         // ---------------- P1: B0 strip (first: retired before the barrier, see WAR above) + A0 rows
 #pragma unroll
@@ -291,12 +330,13 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
             a0[kk][1] = readA(0, B, 1, kk);
         }
         __builtin_amdgcn_sched_barrier(0);
-        stage(0, 1, B ^ 1, kt1);
+        stage(0, 1, B ^ 1, kt1, crossc);
         wait_newer(IC<5>{}, exa);  // B1(kt), read in P2: newer = A1(kt) + B0 A0 B1 A1 of kt+1
         asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
         PP_BARRIER();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         PP_PRIO(1);
+        beside(IC<1>{});
         if constexpr (mma_on) {
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
@@ -304,17 +344,19 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
                 acc[1][0] = Elt<T>::mfma(bl[kk], a0[kk][1], acc[1][0]);
             }
         }
+        interleave();
         PP_PRIO(0);
         PP_BARRIER();
         // ---------------- P2: B1 strip
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) br[kk] = readB(1, B, kk);
         __builtin_amdgcn_sched_barrier(0);
-        stage(1, 0, B, kt2);
+        stage(1, 0, B, kt2, crossc);
         wait_newer(IC<5>{}, exb);  // A1(kt), read in P3: newer = all of kt+1 + B0(kt+2)
         PP_BARRIER();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         PP_PRIO(1);
+        beside(IC<2>{});
         if constexpr (mma_on) {
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
@@ -322,6 +364,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
                 acc[1][1] = Elt<T>::mfma(br[kk], a0[kk][1], acc[1][1]);
             }
         }
+        interleave();
         PP_PRIO(0);
         PP_BARRIER();
         // ---------------- P3: A1 rows
@@ -331,10 +374,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
             a1[kk][1] = readA(1, B, 1, kk);
         }
         __builtin_amdgcn_sched_barrier(0);
-        stage(0, 0, B, kt2);
+        stage(0, 0, B, kt2, crossc);
         PP_BARRIER();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         PP_PRIO(1);
+        beside(IC<3>{});
         if constexpr (mma_on) {
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
@@ -342,13 +386,15 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
                 acc[3][1] = Elt<T>::mfma(br[kk], a1[kk][1], acc[3][1]);
             }
         }
+        interleave();
         PP_PRIO(0);
         PP_BARRIER();
         // ---------------- P4: no reads (B0 strip still in registers); the k-tile's one counted wait
-        stage(1, 1, B, kt2);
+        stage(1, 1, B, kt2, crossc);
         wait_newer(IC<5>{}, exb);  // B0 A0 (kt+1), read in the next P1: newer = B1 A1 (kt+1) + B0 A0 B1 (kt+2)
         PP_BARRIER();
         PP_PRIO(1);
+        beside(IC<4>{});
         if constexpr (mma_on) {
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
@@ -356,6 +402,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
                 acc[3][0] = Elt<T>::mfma(bl[kk], a1[kk][1], acc[3][0]);
             }
         }
+        interleave();
         PP_PRIO(0);
         PP_BARRIER();
     };
@@ -367,13 +414,20 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
         probe_c0 = __builtin_readcyclecounter();
         probe_r0 = __builtin_amdgcn_s_memrealtime();
     }
-    int m0, n0, bz;
-    set_tile(id, m0, n0, bz);
+    int m0, n0, bz;      // current tile
+    int nm0, nn0, nbz;   // next tile of this block
+    set_tile(id, m0, n0, bz, gA, gB);
+    nA[0] = gA[0], nA[1] = gA[1], nB[0] = gB[0], nB[1] = gB[1];
     derive_stage();
     stage_prologue();
     if (p.bias && is_fast(m0, n0)) stage_bias(n0);
     if constexpr ((FUSE & 5) != 0) stage_ln(m0, n0, bz);
     pad_tail();  // no epilogue yet behind the first prologue
+    derive_frag();
+    // A0 B0 of the first tile's k-tile 0 must have landed: all but the five newer half-tiles of the prologue and the EX_TAIL
+    // instructions behind them.  Every later tile finds them waited for by the previous tile's last P4, like any k-tile.
+    wait_newer(IC<5>{}, IC<EX_TAIL>{});
+    PP_BARRIER();
     while (true) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -381,26 +435,46 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        derive_frag();
-        // A0 B0 of k-tile 0 must have landed: all but the five newer half-tiles of the prologue - and the EX_TAIL
-        // vector-memory instructions issued behind them (the previous tile's last C stores), which keep draining under
-        // the first k-tiles.  (A vmcnt(0) here parked every wave of the CU until its C stores were acknowledged - and the
-        // whole chip writes its 256 x 256 tiles in the same few microseconds of each round.)  They are older than
-        // A1(k-tile 1), staged in k-tile 0's P1: the waits for it and for everything younger (k-tile 1's P2 on) already
-        // imply them.  gemm_debug bit 8 (256): drain first (A/B).
+        // The previous tile's last C stores (EX_TAIL of them) keep draining under the first k-tiles.  (A vmcnt(0) here parked
+        // every wave of the CU until its C stores were acknowledged - and the whole chip writes its 256 x 256 tiles in the same
+        // few microseconds of each round.)  They are older than A1(k-tile 1), staged in k-tile 0's P1: the waits for it and for
+        // everything younger (k-tile 1's P2 on) already imply them.  gemm_debug bit 8 (256): drain first (A/B).
         if ((p.debug & 256) != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        wait_newer(IC<5>{}, IC<EX_TAIL>{});
-        PP_BARRIER();
         if (wr == 1) PP_BARRIER();  // group 1 runs one barrier behind group 0 from here on
-        ktile(IC<0>{}, IC<EX_TAIL>{}, IC<EX_TAIL>{}, 0);
-        ktile(IC<1>{}, IC<EX_TAIL>{}, IC<0>{}, 1);
-        for (int kt = 2; kt < nk; kt += 2) {  // nk is even
-            ktile(IC<0>{}, IC<0>{}, IC<0>{}, kt);
-            ktile(IC<1>{}, IC<0>{}, IC<0>{}, kt + 1);
+        // ---- the NEXT tile's coordinates and operand rows (~190 scalar instructions, three integer divisions) are computed
+        // INSIDE the MFMA clusters of k-tile 0 - origin in P1, A rows in P2, W rows in P3 - where the scalar unit has nothing
+        // else to do; they are first read by the stages of k-tile 2.  No next tile: the current one again.  The opaque copies
+        // pin each piece inside its cluster (the inputs are born there, the results are consumed there).
+        const int nid = id + G;
+        const bool more = nid < ntiles;
+        auto hide_next = [&](auto ph) {
+            constexpr int P = decltype(ph)::value;
+            if constexpr (P == 1) {
+                int t = more ? nid : id;
+                asm volatile("" : "+s"(t));
+                tile_origin(t, nm0, nn0, nbz);
+                asm volatile("" : "+s"(nm0), "+s"(nn0), "+s"(nbz));
+            } else if constexpr (P == 2) {
+                rows_a(nm0, nbz, nA);
+                asm volatile("" : "+s"(nA[0]), "+s"(nA[1]));
+            } else if constexpr (P == 3) {
+                rows_b(nn0, nbz, nB);
+                asm volatile("" : "+s"(nB[0]), "+s"(nB[1]));
+            }
+        };
+        if (nk >= 4) {
+            ktile(IC<0>{}, IC<EX_TAIL>{}, IC<EX_TAIL>{}, IC<0>{}, 0, hide_next);
+            ktile(IC<1>{}, IC<EX_TAIL>{}, IC<0>{}, IC<0>{}, 1, nothing);
+            for (int kt = 2; kt < nk; kt += 2) {  // nk is even
+                ktile(IC<0>{}, IC<0>{}, IC<0>{}, IC<1>{}, kt, nothing);
+                ktile(IC<1>{}, IC<0>{}, IC<0>{}, IC<1>{}, kt + 1, nothing);
+            }
+        } else {  // K = 128: the tile's only two k-tiles already stage the next tile - its rows have to be known up front
+            set_tile(more ? nid : id, nm0, nn0, nbz, nA, nB);
+            ktile(IC<0>{}, IC<EX_TAIL>{}, IC<EX_TAIL>{}, IC<1>{}, 0, nothing);
+            ktile(IC<1>{}, IC<EX_TAIL>{}, IC<0>{}, IC<1>{}, 1, nothing);
         }
-        // (the over-fetched stages may still be in flight: a wave only ever writes its own 16 rows of a slot, and its
-        // loads return in order, so the next tile's prologue into the same slots lands after them)
-        if (wr == 0) PP_BARRIER();  // balance group 1's extra barrier: every ds_read of this tile has retired
+        if (wr == 0) PP_BARRIER();  // balance group 1's extra barrier: both groups run the epilogue side by side
 
         // ---- epilogue.  D layout (operands swapped): lane holds tile row ..+(lane&31); register r of a fragment is
         // column (r&3) + 8*(r>>2) + 4*(lane>>5) of its 32-column strip.
@@ -447,20 +521,16 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
                 for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = Elt<T>::mfma(cf[ni], mf, acc[mi][ni]);
                 asm volatile("" : "+v"(mf));   // keep the blocks in sequence (the scheduler would hoist all four fragment builds)
             }
-            // rstd of the lane's own tile row.  Plain epilogue: applied to the accumulators in place - no register stays live
-            // across the epilogue for it (its transposition overwrites all 4 KiB of `ep`).  GEGLU epilogue: its transposition
-            // only uses the first 2 KiB, so rstd is re-read from ep + 2048 per 32-row piece and is the multiplier of the fma
-            // that is the bias add otherwise (128 v_mul per wave and tile less on the GEMM with the most tiles).
-            if constexpr ((FUSE & 8) == 0) {
+            // rstd of the lane's own tile row is the multiplier of the fma that is the bias add otherwise (both epilogues; until
+            // round 4 the plain one scaled the accumulators in place first: 64 v_pk_mul_f32 per wave and tile).  The GEGLU
+            // transposition only uses the first 2 KiB of `ep`, so it re-reads rstd from ep + 2048 per 32-row piece; the plain
+            // one overwrites all 4 KiB and takes the four values into registers here.
+        }
+        float rs4[4] = {1.f, 1.f, 1.f, 1.f};
+        if constexpr (FUSE == 1) {
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-                const float rs = *reinterpret_cast<const float*>(ep + 2048 + ((mi >> 1) * 64 + (mi & 1) * 32 + l31) * 8 + 4);
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[mi][ni][r] *= rs;
-            }
-            }
+            for (int mi = 0; mi < 4; ++mi)
+                rs4[mi] = *reinterpret_cast<const float*>(ep + 2048 + ((mi >> 1) * 64 + (mi & 1) * 32 + l31) * 8 + 4);
         }
         if constexpr ((FUSE & 4) != 0) {
             // operand-swapped form: the statistics run along the tile columns (first MFMA operand), c and b' along the rows
@@ -508,15 +578,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
         }
         PP_FENCE();
 
-        // ---- next tile's pipeline fill goes out before this tile's epilogue
-        id += G;
-        const bool more = id < ntiles;
-        if (more) {
-            set_tile(id, m0, n0, bz);
-            derive_stage();
-            stage_prologue();
-        }
-        PP_FENCE();
+        // (the next tile's pipeline fill went out with the last two k-tiles: nothing to issue here)
         if (FUSE != 2 && FUSE != 1 && FUSE != 4 && fast && (geglu || FUSE == 9)) {
             const int no = (cn0 >> 1) + wc * 32;
             // store addresses = (uniform 64-bit base of the piece's rows) + zext(32-bit lane offset): the SGPR-base form of
@@ -599,8 +661,22 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
                         for (int g = 0; g < 4; ++g) {
                             const int c = ni * 32 + 8 * g + 4 * lhi;
                             V4 o;
+                            if constexpr (FUSE == 1) {
+                                // y = rstd (acc - mean c) + b': one fma per pair, the f32 pair pinned before it is rounded (the
+                                // compiler otherwise folds SOME of these into v_fma_mixlo_f16 - one rounding instead of two - and a
+                                // row's bits would depend on the accumulator slot it sits in: profiles/r04_determinism_bisect.txt)
+                                const f32x2 r2 = {rs4[mi], rs4[mi]};
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) o[e] = (T)(acc[mi][ni][4 * g + e] + (float)bq[ni * 4 + g][e]);
+                                for (int e = 0; e < 4; e += 2) {
+                                    f32x2 y = __builtin_elementwise_fma(f32x2{acc[mi][ni][4 * g + e], acc[mi][ni][4 * g + e + 1]}, r2,
+                                                                        f32x2{(float)bq[ni * 4 + g][e], (float)bq[ni * 4 + g][e + 1]});
+                                    asm("" : "+v"(y));
+                                    o[e] = (T)y[0], o[e + 1] = (T)y[1];
+                                }
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) o[e] = (T)(acc[mi][ni][4 * g + e] + (float)bq[ni * 4 + g][e]);
+                            }
                             *reinterpret_cast<V4*>(ep + l31 * 128 + ((((c >> 3) ^ (l31 >> 1)) & 7) << 4) + ((c >> 2) & 1) * 8) = o;
                         }
                     V8 v[4];
@@ -770,9 +846,17 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
             }
         }
         if (!more) break;
-        if (p.bias && is_fast(m0, n0)) stage_bias(n0);  // the next tile's (m0, n0 were advanced by set_tile above)
+        // ---- hand over to the next tile: its coordinates become the current ones, its bias / LayerNorm pieces go out behind
+        // this tile's C stores (the previous contents of `ep` have been consumed), the lane-derived staging and fragment offsets
+        // are rebuilt (not kept live across the epilogue: 13 registers the epilogue needs)
+        id = nid;
+        m0 = nm0, n0 = nn0, bz = nbz;
+        gA[0] = nA[0], gA[1] = nA[1], gB[0] = nB[0], gB[1] = nB[1];
+        if (p.bias && is_fast(m0, n0)) stage_bias(n0);
         if constexpr ((FUSE & 5) != 0) stage_ln(m0, n0, bz);
         if (!fast) pad_tail();                          // generic epilogue: its store count depends on the tile's edges
+        derive_stage();
+        derive_frag();
     }
     if constexpr ((DBG & 16) != 0) {
         if (blockIdx.x == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
@@ -831,7 +915,7 @@ int ds_launch_gemm_pp(const GemmParams& p0, int batch, hipStream_t stream) {
         {1, gemm_pp_kernel<half_t, 1>},   {2, gemm_pp_kernel<half_t, 2>},   {3, gemm_pp_kernel<half_t, 3>},
         {4, gemm_pp_kernel<half_t, 4>},   {6, gemm_pp_kernel<half_t, 6>},   {8, gemm_pp_kernel<half_t, 8>},   {16, gemm_pp_kernel<half_t, 16>},
         {17, gemm_pp_kernel<half_t, 17>}, {18, gemm_pp_kernel<half_t, 18>}, {20, gemm_pp_kernel<half_t, 20>}, {22, gemm_pp_kernel<half_t, 22>},
-        {24, gemm_pp_kernel<half_t, 24>}, {32, gemm_pp_kernel<half_t, 32>}, {48, gemm_pp_kernel<half_t, 48>}, {49, gemm_pp_kernel<half_t, 49>}, {64, gemm_pp_kernel<half_t, 64>}, {128, gemm_pp_kernel<half_t, 128>},
+        {24, gemm_pp_kernel<half_t, 24>}, {32, gemm_pp_kernel<half_t, 32>}, {48, gemm_pp_kernel<half_t, 48>}, {49, gemm_pp_kernel<half_t, 49>}, {64, gemm_pp_kernel<half_t, 64>},
 #endif
         {-2, gemm_pp_kernel<half_t, 0, 1>},  // -2 / -5 / -3: fused LayerNorm, consumer (plain / GEGLU epilogue) / producer
         {-5, gemm_pp_kernel<half_t, 0, 9>},
