@@ -9,11 +9,15 @@
 // sched_group_barrier.  What it takes:
 //   * no branch inside a step: the online-softmax rescale is deferred.  Scores leave the MFMA already shifted - the
 //     accumulator input of S^T = K Q^T is a register block holding -m_ref of the lane's query row - and in base 2 (Q is
-//     pre-multiplied by scale * log2 e once), so a probability is ONE v_exp_f32.  m_ref is only raised when a tile's maximum
-//     exceeds it by more than THR = 8 (p <= 256 fits f16 and f32 comfortably); that, the first tile and the ragged last tile
-//     are rare wave-uniform branches at the top of a step, outside the scheduled region.
-//   * the maximum of pair k+1's scores is taken at the end of step k (beside the P V MFMAs), so the decision at the top of step
-//     k+1 is one cross-half exchange and a compare.
+//     pre-multiplied by scale * log2 e once), so a probability is ONE v_exp_f32.
+//   * NO running maximum in the steady state (round 5).  m_ref is set from the first tile's maximum and afterwards only raised
+//     when it has to be: a step sums the f16 probabilities it has just packed (v_dot2c_f32_f16 against (1, 1): the row sum the
+//     normalisation needs anyway, taken from the very values the P V MFMA multiplies), and only when some lane's 32-key partial
+//     sum exceeds LIM = 2^14 (every p is then still < 2^14 << 65504) does a rare wave-uniform branch BEHIND the step take the
+//     tile maximum, raise m_ref, rescale O and l and redo the step's probabilities from the scores, which are still intact.
+//     Rounds 3-4 took every tile's maximum inside the step (16 v_max3 + a cross-half exchange + a ballot per step, and the
+//     maximum had to wait for the step's own Q K^T MFMAs to finish - the one place the VALU stalled on the matrix pipe).
+//     f16 keeps 11 bits whatever a probability's magnitude, l and O accumulate in f32: the result is as accurate as with p <= 1.
 //   * K and V^T tiles arrive by LDS-DMA (global_load_lds, swizzle on the source address) into a ring of three buffers each:
 //     no staging registers, no VALU for staging.  V^T is stored row-major exactly as it sits in HBM: the score MFMA's row
 //     order is permuted instead (tile row i holds key pi(i), pi = swap bits 2 and 3), after which the eight f16 a lane packs
@@ -29,10 +33,11 @@ namespace {
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr int TILE_B = 8192;      // one 64 x 64 f16 tile
 constexpr int V_BASE = 3 * TILE_B;
-constexpr float THR = 8.0f;
+constexpr float LIM = 16384.0f;   // a lane's 32-key partial row sum above this re-centres the row (p < 2^14 always)
 constexpr float NEG_BIG = -1.0e30f;
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
 
 // every LDS-DMA this wave has issued has landed, every wave of the block is here, and nothing moves across the point
 #define SP_SYNC()                                              \
@@ -83,25 +88,32 @@ __global__ __launch_bounds__(256, 2) void self_attn_sp_kernel(const SelfAttnPara
     // ---- LDS-DMA staging: per tile and operand two 4-KiB instructions; wave w, piece j covers tile rows (4 j + w) * 8 .. + 7
     const half_t* const kbase = p.k + (long)b * p.sk + h * 64;
     const half_t* const vbase = p.vt + ((long)(b * p.heads + h) * 64) * p.ldv;
-    const int srow = lane >> 3, sslot = lane & 7;
+    // (the lane's staging row / chunk are rebuilt from an opaque lane id inside every issue: hoisted out of the tile loop they
+    // are eight registers this kernel does not have - they went to scratch, and a scratch reload is a vmcnt(0) round trip per tile)
+    auto lane_now = [&]() -> int {
+        unsigned z = 0;
+        asm volatile("" : "+v"(z));
+        return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z));
+    };
+    const unsigned lds0 = (unsigned)(size_t)(lds_void*)smem;   // LDS byte address of the rings
     auto issue_k = [&](int t, int buf) {
+        const int ln = lane_now(), srow = ln >> 3, sslot = ln & 7;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int row = (4 * j + wave) * 8 + srow;
             const int key = min(t * 64 + row, p.Nk - 1);                 // rows past Nk re-read the last key (masked later)
             const int chunk = sslot ^ ((row >> 1) & 7);
-            __builtin_amdgcn_global_load_lds((glb_void*)(kbase + (long)key * p.ldk + chunk * 8),
-                                             (lds_void*)(smem + buf * TILE_B + (4 * j + wave) * 1024), 16, 0, 0);
+            lds_dma16(kbase, (unsigned)(key * (int)p.ldk + chunk * 8) * 2u, lds0 + buf * TILE_B + (4 * j + wave) * 1024);
         }
     };
     auto issue_v = [&](int t, int buf) {
+        const int ln = lane_now(), srow = ln >> 3, sslot = ln & 7;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int row = (4 * j + wave) * 8 + srow;                   // d
             const int chunk = sslot ^ ((row >> 1) & 7);
             const int kc = min(t * 64 + chunk * 8, ((p.Nk - 1) >> 3) << 3);  // chunks past Nk re-read the last one (P = 0 there)
-            __builtin_amdgcn_global_load_lds((glb_void*)(vbase + (long)row * p.ldv + kc),
-                                             (lds_void*)(smem + V_BASE + buf * TILE_B + (4 * j + wave) * 1024), 16, 0, 0);
+            lds_dma16(vbase, (unsigned)(row * (int)p.ldv + kc) * 2u, lds0 + V_BASE + buf * TILE_B + (4 * j + wave) * 1024);
         }
     };
 
@@ -189,86 +201,130 @@ __global__ __launch_bounds__(256, 2) void self_attn_sp_kernel(const SelfAttnPara
             for (int r = 0; r < 16; r += 2) m = fmaxf(fmaxf(m, S[kb][r]), S[kb][r + 1]);
         return m;
     };
-    // rare work at the top of a step (outside the scheduled region): ragged-key masking, the deferred rescale
-    auto fixup = [&](f32x16 (&S)[2], int qb, float& mx, int t) {
-        if (ragged && t == nt - 1) {
-            int nk_here = p.Nk;
-            asm volatile("" : "+s"(nk_here)::"memory");
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = t * 64 + kb * 32 + pi32((r & 3) + 8 * (r >> 2) + 4 * lhi);
-                    if (key >= nk_here) S[kb][r] = NEG_BIG;
-                }
-            mx = cross_max(tile_max(S));
-        }
-        const bool first = t == 0;
-        if (first || __builtin_amdgcn_ballot_w64(mx > THR) != 0) {
-            const float delta = first ? mx : fmaxf(mx, 0.f);   // the lane's reference maximum moves to m_ref + delta
-            const float alpha = first ? 1.0f : fexp2(-delta);
-            mref[qb] += delta;
-            lsum[qb] *= alpha;
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) S[kb][r] -= delta;
-#pragma unroll
-            for (int db = 0; db < 2; ++db)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) O[qb][db][r] *= alpha;
-        }
-    };
-    // One step: softmax of the CURRENT pair on the VALU beside the MFMAs of the NEXT pair's scores and the PREVIOUS pair's P V
-    auto step = [&](f32x16 (&Sc)[2], h8 (&Pc)[2][2], int qbc, f32x16 (&Sn)[2], unsigned kb_base, const h8 (&Pp)[2][2],
-                    unsigned vb_base, float& mx_next) {
-        const int qbn = qbc ^ 1;
-        qk(Sn, qbn, kb_base);
-        pv(Pp, qbn, vb_base);
-        // row sum, two scores per v_pk_add_f32: 17 fewer VALU per step and the same kernel time as scalar adds (239.6 vs
-        // 239.3 us at B = 32, N = 1024, profiles/r03_self_attn_sp.txt) - the step is not VALU-issue bound any more
-        f32x2 s2 = {0.f, 0.f};
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const f32x2 e = {fexp2(Sc[kb][r]), fexp2(Sc[kb][r + 1])};
-                s2 += e;
-                Sc[kb][r] = e[0];
-                Sc[kb][r + 1] = e[1];
-            }
-#pragma unroll
-            for (int hb = 0; hb < 2; ++hb)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) Pc[kb][hb][e] = (half_t)Sc[kb][hb * 8 + e];
-        }
-        lsum[qbc] += s2[0] + s2[1];
-        mx_next = tile_max(Sn);
-        // pin this step's results HERE: the packed probabilities are only consumed by the next step's MFMAs, and the
-        // compiler otherwise sinks the whole softmax below the branch between the steps - out of this scheduling region
-        // (inputs only: a tied in/out operand made the register allocator copy every packed pair into place - 16 v_mov per step)
+    // probabilities of one pair from its (shifted, base-2) scores: P = f16(exp2(S)), and the lane's partial row sum of the
+    // PACKED values (v_dot2c_f32_f16 against (1, 1)).  S is consumed: nothing reads it afterwards, its registers free up as the
+    // step proceeds (the rare re-centring behind a step recomputes the scores from K, which is still in its ring slot).
+    auto softmax = [&](const f32x16 (&S)[2], h8 (&P)[2][2]) -> float {
+        float sum[2] = {0.f, 0.f};   // two chains: the dot accumulates in place, one chain would serialise 16 of them
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int hb = 0; hb < 2; ++hb) asm volatile("" ::"v"(Pc[kb][hb]));
-        asm volatile("" ::"v"(lsum[qbc]), "v"(mx_next));
-        // issue order: the bias block and two fragments first (the first MFMA needs them), then 16 x {1 MFMA, 1 fragment
-        // read, 2 exponentials, 5 other VALU}: the matrix pipe never waits for a block of VALU work
-        __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);      // VALU: the 16 bias registers
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);       // DS read
+            for (int hb = 0; hb < 2; ++hb) {
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    const h2v pr = {(half_t)fexp2(S[kb][hb * 8 + e]), (half_t)fexp2(S[kb][hb * 8 + e + 1])};
+                    P[kb][hb][e] = pr[0];
+                    P[kb][hb][e + 1] = pr[1];
+                    sum[hb] = __builtin_amdgcn_fdot2(pr, h2v{(half_t)1.f, (half_t)1.f}, sum[hb], false);
+                }
+            }
+        return sum[0] + sum[1];
+    };
+    auto mask_ragged = [&](f32x16 (&S)[2], int t) {   // keys >= Nk of the last tile
+        int nk_here = p.Nk;
+        asm volatile("" : "+s"(nk_here)::"memory");
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = t * 64 + kb * 32 + pi32((r & 3) + 8 * (r >> 2) + 4 * lhi);
+                if (key >= nk_here) S[kb][r] = NEG_BIG;
+            }
+    };
+    // rare work at the top of a step (outside the scheduled region): the ragged last tile masks keys, the first tile sets m_ref
+    auto prepare = [&](f32x16 (&S)[2], int qb, int t) {
+        if (ragged && t == nt - 1) mask_ragged(S, t);
+        if (t == 0) {   // scores arrived unshifted (m_ref = 0): centre the row on its first tile's maximum, whatever its sign
+            const float mx = cross_max(tile_max(S));
+            mref[qb] = mx;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) S[kb][r] -= mx;
+        }
+    };
+    // rare work BEHIND a step: some lane's partial row sum outgrew LIM (or overflowed to inf).  The pair's scores are computed
+    // again (K(t) has not left its ring slot), the rows whose tile maximum lies above m_ref are re-centred on it, what they have
+    // accumulated is rescaled and the pair's probabilities are redone.  O[qb] holds pairs before (t, qb) only (this pair's P V
+    // runs in the next step), so nothing of the redone pair is in it yet.
+    auto recentre = [&](f32x16 (&S)[2], h8 (&P)[2][2], int qb, unsigned kc_base, int t, float& sum) {
+        qk(S, qb, kc_base);
+        if (ragged && t == nt - 1) mask_ragged(S, t);
+        const float delta = fmaxf(cross_max(tile_max(S)), 0.f);
+        const float alpha = fexp2(-delta);
+        mref[qb] += delta;
+        lsum[qb] *= alpha;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) S[kb][r] -= delta;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) O[qb][db][r] *= alpha;
+        sum = softmax(S, P);
+    };
+    // One step: softmax of the CURRENT pair on the VALU beside the MFMAs of the NEXT pair's scores and the PREVIOUS pair's P V
+    // (kc_base: the ring slot of the current pair's own K tile, for `recentre`).
+    // Written out as 16 groups of {1 MFMA, the fragment read for the MFMA four groups ahead, 2 v_exp_f32, 1 pack, 1 dot}, each
+    // closed by a sched_barrier: the order below IS the issue order.  Every fragment is requested four MFMAs (~130 cycles: an
+    // LDS round trip) before the MFMA that consumes it, through a ring of four fragment registers, and is waited for with a
+    // COUNTED lgkmcnt(3) - which the compiler only emits because the LDS-DMA pieces of this kernel are issued from inline asm
+    // (`lds_dma16`, ds_common.h): behind a __builtin_amdgcn_global_load_lds it assumes a FLAT access that may bump lgkmcnt
+    // and turns every LDS wait of the kernel into lgkmcnt(0).  (Rounds 3-4 described the same
+    // mix to the scheduler with sched_group_barrier and let it place the reads: at 256 registers it put each read directly in
+    // front of its MFMA, so half of the MFMAs of a step sat behind an s_waitcnt lgkmcnt(0) for their own fragment - the matrix pipe
+    // measured 0.44 busy with a VALU load that explains 0.7.)  MFMA order: the two score blocks alternate (two independent
+    // accumulator chains), then P V with the two output blocks alternating.
+    auto step = [&](f32x16 (&Sc)[2], h8 (&Pc)[2][2], int qbc, unsigned kc_base, f32x16 (&Sn)[2], unsigned kb_base,
+                    const h8 (&Pp)[2][2], unsigned vb_base, int t) {
+        const int qbn = qbc ^ 1;
+        auto frag = [&](int g) -> h8 {   // g: compile-time after unrolling
+            if (g < 8) return *reinterpret_cast<const h8*>(smem + kb_base + koff[g >> 1] + (g & 1) * 4096);
+            return *reinterpret_cast<const h8*>(smem + vb_base + voff[(g - 8) >> 1] + ((g - 8) & 1) * 4096);
+        };
+        h8 fr[4];   // ring of four fragment registers
+#pragma unroll
+        for (int g = 0; g < 4; ++g) fr[g] = frag(g);
+        f32x16 negm;  // the accumulator input of the score MFMAs: -m_ref of the lane's query row in all 16 registers
+        {
+            const f32x2 nm2 = {-mref[qbn], -mref[qbn]};
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                negm[r] = nm2[0];
+                negm[r + 1] = nm2[1];
+            }
+        }
+        float sum[2] = {0.f, 0.f};   // two chains: the dot accumulates in place
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-            if (g < 14) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
-            __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);   // TRANS
-            __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);   // VALU
+            if (g < 8) {
+                const int kb = g & 1, kk = g >> 1;
+                Sn[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[g & 3], qf[qbn][kk], kk == 0 ? negm : Sn[kb], 0, 0, 0);
+            } else {
+                const int c = (g - 8) >> 1, db = (g - 8) & 1;
+                O[qbn][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[g & 3], Pp[c >> 1][c & 1], O[qbn][db], 0, 0, 0);
+            }
+            if (g + 4 < 16) fr[g & 3] = frag(g + 4);
+            {   // probabilities of score pair g of the current pair (S is consumed: its registers free up as the step proceeds)
+                const int kb = g >> 3, hb = (g >> 2) & 1, e = (g & 3) * 2;
+                const h2v pr = {(half_t)fexp2(Sc[kb][hb * 8 + e]), (half_t)fexp2(Sc[kb][hb * 8 + e + 1])};
+                Pc[kb][hb][e] = pr[0];
+                Pc[kb][hb][e + 1] = pr[1];
+                sum[g & 1] = __builtin_amdgcn_fdot2(pr, h2v{(half_t)1.f, (half_t)1.f}, sum[g & 1], false);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
+        float rsum = sum[0] + sum[1];
+        if (__builtin_amdgcn_ballot_w64(!(rsum <= LIM)) != 0)    // (!(<=): catches inf and NaN too)
+            recentre(Sc, Pc, qbc, kc_base, t, rsum);
+        lsum[qbc] += rsum;
     };
 
     // ---- prologue, part 2: scores of pair (0, qb 0)
     SP_SYNC();
     qk(S0, 0, 0u);
-    float mx0 = cross_max(tile_max(S0)), mx1 = 0.f;
 
     int kcur = 0, knext = nt > 1 ? 1 : 0, vprev = 0, vcur = 0;  // ring-buffer indices of K(t), K(t+1), V(t-1), V(t)
     for (int t = 0; t < nt; ++t) {
@@ -279,14 +335,11 @@ __global__ __launch_bounds__(256, 2) void self_attn_sp_kernel(const SelfAttnPara
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         // ---- step A: softmax(t, qb 0) | scores(t, qb 1) | P V (t-1, qb 1)
-        fixup(S0, 0, mx0, t);
-        float mraw;
-        step(S0, P0, 0, S1, (unsigned)kcur * TILE_B, P1, (unsigned)vprev * TILE_B, mraw);
-        mx1 = cross_max(mraw);
+        prepare(S0, 0, t);
+        step(S0, P0, 0, (unsigned)kcur * TILE_B, S1, (unsigned)kcur * TILE_B, P1, (unsigned)vprev * TILE_B, t);
         // ---- step B: softmax(t, qb 1) | scores(t+1, qb 0) | P V (t, qb 0)
-        fixup(S1, 1, mx1, t);
-        step(S1, P1, 1, S0, (unsigned)knext * TILE_B, P0, (unsigned)vcur * TILE_B, mraw);
-        mx0 = cross_max(mraw);
+        prepare(S1, 1, t);
+        step(S1, P1, 1, (unsigned)kcur * TILE_B, S0, (unsigned)knext * TILE_B, P0, (unsigned)vcur * TILE_B, t);
         vprev = vcur;
         vcur = vcur == 2 ? 0 : vcur + 1;
         kcur = knext;

@@ -171,6 +171,17 @@ __device__ __forceinline__ float wave_max(float v) {
 // Logical tile id -> (tm, tn) in GROUP x GROUP super-tiles (column-major inside a group of GROUP tile rows), so the
 // ~64 tiles an XCD has in flight touch ~8 A panels + ~8 W panels instead of 1 + 64: the per-XCD L2 (4 MiB) then
 // serves most panel re-reads (measured on the FF GEMM: L2 hit rate 49 % -> see DESIGN.md).
+// One LDS-DMA piece (16 bytes per lane: lane l lands at lds_addr + 16 l) issued from inline asm: global address = uniform 64-bit
+// base + the lane's 32-bit byte offset, LDS base through M0.  Why not __builtin_amdgcn_global_load_lds: the compiler models that
+// builtin as a FLAT access that may touch LDS and so may bump lgkmcnt out of order ("pending flat"): while one is in flight -
+// and the counted vmcnt waits of these kernels are inline asm it cannot see, so for it one always is - EVERY LDS wait it places is
+// s_waitcnt lgkmcnt(0), which kills any fragment read-ahead (found in round 5 on self_attn_sp_kernel: half of its MFMAs sat behind
+// a full LDS round trip).  The hardware tracks LDS-DMA with vmcnt only (gemm_pp_kernel's lgkmcnt(0) waits would otherwise wait
+// microseconds for its staging), so counted lgkmcnt waits beside DMA in flight are exact.  "memory": nothing moves across it.
+__device__ __forceinline__ void lds_dma16(const void* base, unsigned byte_off, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(byte_off), "s"(base), "s"(lds_addr) : "memory", "m0");
+}
+
 __device__ __forceinline__ void tile_coords(int id, int tiles_m, int tiles_n, int& tm, int& tn) {
     constexpr int GROUP = 8;
     const int per_group = GROUP * tiles_n;
