@@ -665,7 +665,7 @@ __global__ __launch_bounds__(256) void small_attn_kernel(const half_t* __restric
 // 0: self_attn_kernel<1>, 1: self_attn_kernel<2>, 2: self_attn_sp_kernel (see the measurements in ds_launch_self_attn)
 static int self_attn_choice(int B, int heads, int Nq, int Nk) {
     const long blocks_sp = (long)((Nq + 255) / 256) * B * heads;
-    if (g_attn_variant >= 3 || (g_attn_variant == 0 && blocks_sp >= 1024)) return 2;
+    if (g_attn_variant >= 3 || (g_attn_variant == 0 && blocks_sp >= 128)) return 2;
     if (g_attn_variant == 2 || (blocks_sp >= 512 && Nk >= 2048 && g_attn_variant != 1)) return 1;
     return 0;
 }
@@ -680,11 +680,12 @@ int ds_launch_self_attn(const SelfAttnParams& p, hipStream_t stream) {
     // anything finite: keys >= Nk are masked to probability 0 on the last tile)
     DS_REQUIRE(p.ldv % 8 == 0 && p.ldv >= (p.Nk + 7) / 8 * 8 && p.ldq % 8 == 0 && p.ldk % 8 == 0 && p.ldo % 4 == 0,
                "self_attn: ld* alignment (Nk=%d ldv=%ld)", p.Nk, p.ldv);
-    // Large grids: the software-pipelined kernel (attention_sp.hip; 256 query rows per block).  Measured on MI355X, interleaved
-    // rounds, profiles/r03_self_attn_sp.txt: B = 32, N = 1024 250 vs 276 us; B = 32, N = 4096 1581 vs 1679 us; B = 8, N = 4096 398 vs
-    // 422 us; below ~1000 blocks (B = 8, N = 1024: 640 blocks; B = 2) the plain kernels are 2-8 % faster.
-    // Else 64 query rows per wave when that still leaves >= 2 blocks per CU (wins from N = 4096 up, loses at N = 1024 -
-    // profiles/r01_attn_variants.txt), 32 rows per wave otherwise.
+    // From 128 blocks of 256 query rows on: the software-pipelined kernel (attention_sp.hip).  Round 5 (no running maximum,
+    // hand-scheduled step, counted LDS waits; profiles/r05_self_attn_sp_ab.txt, same box, us per launch, sp vs the 64-row flash
+    // kernel): B = 64, N = 1024 448 vs 499; B = 64, N = 4096 2914 vs 3481; B = 8, N = 1024 67 vs 74; B = 4, N = 1024 (320 blocks)
+    // 40.3 vs 47.9; B = 2, N = 1024 (160 blocks) 28.8 vs 30.5; B = 2, heads 20, N = 4096 226 vs 252; B = 2, N = 16384 1462 vs
+    // 1633 - it wins at every shape of the UNet at every batch (rounds 3-4: only from ~1000 blocks on).  Smaller grids keep the
+    // plain kernels: 64 query rows per wave when that still leaves >= 2 blocks per CU, 32 rows per wave otherwise.
     switch (self_attn_choice(p.B, p.heads, p.Nq, p.Nk)) {
         case 2: {
             SelfAttnParams q = p;

@@ -69,7 +69,13 @@ constexpr int HT = 16384;  // bytes of one half-tile: 128 rows x 64 k of f16
 // eight dummy LDS-DMA pieces (`pad_tail`) behind the first prologue and behind the generic epilogue, whose store count
 // depends on the tile's edges.  The counted waits of the first k-tiles leave exactly this many outstanding: more issued
 // than counted only waits longer, fewer would under-wait.
-constexpr int EX_TAIL = 8;
+#ifndef PP_EX
+#define PP_EX 8
+#endif
+#ifndef PP_RES_PF
+#define PP_RES_PF 0
+#endif
+constexpr int EX_MAX = PP_EX;   // build-time A/B (round 5): 16 = every C store of a plain tile may stay in flight under the next tile
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
@@ -111,6 +117,13 @@ template <typename T, int DBG, int FUSE = 0>  // T: half_t (UNet) or bf16_t (VAE
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     typedef typename Elt<T>::v8 V8;
     typedef typename Elt<T>::v4 V4;
+    // the fused GEGLU epilogue issues 8 stores + the bias piece + 2 LayerNorm pieces per tile: its count is capped at 11
+    constexpr int EX_TAIL = (FUSE == 9 && EX_MAX > 11) ? 11 : EX_MAX;
+    // residual prefetch (PP_RES_PF, round 5): the LayerNorm producer - the +residual projections of the transformer blocks.  (The
+    // plain instantiation carries residuals too - the 640-channel level - but sits at 255 registers: with the last k-tile pair
+    // peeled out of its loop four of them went to scratch across the k-loop, and a scratch reload is a vmcnt round trip behind
+    // all the staging in flight.)
+    constexpr int PF = (PP_RES_PF != 0 && FUSE == 2) ? 2 : 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int wr = wave >> 2, wc = wave & 3;
@@ -231,9 +244,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
         const int col = geglu ? tn0 + (wc >> 1) * 128 + (wc & 1) * 32 + (l7 >> 2) * 64 + (l7 & 3) * 8 : tn0 + wc * 64 + l7 * 8;
         __builtin_amdgcn_global_load_lds((glb_void*)(p.bias + col), (lds_void*)ep, 16, 0, 0);
     };
-    auto pad_tail = [&]() {  // EX_TAIL harmless pieces into the idle last KiB of `ep` (KiB 1 and 2 hold the LayerNorm pieces)
+    auto pad_tail = [&](auto nc) {  // harmless pieces into the idle last KiB of `ep` (KiB 1 and 2 hold the LayerNorm pieces)
 #pragma unroll
-        for (int j = 0; j < EX_TAIL; ++j)
+        for (int j = 0; j < decltype(nc)::value; ++j)
             __builtin_amdgcn_global_load_lds((glb_void*)(reinterpret_cast<const char*>(gA[0]) + (size_t)oA[0]),
                                              (lds_void*)(ep + 3072), 16, 0, 0);
     };
@@ -306,7 +319,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     // `beside(IC<phase>)`: scalar work issued INSIDE the phase's MFMA cluster, six scalar instructions behind every MFMA
     // (sched_group_barrier): the next tile's coordinates in k-tile 0, nothing anywhere else.
     auto nothing = [](auto) {};
-    auto ktile = [&](auto bufc, auto exa, auto exb, auto crossc, int kt, auto beside) {  // exa: EX of the P1 wait, exb: of the P2 / P4 waits
+    auto ktile = [&](auto bufc, auto exa, auto exb, auto exd, auto crossc, int kt, auto beside) {  // exa / exb / exd: EX of the P1 / P2 / P4 wait
         constexpr int B = decltype(bufc)::value;
         constexpr bool BESIDE = !std::is_same<decltype(beside), decltype(nothing)>::value;
         auto interleave = [&]() {
@@ -391,7 +404,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
         PP_BARRIER();
         // ---------------- P4: no reads (B0 strip still in registers); the k-tile's one counted wait
         stage(1, 1, B, kt2, crossc);
-        wait_newer(IC<5>{}, exb);  // B0 A0 (kt+1), read in the next P1: newer = B1 A1 (kt+1) + B0 A0 B1 (kt+2)
+        wait_newer(IC<5>{}, exd);  // B0 A0 (kt+1), read in the next P1: newer = B1 A1 (kt+1) + B0 A0 B1 (kt+2)
         PP_BARRIER();
         PP_PRIO(1);
         beside(IC<4>{});
@@ -422,7 +435,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     stage_prologue();
     if (p.bias && is_fast(m0, n0)) stage_bias(n0);
     if constexpr ((FUSE & 5) != 0) stage_ln(m0, n0, bz);
-    pad_tail();  // no epilogue yet behind the first prologue
+    pad_tail(IC<EX_TAIL>{});  // no epilogue yet behind the first prologue
     derive_frag();
     // A0 B0 of the first tile's k-tile 0 must have landed: all but the five newer half-tiles of the prologue and the EX_TAIL
     // instructions behind them.  Every later tile finds them waited for by the previous tile's last P4, like any k-tile.
@@ -462,17 +475,46 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
                 asm volatile("" : "+s"(nB[0]), "+s"(nB[1]));
             }
         };
+        // ---- residual prefetch (build-time switch PP_RES_PF): the tile's residual rows (one 128-byte line per row and wave: two
+        // 4-byte-per-lane LDS-DMA pieces into the idle KiB of `ep`, no register, no wait) are pulled into L2 two k-tiles before the
+        // epilogue asks for them.  Without it every +residual tile waits for its 128 KiB straight from HBM - and the whole chip
+        // asks in the same microsecond (32 MiB per round: ~6 us at HBM rate, measured as the difference between the +residual and
+        // the plain shapes' tile boundary, profiles/r05_pp_seamless_ab.txt).  Two more vector-memory instructions in flight behind
+        // A1(nk-1): the five counted waits that follow allow for them (PF).
+        auto prefetch_res = [&](auto ph) {
+            if constexpr (decltype(ph)::value == 1 && PF != 0) {
+                const int ln = lane_id();
+                const bool on = p.residual != nullptr && is_fast(m0, n0);
+                const char* const r0 = on ? reinterpret_cast<const char*>(p.residual + (long)bz * p.sR + (long)(m0 + wr * 64) * p.ldr + n0 + wc * 64)
+                                          : reinterpret_cast<const char*>(gA[0]);
+                const unsigned lo = on ? (unsigned)(ln * (int)p.ldr) * 2u : oA[0];
+                const size_t half = on ? (size_t)p.ldr * 256 : 0;   // rows 128.. of the tile
+                __builtin_amdgcn_global_load_lds((glb_void*)(r0 + (size_t)lo), (lds_void*)(ep + 3072), 4, 0, 0);
+                __builtin_amdgcn_global_load_lds((glb_void*)(r0 + half + (size_t)lo), (lds_void*)(ep + 3072 + 256), 4, 0, 0);
+            }
+        };
         if (nk >= 4) {
-            ktile(IC<0>{}, IC<EX_TAIL>{}, IC<EX_TAIL>{}, IC<0>{}, 0, hide_next);
-            ktile(IC<1>{}, IC<EX_TAIL>{}, IC<0>{}, IC<0>{}, 1, nothing);
-            for (int kt = 2; kt < nk; kt += 2) {  // nk is even
-                ktile(IC<0>{}, IC<0>{}, IC<0>{}, IC<1>{}, kt, nothing);
-                ktile(IC<1>{}, IC<0>{}, IC<0>{}, IC<1>{}, kt + 1, nothing);
+            ktile(IC<0>{}, IC<EX_TAIL>{}, IC<EX_TAIL>{}, IC<EX_TAIL>{}, IC<0>{}, 0, hide_next);
+            ktile(IC<1>{}, IC<EX_TAIL>{}, IC<0>{}, IC<0>{}, IC<0>{}, 1, nothing);
+            if constexpr (PF != 0) {
+                for (int kt = 2; kt < nk - 2; kt += 2) {  // nk is even; no stage of these k-tiles reaches past the tile
+                    ktile(IC<0>{}, IC<0>{}, IC<0>{}, IC<0>{}, IC<0>{}, kt, nothing);
+                    ktile(IC<1>{}, IC<0>{}, IC<0>{}, IC<0>{}, IC<0>{}, kt + 1, nothing);
+                }
+                if (nk >= 6) {   // the last two k-tiles stage the next tile's first two and prefetch this tile's residual rows
+                    ktile(IC<0>{}, IC<0>{}, IC<PF>{}, IC<PF>{}, IC<1>{}, nk - 2, prefetch_res);
+                    ktile(IC<1>{}, IC<PF>{}, IC<PF>{}, IC<0>{}, IC<1>{}, nk - 1, nothing);
+                }
+            } else {
+                for (int kt = 2; kt < nk; kt += 2) {  // nk is even; the last two k-tiles stage the next tile's first two
+                    ktile(IC<0>{}, IC<0>{}, IC<0>{}, IC<0>{}, IC<1>{}, kt, nothing);
+                    ktile(IC<1>{}, IC<0>{}, IC<0>{}, IC<0>{}, IC<1>{}, kt + 1, nothing);
+                }
             }
         } else {  // K = 128: the tile's only two k-tiles already stage the next tile - its rows have to be known up front
             set_tile(more ? nid : id, nm0, nn0, nbz, nA, nB);
-            ktile(IC<0>{}, IC<EX_TAIL>{}, IC<EX_TAIL>{}, IC<1>{}, 0, nothing);
-            ktile(IC<1>{}, IC<EX_TAIL>{}, IC<0>{}, IC<1>{}, 1, nothing);
+            ktile(IC<0>{}, IC<EX_TAIL>{}, IC<EX_TAIL>{}, IC<EX_TAIL>{}, IC<1>{}, 0, nothing);
+            ktile(IC<1>{}, IC<EX_TAIL>{}, IC<0>{}, IC<0>{}, IC<1>{}, 1, nothing);
         }
         if (wr == 0) PP_BARRIER();  // balance group 1's extra barrier: both groups run the epilogue side by side
 
@@ -854,7 +896,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
         gA[0] = nA[0], gA[1] = nA[1], gB[0] = nB[0], gB[1] = nB[1];
         if (p.bias && is_fast(m0, n0)) stage_bias(n0);
         if constexpr ((FUSE & 5) != 0) stage_ln(m0, n0, bz);
-        if (!fast) pad_tail();                          // generic epilogue: its store count depends on the tile's edges
+        if (!fast) pad_tail(IC<EX_TAIL>{});             // generic epilogue: its store count depends on the tile's edges
+        else if (FUSE == 0 && geglu) pad_tail(IC<(EX_TAIL > 8 ? EX_TAIL - 8 : 0)>{});   // unfused GEGLU tile: 8 stores
         derive_stage();
         derive_frag();
     }

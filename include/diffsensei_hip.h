@@ -42,8 +42,8 @@ int ds_device_info(int* cu_count, int* lds_bytes, char* arch_name, int arch_name
  *                        gemm_glds_kernel<64,false,3|4> | 1 never (A/B: profiles/r02_ring_in_pipeline_ab.txt)
  *   "conv_halo_variant"  0 auto (16x16-pixel blocks from 1024 blocks on) | 1 force conv_halo_kernel (8x16 pixels) |
  *                        2 force conv_halo256_kernel (16x16 pixels)
- *   "attn_variant"       0 auto (>= 1024 blocks of 256 query rows: the software-pipelined self_attn_sp_kernel; else 64 query
- *                        rows per wave from Nk >= 2048 and >= 512 blocks on) | 1 force self_attn_kernel<1> (32 rows per wave) |
+ *   "attn_variant"       0 auto (>= 128 blocks of 256 query rows: the software-pipelined self_attn_sp_kernel - every UNet shape
+ *                        at every batch; smaller grids: self_attn_kernel<1>) | 1 force self_attn_kernel<1> (32 rows per wave) |
  *                        2 force self_attn_kernel<2> (64 rows per wave) | 3 force self_attn_sp_kernel | 4 the same with the
  *                        plain block order instead of the per-XCD head grouping (A/B: profiles/r03_self_attn_sp.txt)
  *   "ip_attn_min_blocks" grid size below which ip_attn_kernel stops doubling its query tiles per block (default 1024)

@@ -543,24 +543,26 @@ def test_self_attention_64row_variant_forced(hip_lib, B, heads, N):
     assert torch.equal(out[1], out[2]), "64-row and 32-row flash kernels differ"
 
 
-def test_self_attention_64row_natural_dispatch(hip_lib):
-    """The benchmark's level-1 shape class (N = 4096, heads 10) at a batch that crosses the automatic threshold
-    (16 * B * heads >= 512 blocks): ds_self_attn_f16 picks `self_attn_kernel<2>` by itself."""
+def test_self_attention_natural_dispatch(hip_lib):
+    """What ds_self_attn_f16 picks by itself (round 5 rule: the software-pipelined kernel from 128 blocks of 256 query rows on,
+    i.e. for every UNet shape at every batch; the 32-row flash kernel below): a level-1 shape class at UNet batch 4 (640
+    blocks) must run `self_attn_sp_kernel` - same bits as attn_variant 3 -, a 16-block problem `self_attn_kernel<1>`."""
     from diffsensei_amd import _lib
     ops = _ops(hip_lib)
     lib = _lib.load()
-    B, heads, N = 4, 10, 4096
-    assert ((N + 255) // 256) * B * heads >= 512 and N >= 2048
-    g = torch.Generator().manual_seed(77)
-    q, k, vt, ref = _sdpa_case(g, B, heads, N)
-    auto = ops.self_attention(q, k, vt, heads)
-    try:
-        lib.ds_set_option(b"attn_variant", 1)
-        small = ops.self_attention(q, k, vt, heads)
-    finally:
-        lib.ds_set_option(b"attn_variant", 0)
-    _close(auto, ref, tol=3e-3, what="self-attn auto N=4096")
-    assert torch.equal(auto, small)
+    for (B, heads, N, forced) in ((4, 10, 4096, 3), (1, 4, 1024, 1)):
+        blocks = ((N + 255) // 256) * B * heads
+        assert (blocks >= 128) == (forced == 3)
+        g = torch.Generator().manual_seed(77 + N)
+        q, k, vt, ref = _sdpa_case(g, B, heads, N)
+        auto = ops.self_attention(q, k, vt, heads)
+        try:
+            lib.ds_set_option(b"attn_variant", forced)
+            same = ops.self_attention(q, k, vt, heads)
+        finally:
+            lib.ds_set_option(b"attn_variant", 0)
+        _close(auto, ref, tol=3e-3, what=f"self-attn auto N={N}")
+        assert torch.equal(auto, same), (B, heads, N)
 
 
 @pytest.mark.parametrize("B,heads,N", [(2, 2, 63), (1, 4, 99), (1, 2, 1001), (2, 1, 20), (1, 3, 2317)])
