@@ -25,6 +25,8 @@
 //
 // K order: channel slices outer, taps inner (k = tap*Cin + ci in the weight rows) - the sum is the same set of
 // products as the tap-major kernel's, in a different order, so results agree to fp32-accumulation rounding.
+#include <type_traits>
+
 #include "ds_common.h"
 #include "ds_kernels.h"
 
@@ -230,8 +232,13 @@ __global__ __launch_bounds__(256, 3) void conv_halo_kernel(const GemmParams p) {
             const int row = id >> 4, c = id & 15;
             V8 v = *reinterpret_cast<const V8*>(sC + row * CS_STRIDE + c * 16);
             if (Rp) {
+                // f16: one v_pk_add_f16 per two values - the same number as (f16)((float)a + (float)b), which never rounds twice
+                // (tests/test_f16_add_equivalence.py); bf16 (VAE decoder) keeps the f32 form
+                if constexpr (std::is_same<T, half_t>::value) v = v + rv[u];
+                else {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (T)((float)v[e] + (float)rv[u][e]);
+                    for (int e = 0; e < 8; ++e) v[e] = (T)((float)v[e] + (float)rv[u][e]);
+                }
             }
             if (ok[u]) *reinterpret_cast<V8*>(reinterpret_cast<T*>(p.C) + mrow[u] * p.ldc + ncol[u]) = v;
         }
@@ -298,20 +305,22 @@ __global__ __launch_bounds__(256, 2) void conv_halo256_kernel(const GemmParams p
         const int n = min(n0 + row, p.N - 1);
         woff[j] = n * (int)p.ldw + chunk * 8;
     }
+    // LDS-DMA from inline asm (`lds_dma16_v`, ds_common.h): behind the builtin the compiler turns every LDS wait of the kernel
+    // into lgkmcnt(0), and the fragment read-ahead of the k-loop below would wait for the reads it has just issued
+    const unsigned lds0 = (unsigned)(size_t)(lds_void*)smem;
     auto issue_patch = [&](int ci0) {
-        char* d = sP + wave * PPW2 * 1024;
+        const unsigned d = lds0 + wave * PPW2 * 1024;
 #pragma unroll
         for (int j = 0; j < PPW2; ++j) {
             if (wave * PPW2 + j >= NPIECE2) continue;  // wave-uniform: the last wave owns fewer pieces
             const void* src = poff[j] >= 0 ? (const void*)(p.A + poff[j] + ci0) : (const void*)g_halo_zero_page;
-            __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(d + j * 1024), 16, 0, 0);
+            lds_dma16_v(src, d + j * 1024);
         }
     };
     auto issue_w = [&](int k0, int buf) {
-        char* d = sW + buf * (BN * 128) + wave * 4 * 1024;
+        const unsigned d = lds0 + PBYTES2 + buf * (BN * 128) + wave * 4 * 1024;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            __builtin_amdgcn_global_load_lds((glb_void*)(p.W + k0 + woff[j]), (lds_void*)(d + j * 1024), 16, 0, 0);
+        for (int j = 0; j < 4; ++j) lds_dma16_v(p.W + k0 + woff[j], d + j * 1024);
     };
 
     char* const sC = smem;   // epilogue staging tile (over the patch / W buffers once the k-loop is done)
@@ -334,54 +343,91 @@ __global__ __launch_bounds__(256, 2) void conv_halo256_kernel(const GemmParams p
     #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+        // ---- k-loop (round 5).  The fragments of k-step kk + 1 are requested BEFORE the MFMAs of k-step kk (two register sets),
+        // so a read has 8 MFMAs (~260 cycles) to return; the k-tile's one barrier sits in front of its LAST k-step, where every
+        // fragment read of the tile has returned - the W buffer is then free for the k-tile after next, and the first fragments
+        // of the next k-tile load under the last 8 MFMAs of this one.  (Rounds 1-4: reads one or two MFMAs ahead of their use
+        // and, because the staging went through __builtin_amdgcn_global_load_lds, every wait an lgkmcnt(0): a fragment round
+        // trip exposed per four MFMAs.)
         const int slices = p.Cin / 64;
         const int nkt = slices * 9;
-        issue_patch(0);
-        issue_w(0, 0);
-        int s = 0, tap = 0;
-        for (int kt = 0; kt < nkt; ++kt) {
-            if (tap == 0 && kt > 0) {  // every wave is done with the previous slice's patch once it arrives here
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-                issue_patch(s * 64);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // W(kt) (and a new patch) have landed
-            __builtin_amdgcn_s_barrier();                      // ... everywhere; and buffer (kt+1)&1 has been drained
-            asm volatile("" ::: "memory");
-            if (kt + 1 < nkt) {
-                const int ntap = tap == 8 ? 0 : tap + 1, ns = tap == 8 ? s + 1 : s;
-                issue_w(ntap * p.Cin + ns * 64, (kt + 1) & 1);
-            }
-            const char* cW = sW + (kt & 1) * (BN * 128);
-            const int ky = tap / 3, kx = tap - 3 * ky;
+        auto set_abase = [&](int (&ab)[MI], int tp) {
+            const int ky = tp / 3, kx = tp - 3 * ky;
             const int shift = ky * HWD + kx;
-            int abase[MI];
     #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
                 const int q = q0[mi] + shift;
-                abase[mi] = q * 128 + ((lhi ^ (((rowswz ? q : (l31 & 15) + kx) >> 1) & 7)) << 4);
+                ab[mi] = q * 128 + ((lhi ^ (((rowswz ? q : (l31 & 15) + kx) >> 1) & 7)) << 4);
             }
+        };
+        auto load = [&](V8 (&af)[MI], V8 (&bf)[2], const int (&ab)[MI], const char* cw, int kk) {
     #pragma unroll
+            for (int mi = 0; mi < MI; ++mi) af[mi] = *reinterpret_cast<const V8*>(sP + (ab[mi] ^ (kk << 5)));
+    #pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const int r = cbase + ni * 32 + l31;
+                bf[ni] = *reinterpret_cast<const V8*>(cw + r * 128 + swz(r, kk * 2 + lhi));
+            }
+        };
+        auto mfmas = [&](const V8 (&af)[MI], const V8 (&bf)[2]) {
+    #pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+    #pragma unroll
+                for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = Elt<T>::mfma(bf[ni], af[mi], acc[mi][ni]);
+        };
+        auto landed_everywhere = [&]() {   // this wave's LDS-DMA pieces have landed, and so have everybody else's
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        };
+        auto w_k0 = [&](int tp, int sl) { return tp * p.Cin + sl * 64; };
+
+        issue_patch(0);
+        issue_w(0, 0);
+        landed_everywhere();
+        if (nkt > 1) issue_w(w_k0(1, 0), 1);
+        int s = 0, tap = 0;
+        int abase[MI];
+        set_abase(abase, 0);
+        const char* cW = sW;
+        V8 af[2][MI], bf[2][2];
+        load(af[0], bf[0], abase, cW, 0);
+        for (int kt = 0; kt + 1 < nkt; ++kt) {   // (the last k-tile is peeled: no conditional between the next tile's reads and
+    #pragma unroll                              //  the MFMAs, so the compiler keeps its LDS waits counted there too)
             for (int kk = 0; kk < 4; ++kk) {
-                V8 af[MI], bf[2];
-    #pragma unroll
-                for (int mi = 0; mi < MI; ++mi) af[mi] = *reinterpret_cast<const V8*>(sP + (abase[mi] ^ (kk << 5)));
-    #pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                    const int r = cbase + ni * 32 + l31;
-                    bf[ni] = *reinterpret_cast<const V8*>(cW + r * 128 + swz(r, kk * 2 + lhi));
+                if (kk < 3) {
+                    load(af[(kk + 1) & 1], bf[(kk + 1) & 1], abase, cW, kk + 1);
+                } else {
+                    const int ntap = tap == 8 ? 0 : tap + 1, ns = tap == 8 ? s + 1 : s;
+                    const int ntap2 = ntap == 8 ? 0 : ntap + 1, ns2 = ntap == 8 ? ns + 1 : ns;
+                    // every fragment read of this k-tile has returned (the last ones were requested a k-step ago)
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (ntap == 0) {
+                        // new channel slice: the single patch buffer is free once every wave is here (the co-resident block
+                        // computes while this one waits for the refill)
+                        __builtin_amdgcn_s_barrier();
+                        asm volatile("" ::: "memory");
+                        issue_patch(ns * 64);
+                    }
+                    landed_everywhere();                           // W(kt + 1) (and a new patch); nobody reads buffer kt & 1 any more
+                    if (kt + 2 < nkt) issue_w(w_k0(ntap2, ns2), kt & 1);
+                    tap = ntap;
+                    s = ns;
+                    cW = sW + ((kt + 1) & 1) * (BN * 128);
+                    set_abase(abase, tap);
+                    load(af[0], bf[0], abase, cW, 0);
                 }
-    #pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
-    #pragma unroll
-                    for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = Elt<T>::mfma(bf[ni], af[mi], acc[mi][ni]);
+                __builtin_amdgcn_sched_barrier(0);   // the reads go out FIRST: left alone the scheduler sinks them between the MFMAs
+                mfmas(af[kk & 1], bf[kk & 1]);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            if (tap == 8) {
-                tap = 0;
-                ++s;
-            } else {
-                ++tap;
-            }
+        }
+    #pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            if (kk < 3) load(af[(kk + 1) & 1], bf[(kk + 1) & 1], abase, cW, kk + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(af[kk & 1], bf[kk & 1]);
+            __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
 
@@ -455,8 +501,13 @@ __global__ __launch_bounds__(256, 2) void conv_halo256_kernel(const GemmParams p
             const int row = id >> 4, c = id & 15;
             V8 v = *reinterpret_cast<const V8*>(sC + row * CS_STRIDE + c * 16);
             if (Rp) {
+                // f16: one v_pk_add_f16 per two values - the same number as (f16)((float)a + (float)b), which never rounds twice
+                // (tests/test_f16_add_equivalence.py); bf16 (VAE decoder) keeps the f32 form
+                if constexpr (std::is_same<T, half_t>::value) v = v + rv[u];
+                else {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (T)((float)v[e] + (float)rv[u][e]);
+                    for (int e = 0; e < 8; ++e) v[e] = (T)((float)v[e] + (float)rv[u][e]);
+                }
             }
             if (ok[u]) *reinterpret_cast<V8*>(reinterpret_cast<T*>(p.C) + mrow[u] * p.ldc + ncol[u]) = v;
         }

@@ -182,6 +182,11 @@ __device__ __forceinline__ void lds_dma16(const void* base, unsigned byte_off, u
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(byte_off), "s"(base), "s"(lds_addr) : "memory", "m0");
 }
 
+// the same with a per-lane 64-bit global address (the halo-patch pieces: image rows for some lanes, the zero page for others)
+__device__ __forceinline__ void lds_dma16_v(const void* lane_ptr, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(lane_ptr), "s"(lds_addr) : "memory", "m0");
+}
+
 __device__ __forceinline__ void tile_coords(int id, int tiles_m, int tiles_n, int& tm, int& tn) {
     constexpr int GROUP = 8;
     const int per_group = GROUP * tiles_n;

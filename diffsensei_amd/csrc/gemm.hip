@@ -317,8 +317,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x16 (&acc)[WR /
                     }
                     if (Rg) {
                         const h8 rv = rvs[j];
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rv[e]);
+                        v = v + rv;   // v_pk_add_f16: the same number as (f16)((float)a + (float)b) (tests/test_f16_add_equivalence.py)
                     }
                     *reinterpret_cast<h8*>(Cg + (long)m * p.ldc + n) = v;
                     if constexpr (LNF) {

@@ -70,12 +70,14 @@ constexpr int HT = 16384;  // bytes of one half-tile: 128 rows x 64 k of f16
 // depends on the tile's edges.  The counted waits of the first k-tiles leave exactly this many outstanding: more issued
 // than counted only waits longer, fewer would under-wait.
 #ifndef PP_EX
-#define PP_EX 8
+#define PP_EX 16
 #endif
-#ifndef PP_RES_PF
-#define PP_RES_PF 0
-#endif
-constexpr int EX_MAX = PP_EX;   // build-time A/B (round 5): 16 = every C store of a plain tile may stay in flight under the next tile
+// How many of a tile's trailing vector-memory instructions - its C stores - may still be in flight when the next tile's first
+// k-tiles run.  16 = every store of a plain tile (round 5; 8 until round 4: the first half of a tile's stores had to be
+// acknowledged before the next tile's first MFMA, and the whole chip writes its tiles in the same microseconds).  Build-time
+// A/B (-DPP_EX=8, tools/build_variants.py), batch-64 forward, same box: gemm_pp_kernel 258.6 -> 257.4 ms
+// (profiles/r05_pp_ex16_pf_ab.txt).
+constexpr int EX_MAX = PP_EX;
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
@@ -119,11 +121,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     typedef typename Elt<T>::v4 V4;
     // the fused GEGLU epilogue issues 8 stores + the bias piece + 2 LayerNorm pieces per tile: its count is capped at 11
     constexpr int EX_TAIL = (FUSE == 9 && EX_MAX > 11) ? 11 : EX_MAX;
-    // residual prefetch (PP_RES_PF, round 5): the LayerNorm producer - the +residual projections of the transformer blocks.  (The
-    // plain instantiation carries residuals too - the 640-channel level - but sits at 255 registers: with the last k-tile pair
-    // peeled out of its loop four of them went to scratch across the k-loop, and a scratch reload is a vmcnt round trip behind
-    // all the staging in flight.)
-    constexpr int PF = (PP_RES_PF != 0 && FUSE == 2) ? 2 : 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int wr = wave >> 2, wc = wave & 3;
@@ -475,41 +472,15 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
                 asm volatile("" : "+s"(nB[0]), "+s"(nB[1]));
             }
         };
-        // ---- residual prefetch (build-time switch PP_RES_PF): the tile's residual rows (one 128-byte line per row and wave: two
-        // 4-byte-per-lane LDS-DMA pieces into the idle KiB of `ep`, no register, no wait) are pulled into L2 two k-tiles before the
-        // epilogue asks for them.  Without it every +residual tile waits for its 128 KiB straight from HBM - and the whole chip
-        // asks in the same microsecond (32 MiB per round: ~6 us at HBM rate, measured as the difference between the +residual and
-        // the plain shapes' tile boundary, profiles/r05_pp_seamless_ab.txt).  Two more vector-memory instructions in flight behind
-        // A1(nk-1): the five counted waits that follow allow for them (PF).
-        auto prefetch_res = [&](auto ph) {
-            if constexpr (decltype(ph)::value == 1 && PF != 0) {
-                const int ln = lane_id();
-                const bool on = p.residual != nullptr && is_fast(m0, n0);
-                const char* const r0 = on ? reinterpret_cast<const char*>(p.residual + (long)bz * p.sR + (long)(m0 + wr * 64) * p.ldr + n0 + wc * 64)
-                                          : reinterpret_cast<const char*>(gA[0]);
-                const unsigned lo = on ? (unsigned)(ln * (int)p.ldr) * 2u : oA[0];
-                const size_t half = on ? (size_t)p.ldr * 256 : 0;   // rows 128.. of the tile
-                __builtin_amdgcn_global_load_lds((glb_void*)(r0 + (size_t)lo), (lds_void*)(ep + 3072), 4, 0, 0);
-                __builtin_amdgcn_global_load_lds((glb_void*)(r0 + half + (size_t)lo), (lds_void*)(ep + 3072 + 256), 4, 0, 0);
-            }
-        };
+        // (Measured and not kept, round 5: pulling the tile's residual rows into L2 two k-tiles ahead of the epilogue with two
+        // 4-byte-per-lane LDS-DMA pieces per wave - the +residual shapes did not move, 83.6 vs 81.9 ms per forward,
+        // profiles/r05_pp_ex16_pf_ab.txt: their longer tile boundary is the residual ADD's instructions, not the rows' latency.)
         if (nk >= 4) {
             ktile(IC<0>{}, IC<EX_TAIL>{}, IC<EX_TAIL>{}, IC<EX_TAIL>{}, IC<0>{}, 0, hide_next);
             ktile(IC<1>{}, IC<EX_TAIL>{}, IC<0>{}, IC<0>{}, IC<0>{}, 1, nothing);
-            if constexpr (PF != 0) {
-                for (int kt = 2; kt < nk - 2; kt += 2) {  // nk is even; no stage of these k-tiles reaches past the tile
-                    ktile(IC<0>{}, IC<0>{}, IC<0>{}, IC<0>{}, IC<0>{}, kt, nothing);
-                    ktile(IC<1>{}, IC<0>{}, IC<0>{}, IC<0>{}, IC<0>{}, kt + 1, nothing);
-                }
-                if (nk >= 6) {   // the last two k-tiles stage the next tile's first two and prefetch this tile's residual rows
-                    ktile(IC<0>{}, IC<0>{}, IC<PF>{}, IC<PF>{}, IC<1>{}, nk - 2, prefetch_res);
-                    ktile(IC<1>{}, IC<PF>{}, IC<PF>{}, IC<0>{}, IC<1>{}, nk - 1, nothing);
-                }
-            } else {
-                for (int kt = 2; kt < nk; kt += 2) {  // nk is even; the last two k-tiles stage the next tile's first two
-                    ktile(IC<0>{}, IC<0>{}, IC<0>{}, IC<0>{}, IC<1>{}, kt, nothing);
-                    ktile(IC<1>{}, IC<0>{}, IC<0>{}, IC<0>{}, IC<1>{}, kt + 1, nothing);
-                }
+            for (int kt = 2; kt < nk; kt += 2) {  // nk is even; the last two k-tiles stage the next tile's first two
+                ktile(IC<0>{}, IC<0>{}, IC<0>{}, IC<0>{}, IC<1>{}, kt, nothing);
+                ktile(IC<1>{}, IC<0>{}, IC<0>{}, IC<0>{}, IC<1>{}, kt + 1, nothing);
             }
         } else {  // K = 128: the tile's only two k-tiles already stage the next tile - its rows have to be known up front
             set_tile(more ? nid : id, nm0, nn0, nbz, nA, nB);
@@ -728,20 +699,31 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
                         const int row = i * 8 + (lane_e >> 3), ch = lane_e & 7;
                         v[i] = *reinterpret_cast<const V8*>(ep + row * 128 + (((ch ^ (row >> 1)) & 7) << 4));
                         if constexpr (RES) {
+                            // f16 + f16, rounded once: v_pk_add_f16, four instructions per 8 values.  Until round 4 this was
+                            // (T)((float)a + (float)b) - 24 instructions - which is the SAME number: the f32 sum of two f16 values
+                            // is exact unless their exponents are >= 13 apart, and then the small one is far below the large
+                            // one's half-ulp: no double rounding (checked for all 4.0e9 pairs of finite f16,
+                            // tests/test_f16_add_equivalence.py).  bf16 (VAE) keeps the f32 form.
+                            if constexpr (std::is_same<T, half_t>::value) v[i] = v[i] + rv[i];
+                            else {
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) v[i][e] = (T)((float)v[i][e] + (float)rv[i][e]);
+                                for (int e = 0; e < 8; ++e) v[i][e] = (T)((float)v[i][e] + (float)rv[i][e]);
+                            }
                         }
                         // Fused LayerNorm (producer): (sum, sum of squares) of the 64 values this wave stores per row.  Row
-                        // i * 8 + (lane >> 3) of the piece is spread over the 8 lanes lane & 7: butterfly over them with DPP
+                        // i * 8 + (lane >> 3) of the piece is spread over the 8 lanes lane & 7: per lane two dot instructions per
+                        // f16 pair (v_dot2c_f32_f16: x . (1, 1) and x . x, f32 accumulate; round 4 converted, added and fma'd
+                        // value by value: 24 instructions per 8 values instead of 8), then a butterfly over the 8 lanes with DPP
                         // (quad_perm xor 1, xor 2, then row_half_mirror pairs lane j with 7 - j), after which lane & 7 == i
                         // keeps row group i: one 8-byte store per row from 32 lanes, 256 contiguous bytes per piece.
                         if constexpr ((FUSE & 2) != 0) {
+                            typedef _Float16 h2v __attribute__((ext_vector_type(2)));
                             float s1 = 0.f, q1 = 0.f;
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) {
-                                const float f = (float)v[i][e];
-                                s1 += f;
-                                q1 = fmaf(f, f, q1);
+                            for (int e = 0; e < 8; e += 2) {
+                                const h2v pr = {v[i][e], v[i][e + 1]};
+                                s1 = __builtin_amdgcn_fdot2(pr, h2v{(_Float16)1.f, (_Float16)1.f}, s1, false);
+                                q1 = __builtin_amdgcn_fdot2(pr, pr, q1, false);
                             }
                             s1 += dpp_f32<0xB1>(s1);
                             q1 += dpp_f32<0xB1>(q1);
@@ -879,8 +861,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
                         }
                         if (Rg) {
                             const V8 rv = *reinterpret_cast<const V8*>(Rg + (long)m * p.ldr + n);
+                            if constexpr (std::is_same<T, half_t>::value) v = v + rv;
+                            else {
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) v[e] = (T)((float)v[e] + (float)rv[e]);
+                                for (int e = 0; e < 8; ++e) v[e] = (T)((float)v[e] + (float)rv[e]);
+                            }
                         }
                         *reinterpret_cast<V8*>(Cg + (long)m * p.ldc + n) = v;
                     }
