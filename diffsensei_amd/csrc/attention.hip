@@ -690,7 +690,6 @@ int ds_launch_self_attn(const SelfAttnParams& p, hipStream_t stream) {
         case 2: {
             SelfAttnParams q = p;
             q.xcd_map = g_attn_variant == 4 ? 0 : 1;   // 4: A/B only - the plain block order
-            if (g_attn_variant >= 5) q.xcd_map |= (g_attn_variant - 4) << 1;   // 5..7: A/B only - second co-resident block 1..3 sleeps late
             return ds_launch_self_attn_sp(q, stream);
         }
         case 1: hipLaunchKernelGGL(self_attn_kernel<2>, dim3((p.Nq + 255) / 256, p.B * p.heads), dim3(256), 0, stream, p); break;

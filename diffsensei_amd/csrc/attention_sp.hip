@@ -77,13 +77,8 @@ __global__ __launch_bounds__(256, 2) void self_attn_sp_kernel(const SelfAttnPara
     // query blocks of one head were spread over all eight XCDs and every one of them pulled that head's K / V^T through its own
     // L2: 2.85 GB of fabric reads per launch for 0.17 GB of K + V (PMC, profiles/r03_pmc_conv_attn_ip_summary.txt).  The 1-D
     // grid is remapped so that an XCD owns a contiguous run of work items = all query blocks of a few heads, back to back.
-    // A/B (attn_variant 5..7): the second block of every CU of the first generation starts late, so that the two co-resident
-    // blocks - same work, same instruction stream, started together - do not meet at every SP_SYNC (conv_halo.hip has the story)
-    if ((p.xcd_map >> 1) != 0 && blockIdx.x >= 256 && blockIdx.x < 512) {
-        for (int u = 0; u < (p.xcd_map >> 1); ++u) __builtin_amdgcn_s_sleep(40);
-    }
     const int nqb = (p.Nq + 255) / 256;
-    const int item = (p.xcd_map & 1) ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+    const int item = p.xcd_map ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
     const int bh = item / nqb, qblk = item - bh * nqb;
     const int b = bh / p.heads, h = bh % p.heads;
     const int q0 = qblk * 256 + wave * 64;

@@ -63,7 +63,7 @@ int ds_set_option(const char* key, int value) {
         return 0;
     }
     if (strcmp(key, "attn_variant") == 0) {
-        DS_REQUIRE(value >= 0 && value <= 7, "attn_variant must be 0..7");
+        DS_REQUIRE(value >= 0 && value <= 4, "attn_variant must be 0..4");
         ds_attn_set_variant(value);
         return 0;
     }

@@ -279,18 +279,6 @@ __global__ __launch_bounds__(256, 2) void conv_halo256_kernel(const GemmParams p
     const int lrow = lane >> 3, slot = lane & 7;
     const bool rowswz = (p.debug & 1024) != 0;  // A/B only: the row-index patch swizzle (2-way bank conflicts on every A read)
 
-    // De-phase the two blocks that share a CU (round 5).  Both start together, run the same instruction stream on the same amount
-    // of work and so reach every channel-slice boundary - barrier, 44 KiB patch refill from HBM, barrier: ~2 us with nothing to
-    // compute - at the same time, generation after generation (they also finish together, so their successors start together):
-    // the "co-resident block computes while this one waits" of the design never happened.  The second block of every CU of the
-    // FIRST generation (the dispatcher fills all CUs once before it doubles up: blocks 256 .. 511) therefore starts a fraction of
-    // a slice late; later generations inherit the offset.  gemm_debug bits 12-13: the delay in units of s_sleep 127 (A/B).
-    {
-        const int units = (p.debug >> 12) & 3;
-        if (blockIdx.x >= 256 && blockIdx.x < 512) {
-            for (int u = 0; u < units; ++u) __builtin_amdgcn_s_sleep(127);
-        }
-    }
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     int tm, tn;
     tile_coords(tile, p.tiles_m, p.tiles_n, tm, tn);

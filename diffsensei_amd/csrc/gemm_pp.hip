@@ -419,11 +419,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 
     int id = tile_local;
     if (id >= ntiles) return;
-    // A/B (gemm_debug bit 14): stagger the blocks' start so that the 256 CUs - same work, same schedule - do not all reach their
-    // tile boundaries (stores, residual reads, idle matrix pipes) in the same microsecond: 8 phases, 4096 cycles apart
-    if ((p.debug & 16384) != 0) {
-        for (int u = 0; u < (int)(blockIdx.x & 7); ++u) __builtin_amdgcn_s_sleep(64);
-    }
     unsigned long long probe_c0 = 0, probe_r0 = 0;
     if constexpr ((DBG & 16) != 0) {  // clock probe: shader cycles vs the constant 100 MHz reference
         probe_c0 = __builtin_readcyclecounter();
