@@ -372,8 +372,9 @@ def main():
     ap.add_argument("--refs", type=int, default=2, choices=(0, 1, 2, 3, 4),
                     help="character references in the request (BASELINE config 2: 1, config 5: 4)")
     ap.add_argument("--attn", choices=("fp16", "fp8"), default="fp16",
-                    help="self-attention arithmetic: fp16 (the reference's; the metric line) or fp8 = OCP e4m3 on the MX matrix "
-                         "instruction (BASELINE config 5: --size 2048 --refs 4 --attn fp8 --num-samples 1)")
+                    help="self-attention arithmetic: fp16 (the reference's; the metric line and, since round 5, BASELINE config 5 too) or "
+                         "fp8 = OCP e4m3 on the MX matrix instruction - measured, NOT adopted (BASELINE.md section 5: 5.4e-2 per op for no "
+                         "end-to-end gain over the round-5 fp16 kernel); kept as an opt-in A/B: --size 2048 --refs 4 --attn fp8 --num-samples 1")
     ap.add_argument("--no-dialog", action="store_true", help="no dialog boxes (BASELINE config 2)")
     ap.add_argument("--no-parity", action="store_true", help="skip the GPU-vs-oracle parity run on BASELINE configs[0]")
     ap.add_argument("--cpu-full", action="store_true",
@@ -486,7 +487,7 @@ def main():
                                           for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}
         # HBM-side traffic comes from separate rocprofv3 --pmc passes (tools/gpu_pmc_pp.sh), committed under profiles/:
         # it cannot be collected inside this process.  Attached only when it was measured for this very kernel.
-        for pmc_name in ("r04_pmc_gemm_pp.json", "r03_pmc_gemm_pp.json", "r02_pmc_gemm_pp.json", "r01_pmc_gemm_pp.json"):   # newest committed pass for this kernel
+        for pmc_name in ("r05_pmc_gemm_pp.json", "r04_pmc_gemm_pp.json", "r03_pmc_gemm_pp.json", "r02_pmc_gemm_pp.json", "r01_pmc_gemm_pp.json"):   # newest committed pass for this kernel
             pmc_path = os.path.join(ROOT, "profiles", pmc_name)
             if not os.path.exists(pmc_path):
                 continue

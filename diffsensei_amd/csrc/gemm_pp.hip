@@ -105,10 +105,16 @@ __device__ __forceinline__ float dpp_f32(float v) {
         PP_FENCE();                              \
     } while (0)
 
+// PP_STATIC_PRIO (build-time A/B, round 5; MI355X_MICROARCH.md "static priority for the younger half"): no per-cluster flips,
+// waves 4..7 - dispatched second, the arbitration losers of every phase - run at priority 1 for the whole kernel
+#ifdef PP_STATIC_PRIO
+#define PP_PRIO(v) do { } while (0)
+#else
 #define PP_PRIO(v)                                              \
     do {                                                        \
         if constexpr ((DBG & 8) == 0) __builtin_amdgcn_s_setprio(v); \
     } while (0)
+#endif
 
 // FUSE (fused LayerNorm, see the header): 0 none - the instantiation every other GEMM runs, its code is untouched by the
 // feature; 1 consumer with the plain epilogue, 9 consumer with the GEGLU epilogue (statistics + c pieces, one extra MFMA per
@@ -419,6 +425,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 
     int id = tile_local;
     if (id >= ntiles) return;
+#ifdef PP_STATIC_PRIO
+    if (wr == 1) __builtin_amdgcn_s_setprio(1);
+#endif
     unsigned long long probe_c0 = 0, probe_r0 = 0;
     if constexpr ((DBG & 16) != 0) {  // clock probe: shader cycles vs the constant 100 MHz reference
         probe_c0 = __builtin_readcyclecounter();
