@@ -45,11 +45,6 @@ __device__ __attribute__((aligned(256))) char g_halo_zero_page[256];
 
 __device__ __forceinline__ int swz(int row, int chunk) { return ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-template <int V>
-struct IC {
-    static constexpr int value = V;
-};
-
 template <typename T>  // half_t (UNet) or bf16_t (VAE decoder)
 __global__ __launch_bounds__(256, 3) void conv_halo_kernel(const GemmParams p) {
     typedef typename Elt<T>::v8 V8;
@@ -95,8 +90,7 @@ __global__ __launch_bounds__(256, 3) void conv_halo_kernel(const GemmParams p) {
         char* d = sP + wave * 6 * 1024;
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
-            const int po = poff[j];
-            const void* src = po >= 0 ? (const void*)(p.A + po + ci0) : (const void*)g_halo_zero_page;
+            const void* src = poff[j] >= 0 ? (const void*)(p.A + poff[j] + ci0) : (const void*)g_halo_zero_page;
             __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(d + j * 1024), 16, 0, 0);
         }
     };
@@ -107,124 +101,113 @@ __global__ __launch_bounds__(256, 3) void conv_halo_kernel(const GemmParams p) {
             __builtin_amdgcn_global_load_lds((glb_void*)(p.W + k0 + woff[j]), (lds_void*)(d + j * 1024), 16, 0, 0);
     };
 
-    char* const sC = smem;
-    auto body = [&](auto tailc) {
-        // TAIL (as in conv_halo256_kernel below): the block's channel tile has at most 64 valid columns (Cout = 320: every third
-        // tile; Cout = 64).  The four waves then split the 128 pixels four ways over ONE 64-column strip (wave tile 32 x 64, 8 MFMAs
-        // per tap instead of 16) instead of two of them computing 64 columns nobody stores: half a tile's work, bit-identical values.
-        constexpr bool TAIL = decltype(tailc)::value != 0;
-        constexpr int MI = TAIL ? 1 : 2;
-        const int rbase = TAIL ? wave * 32 : wm * 64, cbase = TAIL ? 0 : wn * 64;
-        // ---- A fragment rows: GEMM row r = rbase + 32 mi + l31  <->  patch pixel (r >> 4, r & 15), tap (0,0) at q0
-        int q0[MI];
+    // ---- A fragment rows: GEMM row r = 64 wm + 32 mi + l31  <->  patch pixel (r >> 4, r & 15), tap (0,0) at q0
+    int q0[2];
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) q0[mi] = ((rbase >> 4) + mi * 2 + (l31 >> 4)) * HWD + (l31 & 15);
+    for (int mi = 0; mi < 2; ++mi) q0[mi] = (wm * 4 + mi * 2 + (l31 >> 4)) * HWD + (l31 & 15);
 
-        f32x16 acc[MI][2];
+    f32x16 acc[2][2];
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-        const int slices = p.Cin / 64;
-        issue_patch(0);
-        issue_w(0);
-        for (int s = 0; s < slices; ++s) {
+    const int slices = p.Cin / 64;
+    issue_patch(0);
+    issue_w(0);
+    for (int s = 0; s < slices; ++s) {
 #pragma unroll 1
-            for (int tap = 0; tap < 9; ++tap) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int tap = 0; tap < 9; ++tap) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            const int shift = ky * HWD + kx;
+            V8 af[4][2], bf[4][2];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const int q = q0[mi] + shift;
+                const int base = q * 128 + ((lhi ^ (((rowswz ? q : (l31 & 15) + kx) >> 1) & 7)) << 4);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) af[kk][mi] = *reinterpret_cast<const V8*>(sP + (base ^ (kk << 5)));
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const int r = wn * 64 + ni * 32 + l31;
+                    bf[kk][ni] = *reinterpret_cast<const V8*>(sW + r * 128 + swz(r, kk * 2 + lhi));
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const bool last = (s + 1 == slices) & (tap == 8);
+            if (!last) {  // the W buffer (and after tap 8 the patch) is drained once everyone holds its fragments
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
-                const int ky = tap / 3, kx = tap - 3 * ky;
-                const int shift = ky * HWD + kx;
-                V8 af[4][MI], bf[4][2];
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi) {
-                    const int q = q0[mi] + shift;
-                    const int base = q * 128 + ((lhi ^ (((rowswz ? q : (l31 & 15) + kx) >> 1) & 7)) << 4);
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) af[kk][mi] = *reinterpret_cast<const V8*>(sP + (base ^ (kk << 5)));
+                if (tap == 8) {
+                    issue_patch((s + 1) * 64);
+                    issue_w((s + 1) * 64);
+                } else {
+                    issue_w((tap + 1) * p.Cin + s * 64);
                 }
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                    for (int ni = 0; ni < 2; ++ni) {
-                        const int r = cbase + ni * 32 + l31;
-                        bf[kk][ni] = *reinterpret_cast<const V8*>(sW + r * 128 + swz(r, kk * 2 + lhi));
-                    }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                const bool last = (s + 1 == slices) & (tap == 8);
-                if (!last) {  // the W buffer (and after tap 8 the patch) is drained once everyone holds its fragments
-                    __builtin_amdgcn_s_barrier();
-                    asm volatile("" ::: "memory");
-                    if (tap == 8) {
-                        issue_patch((s + 1) * 64);
-                        issue_w((s + 1) * 64);
-                    } else {
-                        issue_w((tap + 1) * p.Cin + s * 64);
-                    }
-                }
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                        for (int ni = 0; ni < 2; ++ni)
-                            acc[mi][ni] = Elt<T>::mfma(bf[kk][ni], af[kk][mi], acc[mi][ni]);
             }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+                        acc[mi][ni] = Elt<T>::mfma(bf[kk][ni], af[kk][mi], acc[mi][ni]);
         }
-        __syncthreads();
+    }
+    __syncthreads();
 
-        // ---- epilogue: bias (+ per-image bias), round to f16, park the 128 x 128 tile in LDS, then whole 16-byte pieces
-        // of output rows (+ residual).  D layout (operands swapped): lane holds row ..+(lane&31); register r is column
-        // (r&3) + 8*(r>>2) + 4*(lane>>5) of its 32-column fragment.
-        // (no branch / s_waitcnt per 4 values: biases fetched once with clamped addresses, residual pieces requested in
-        // batches of four before they are needed - see conv_halo256_kernel)
-        V4 b0[2][4], b1[2][4];
+    // ---- epilogue: bias (+ per-image bias), round to f16, park the 128 x 128 tile in LDS, then whole 16-byte pieces
+    // of output rows (+ residual).  D layout (operands swapped): lane holds row ..+(lane&31); register r is column
+    // (r&3) + 8*(r>>2) + 4*(lane>>5) of its 32-column fragment.
+    // (no branch / s_waitcnt per 4 values: biases fetched once with clamped addresses, residual pieces requested in
+    // batches of four before they are needed - see conv_halo256_kernel)
+    char* const sC = smem;
+    V4 b0[2][4], b1[2][4];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) b0[ni][g] = b1[ni][g] = V4{0, 0, 0, 0};
+    if (p.bias) {
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) b0[ni][g] = b1[ni][g] = V4{0, 0, 0, 0};
-        if (p.bias) {
+            for (int g = 0; g < 4; ++g)
+                b0[ni][g] = *reinterpret_cast<const V4*>(p.bias + min(n0 + wn * 64 + ni * 32 + 8 * g + 4 * lhi, p.N - 4));
+    }
+    if (p.rowbias) {
+        const half_t* rb = p.rowbias + (long)b * p.rowbias_ld;
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
+        for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    b0[ni][g] = *reinterpret_cast<const V4*>(p.bias + min(n0 + cbase + ni * 32 + 8 * g + 4 * lhi, p.N - 4));
-        }
-        if (p.rowbias) {
-            const half_t* rb = p.rowbias + (long)b * p.rowbias_ld;
+            for (int g = 0; g < 4; ++g)
+                b1[ni][g] = *reinterpret_cast<const V4*>(rb + min(n0 + wn * 64 + ni * 32 + 8 * g + 4 * lhi, p.N - 4));
+    }
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
+    for (int mi = 0; mi < 2; ++mi) {
+        const int ms = wm * 64 + mi * 32 + l31;
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    b1[ni][g] = *reinterpret_cast<const V4*>(rb + min(n0 + cbase + ni * 32 + 8 * g + 4 * lhi, p.N - 4));
-        }
+        for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            const int ms = rbase + mi * 32 + l31;
+            for (int g = 0; g < 4; ++g) {
+                const int nl = wn * 64 + ni * 32 + 8 * g + 4 * lhi;
+                V4 o;
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int nl = cbase + ni * 32 + 8 * g + 4 * lhi;
-                    V4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float v = acc[mi][ni][4 * g + e];
-                        v += (float)b0[ni][g][e];
-                        v += (float)b1[ni][g][e];
-                        o[e] = (T)v;
-                    }
-                    *reinterpret_cast<V4*>(sC + ms * CS_STRIDE + nl * 2) = o;
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[mi][ni][4 * g + e];
+                    v += (float)b0[ni][g][e];
+                    v += (float)b1[ni][g][e];
+                    o[e] = (T)v;
                 }
-        }
-    };
-    // gemm_debug bit 12 (4096): A/B, tail tiles as full tiles (bit 11 is the same switch of conv_halo256_kernel)
-    if (p.N - n0 <= 64 && (p.debug & 4096) == 0) body(IC<1>{});
-    else body(IC<0>{});
+                *reinterpret_cast<V4*>(sC + ms * CS_STRIDE + nl * 2) = o;
+            }
+    }
     __syncthreads();
     const T* const Rp = reinterpret_cast<const T*>(p.residual);
 #pragma unroll 1

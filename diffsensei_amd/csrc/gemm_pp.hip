@@ -105,9 +105,13 @@ __device__ __forceinline__ float dpp_f32(float v) {
         PP_FENCE();                              \
     } while (0)
 
-// PP_STATIC_PRIO (build-time A/B, round 5; MI355X_MICROARCH.md "static priority for the younger half"): no per-cluster flips,
-// waves 4..7 - dispatched second, the arbitration losers of every phase - run at priority 1 for the whole kernel
-#ifdef PP_STATIC_PRIO
+// Static priority (round 5; MI355X_MICROARCH.md, "static priority for the younger half"): waves 4..7 - dispatched second, the
+// arbitration losers of every phase - run at priority 1 for the whole kernel, and nobody flips s_setprio around its MFMA
+// clusters any more (rounds 1-4: s_setprio 1 / 0 around every cluster of every wave).  Build-time A/B, batch-64 forward, two
+// interleaved rounds on one box: every instantiation -0.6...-0.9 %, forward 442.6 -> 440.9 ms, same bits
+// (profiles/r05_pp_static_prio_ab.txt).  -DPP_PER_CLUSTER_PRIO restores the flips.
+#ifndef PP_PER_CLUSTER_PRIO
+#define PP_STATIC_PRIO 1
 #define PP_PRIO(v) do { } while (0)
 #else
 #define PP_PRIO(v)                                              \

@@ -21,6 +21,20 @@ if i >= 0:
     print("  forward", obj["unet_forward_ms_event_sum"], "ms")
 PY
 }
+timeout 600 python -m pytest tests/test_gpu_ops.py tests/test_gpu_ln_fusion.py -q -m gpu -p no:cacheprovider -k "gemm or ln or fused or conv" > "$out/f3_pytest_gemm_conv.log" 2>&1
+echo "pytest gemm+conv rc=$?"; tail -2 "$out/f3_pytest_gemm_conv.log"
+# ---- the bench line of the final tree and the rocprofv3 kernel trace of the same workload on the same box (graph replay off)
+timeout 900 python bench.py --steps 3 --warmup 1 > "$out/r05_bench_default_ns32_final.json" 2> "$out/r05_bench_default_ns32_final.err"
+echo "bench rc=$? $(python -c "import json;d=json.load(open('$out/r05_bench_default_ns32_final.json'));print(d['value'], d['roofline']['frac'], d['roofline']['avg_launch_us'])")"; perk "$out/r05_bench_default_ns32_final.err" "$out/r05_bench_default_ns32_final_per_kernel.json"
+cd /tmp
+DIFFSENSEI_GRAPH=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof_r05" -o bench_ns32_eager -- \
+    python "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > "$out/r05_prof_bench.json" 2> "$out/r05_prof_bench.err"
+echo "rocprof rc=$?"
+cd "$R"
+f=$(find "$out/prof_r05" -name "*kernel_stats.csv" | head -1)
+mkdir -p "$out/r05_rocprof_kernel_stats"
+[[ -n "$f" ]] && cp "$f" "$out/r05_rocprof_kernel_stats/bench_ns32_eager_kernel_stats_final.csv" && head -14 "$f" | cut -c1-220
+rm -rf "$out/prof_r05"
 timeout 600 python bench.py --steps 3 --warmup 1 --num-samples 1 --refs 1 --no-dialog --no-cpu-baseline > "$out/r05_bench_c2_ns1_1ref_final.json" 2> "$out/c2.err"
 echo "c2 rc=$? $(python -c "import json;print(json.load(open('$out/r05_bench_c2_ns1_1ref_final.json'))['value'])")"; perk "$out/c2.err" "$out/r05_bench_c2_ns1_1ref_final_per_kernel.json"
 timeout 900 python bench.py --steps 3 --warmup 1 --mllm --num-samples 4 --no-cpu-baseline > "$out/r05_bench_c3_mllm_ns4_final.json" 2> "$out/c3.err"
