@@ -414,13 +414,6 @@ __global__ __launch_bounds__(256, (BM > 128 ? 1 : (STAGES >= 4 ? 1 : (STAGES == 
         wrow[j] = p.W + bz * p.sW + (long)n * p.ldw + chunk * 8;
     }
 
-    // One LDS-DMA piece.  The ring instantiations (STAGES >= 3: the small grids of small batches, where a SIMD often holds ONE wave
-    // and nothing but the wave itself can overlap its fragment reads with its MFMAs) issue it from inline asm: behind the builtin
-    // the compiler places every LDS wait as lgkmcnt(0) (ds_common.h, `lds_dma16`), which would serialise the k-step read-ahead below.
-    auto dma = [&](const void* src, char* dst) {
-        if constexpr (STAGES >= 3) lds_dma16_v(src, (unsigned)(size_t)(lds_void*)dst);
-        else __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)dst, 16, 0, 0);
-    };
     auto issue = [&](int kt, int buf) {
         const int k0 = kt * BK;
         char* dA = sA + buf * BM * 128 + wave * ASEG * 1024;
@@ -445,19 +438,19 @@ __global__ __launch_bounds__(256, (BM > 128 ? 1 : (STAGES >= 4 ? 1 : (STAGES == 
                 }
                 const long off = ((long)a_pb[j] + (long)iy * p.Win + ix) * p.Cin + ci0 + a_ch[j];
                 const void* src = ok ? (const void*)(p.A + off) : (const void*)g_zero_page;
-                dma(src, dA + j * 1024);
+                __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(dA + j * 1024), 16, 0, 0);
             }
         } else {
             const bool first = k0 < p.K1;
 #pragma unroll
             for (int j = 0; j < ASEG; ++j) {
                 const half_t* src = first ? a1[j] + k0 : a2[j] + (k0 - p.K1);
-                dma(src, dA + j * 1024);
+                __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(dA + j * 1024), 16, 0, 0);
             }
         }
 #pragma unroll
         for (int j = 0; j < BSEG; ++j)
-            dma(wrow[j] + k0, dB + j * 1024);
+            __builtin_amdgcn_global_load_lds((glb_void*)(wrow[j] + k0), (lds_void*)(dB + j * 1024), 16, 0, 0);
     };
 
     f32x16 acc[MI][2];
@@ -504,35 +497,29 @@ __global__ __launch_bounds__(256, (BM > 128 ? 1 : (STAGES >= 4 ? 1 : (STAGES == 
             if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1, fill);
             const char* cA = sA + buf * BM * 128;
             const char* cB = sB + buf * BN * 128;
-            // k-step read-ahead (round 5): the fragments of k-step kk + 1 are requested before the MFMAs of k-step kk, in two
-            // register sets, and waited for with counted lgkmcnt.  (Rounds 2-4: all 4 x (MI + 2) fragments, lgkmcnt(0), then all
-            // MFMAs - on a SIMD that holds one wave, as in these grids, the LDS round trips and the matrix pipe took turns.)
-            h8 af[2][MI], bf[2][2];
-            auto load = [&](int kk, int set) {
+            h8 af[4][MI], bf[4][2];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
                 const int ch = kk * 2 + lhi;
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) {
                     const int r = wm * (BM / 2) + mi * 32 + l31;
-                    af[set][mi] = *reinterpret_cast<const h8*>(cA + r * 128 + swz(r, ch));
+                    af[kk][mi] = *reinterpret_cast<const h8*>(cA + r * 128 + swz(r, ch));
                 }
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) {
                     const int r = wn * 64 + ni * 32 + l31;
-                    bf[set][ni] = *reinterpret_cast<const h8*>(cB + r * 128 + swz(r, ch));
+                    bf[kk][ni] = *reinterpret_cast<const h8*>(cB + r * 128 + swz(r, ch));
                 }
-            };
-            load(0, 0);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                if (kk < 3) load(kk + 1, (kk + 1) & 1);
-                __builtin_amdgcn_sched_barrier(0);
+            for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < 2; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[kk & 1][ni], af[kk & 1][mi], acc[mi][ni], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[kk][ni], af[kk][mi], acc[mi][ni], 0, 0, 0);
             buf = buf + 1 == STAGES ? 0 : buf + 1;
             fill = fill + 1 == STAGES ? 0 : fill + 1;
         }
