@@ -101,14 +101,14 @@ __device__ __forceinline__ void swap32(unsigned& vdst, unsigned& src) {
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-// PP_DIRECT_EPI (round 5): the branch-free epilogues hand their 32 x 64 pieces to memory WITHOUT the transposition through LDS.
-// A lane holds tile row l31; its two half-wave partners (l, l + 32) hold columns 8g + {0..3} and 8g + {4..7} of every group g, so
-// one v_permlane32_swap per dword and group pair leaves the lower lane with columns 16j .. 16j+7 and the upper one with
-// 16j+8 .. 16j+15 of the row: one 16-byte store per lane, 32 rows x 32 bytes per instruction (cdna_hip_programming.md T21: such
-// row-per-lane tails are store-ISSUE-bound, not bandwidth-bound).  Per wave and tile 32 ds_write_b64 + 16 ds_read_b128 (+ their
-// waits: every piece was a write -> read round trip) become 32 swaps; residual rows are loaded in the same row-per-lane shape, and
-// the LayerNorm statistics of a row are one exchange between its two lanes instead of an 8-lane butterfly.  -DPP_DIRECT_EPI=0:
-// the LDS transposition (A/B).
+// PP_DIRECT_EPI (round 5): the branch-free GEGLU epilogue hands its 32 x 32 output pieces to memory WITHOUT the transposition
+// through LDS.  A lane holds tile row l31; its two half-wave partners (l, l + 32) hold columns 8g + {0..3} and 8g + {4..7} of every
+// group g, so one v_permlane32_swap per dword and group pair leaves the lower lane with columns 16j .. 16j+7 and the upper one
+// with 16j+8 .. 16j+15 of the row: one 16-byte store per lane, 32 rows x 32 bytes per instruction - a 64-byte output row leaves in
+// two halves (cdna_hip_programming.md T21).  Per wave and tile 16 ds_write_b64 + 8 ds_read_b128 and their write -> read round
+// trips become 16 swaps: the GEGLU GEMMs -1.4 % (1542.8 -> 1521.6 us at M = 65536; profiles/r05_pp_direct_epilogue_ab.txt).
+// The plain epilogues keep the LDS transposition: their 128-byte rows in four pieces measured +4 ... +15 % (same file).
+// -DPP_DIRECT_EPI=0: the LDS transposition here too (A/B).
 #ifndef PP_DIRECT_EPI
 #define PP_DIRECT_EPI 1
 #endif
@@ -808,102 +808,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
                     }
                 }
             };
-            // PP_DIRECT_EPI: the same arithmetic on the same values, handed over without LDS (see the macro's comment)
-            auto plain_direct = [&](auto resc) {
-                constexpr bool RES = decltype(resc)::value != 0;
-                V8 rv[4];   // piece (ni, j) -> rv[ni * 2 + j]: the lane's 8 columns ni * 32 + 16 j + 8 lhi .. of its row
-                char* const Cw = reinterpret_cast<char*>(Cg) + ((long)(cm0 + wr * 64) * p.ldc + nwp) * 2;
-                const char* const Rw = RES ? reinterpret_cast<const char*>(Rg) + ((long)(cm0 + wr * 64) * p.ldr + nwp) * 2 : nullptr;
-                const unsigned vC = (unsigned)((l31 * p.ldc + lhi * 8) * 2);
-                const unsigned vR = (unsigned)((l31 * p.ldr + lhi * 8) * 2);
-                auto load_res = [&](int mi) {
-                    const char* const Rr = Rw + (long)((mi >> 1) * 128 + (mi & 1) * 32) * p.ldr * 2;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) rv[q] = *reinterpret_cast<const V8*>(Rr + (size_t)vR + q * 32);
-                };
-                if constexpr (RES) load_res(0);
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi) {
-                    const int mb = cm0 + (mi >> 1) * 128 + wr * 64 + (mi & 1) * 32;
-                    unsigned w[2][4][2];
-#pragma unroll
-                    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            V4 o;
-                            if constexpr (FUSE == 1) {
-                                const f32x2 r2 = {rs4[mi], rs4[mi]};
-#pragma unroll
-                                for (int e = 0; e < 4; e += 2) {
-                                    f32x2 y = __builtin_elementwise_fma(f32x2{acc[mi][ni][4 * g + e], acc[mi][ni][4 * g + e + 1]}, r2,
-                                                                        f32x2{(float)bq[ni * 4 + g][e], (float)bq[ni * 4 + g][e + 1]});
-                                    asm("" : "+v"(y));   // (one rounding per step everywhere: profiles/r04_determinism_bisect.txt)
-                                    o[e] = (T)y[0], o[e + 1] = (T)y[1];
-                                }
-                            } else {
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) o[e] = (T)(acc[mi][ni][4 * g + e] + (float)bq[ni * 4 + g][e]);
-                            }
-                            const u32x2 t = __builtin_bit_cast(u32x2, o);
-                            w[ni][g][0] = t[0], w[ni][g][1] = t[1];
-                        }
-                    V8 v[4];
-                    float s1 = 0.f, q1 = 0.f;
-#pragma unroll
-                    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            swap32(w[ni][2 * j][0], w[ni][2 * j + 1][0]);
-                            swap32(w[ni][2 * j][1], w[ni][2 * j + 1][1]);
-                            const u32x4 u = {w[ni][2 * j][0], w[ni][2 * j][1], w[ni][2 * j + 1][0], w[ni][2 * j + 1][1]};
-                            V8& x = v[ni * 2 + j];
-                            x = __builtin_bit_cast(V8, u);
-                            if constexpr (RES) {
-                                // v_pk_add_f16 == (f16)((float)a + (float)b) (tests/test_f16_add_equivalence.py); bf16 keeps the f32 form
-                                if constexpr (std::is_same<T, half_t>::value) x = x + rv[ni * 2 + j];
-                                else {
-#pragma unroll
-                                    for (int e = 0; e < 8; ++e) x[e] = (T)((float)x[e] + (float)rv[ni * 2 + j][e]);
-                                }
-                            }
-                            // fused LayerNorm (producer): the lane's 32 of its row's 64 stored values, two dot instructions per pair
-                            if constexpr ((FUSE & 2) != 0) {
-                                typedef _Float16 h2v __attribute__((ext_vector_type(2)));
-#pragma unroll
-                                for (int e = 0; e < 8; e += 2) {
-                                    const h2v pr = {x[e], x[e + 1]};
-                                    s1 = __builtin_amdgcn_fdot2(pr, h2v{(_Float16)1.f, (_Float16)1.f}, s1, false);
-                                    q1 = __builtin_amdgcn_fdot2(pr, pr, q1, false);
-                                }
-                            }
-                        }
-                    // the NEXT piece's residual rows are requested before this piece's stores: the wait for them then
-                    // leaves the stores in flight (requested behind them, it would wait for their acknowledgement)
-                    if constexpr (RES) {
-                        if (mi < 3) load_res(mi + 1);
-                    }
-                    if constexpr ((FUSE & 2) != 0) {
-                        // the row's other half sits in the partner lane (l ^ 32): one exchange, then the lower lane writes the pair -
-                        // 32 lanes x 8 bytes, 256 contiguous bytes per piece, the format ln_finalize_kernel and the consumers read
-                        unsigned a0 = __builtin_bit_cast(unsigned, s1), a1 = a0, b0 = __builtin_bit_cast(unsigned, q1), b1 = b0;
-                        swap32(a0, a1);
-                        swap32(b0, b1);
-                        const f32x2 o2 = {__builtin_bit_cast(float, a0) + __builtin_bit_cast(float, a1),
-                                          __builtin_bit_cast(float, b0) + __builtin_bit_cast(float, b1)};
-                        if (lhi == 0) *reinterpret_cast<f32x2*>(p.stats_out + 2 * ((long)(nwp >> 6) * p.M + mb + l31)) = o2;
-                    }
-                    char* const Cr = Cw + (long)((mi >> 1) * 128 + (mi & 1) * 32) * p.ldc * 2;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) *reinterpret_cast<V8*>(Cr + (size_t)vC + q * 32) = v[q];
-                }
-            };
-#if PP_DIRECT_EPI
-            if (__builtin_amdgcn_readfirstlane((int)(Rg != nullptr))) plain_direct(IC<1>{});
-            else plain_direct(IC<0>{});
-#else
+            // (The same hand-over WITHOUT the LDS transposition - v_permlane32_swap + row-per-lane 16-byte stores, as in the GEGLU
+            // epilogue above - was built and measured for these plain tiles too: 128-byte rows leave as four 32-byte pieces from four
+            // instructions and the residual rows arrive the same way: +4 % on the plain shapes, +15 % with a residual
+            // (profiles/r05_pp_direct_epilogue_ab.txt).  Only the 64-byte rows of the GEGLU tiles go direct.)
             if (__builtin_amdgcn_readfirstlane((int)(Rg != nullptr))) plain(IC<1>{});
             else plain(IC<0>{});
-#endif
         } else if constexpr (FUSE != 0) {
         } else if (geglu) {
             const int nw = cn0 + (wc >> 1) * 128 + (wc & 1) * 32;  // hidden strip; gates 64 columns further
