@@ -78,12 +78,7 @@ __global__ __launch_bounds__(256, 2) void self_attn_sp_kernel(const SelfAttnPara
     // L2: 2.85 GB of fabric reads per launch for 0.17 GB of K + V (PMC, profiles/r03_pmc_conv_attn_ip_summary.txt).  The 1-D
     // grid is remapped so that an XCD owns a contiguous run of work items = all query blocks of a few heads, back to back.
     const int nqb = (p.Nq + 255) / 256;
-    // Persistent blocks (round 5, build switch SP_PERSISTENT): the grid is two blocks per CU and a block walks the work items
-    // vb = blockIdx.x, + gridDim.x, ... (gridDim.x is a multiple of 8, so a block's items all belong to its own XCD's chunk of
-    // the remapped order) instead of one block per item: at N = 1024 a block lives 45 us, 8 of them outside its tile loop.
-    const int nitems = nqb * p.B * p.heads;
-    for (int vb = (int)blockIdx.x; vb < nitems; vb += (int)gridDim.x) {
-    const int item = p.xcd_map ? xcd_remap(vb, nitems) : vb;
+    const int item = p.xcd_map ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
     const int bh = item / nqb, qblk = item - bh * nqb;
     const int b = bh / p.heads, h = bh % p.heads;
     const int q0 = qblk * 256 + wave * 64;
@@ -352,67 +347,31 @@ __global__ __launch_bounds__(256, 2) void self_attn_sp_kernel(const SelfAttnPara
     }
     pv(P1, 1, (unsigned)vprev * TILE_B);   // the last pair's P V
 
-    // ---- epilogue: O / l.  A row's 64 outputs sit in its two lanes (l, l + 32) as 4-column groups; one v_permlane32_swap per
-    // dword and group pair gives each lane 8 consecutive columns: 8 stores of 16 bytes per wave instead of 16 of 8
-    // (cdna_hip_programming.md T21: this tail is store-issue-bound)
+    // ---- epilogue: O / l
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
         const float l = lsum[qb] + __shfl_xor(lsum[qb], 32, 64);
         const float inv = 1.0f / l;
         const int qrow = q0 + qb * 32 + l31;
-        half_t* op = p.o + (long)b * p.so + (long)min(qrow, p.Nq - 1) * p.ldo + h * 64;
-        const bool wide = (p.ldo & 7) == 0;   // 16-byte stores need 16-byte rows
+        if (qrow < p.Nq) {
+            half_t* op = p.o + (long)b * p.so + (long)qrow * p.ldo + h * 64;
 #pragma unroll
-        for (int db = 0; db < 2; ++db) {
-            unsigned w[4][2];
+            for (int db = 0; db < 2; ++db)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                h4 o;
+                for (int g = 0; g < 4; ++g) {
+                    h4 o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (half_t)(O[qb][db][4 * g + e] * inv);
-                if (!wide) {
-                    if (qrow < p.Nq) *reinterpret_cast<h4*>(op + db * 32 + 8 * g + 4 * lhi) = o;
+                    for (int e = 0; e < 4; ++e) o[e] = (half_t)(O[qb][db][4 * g + e] * inv);
+                    *reinterpret_cast<h4*>(op + db * 32 + 8 * g + 4 * lhi) = o;
                 }
-                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                const u32x2 t = __builtin_bit_cast(u32x2, o);
-                w[g][0] = t[0], w[g][1] = t[1];
-            }
-            if (wide) {
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(w[2 * j][0]), "+v"(w[2 * j + 1][0]));
-                    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(w[2 * j][1]), "+v"(w[2 * j + 1][1]));
-                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-                    const u32x4 v = {w[2 * j][0], w[2 * j][1], w[2 * j + 1][0], w[2 * j + 1][1]};
-                    if (qrow < p.Nq) *reinterpret_cast<u32x4*>(op + db * 32 + 16 * j + 8 * lhi) = v;
-                }
-            }
         }
     }
-    __syncthreads();   // every wave is done with the K / V^T rings before the next item's first tiles are requested
-    }   // work items
 }
 
 }  // namespace
 
-#ifndef SP_PERSISTENT
-#define SP_PERSISTENT 1
-#endif
-
 int ds_launch_self_attn_sp(const SelfAttnParams& p, hipStream_t stream) {
-    const int nitems = ((p.Nq + 255) / 256) * p.B * p.heads;
-    int grid = nitems;
-#if SP_PERSISTENT
-    static int slots = 0;   // two blocks per CU (launch bounds), a multiple of 8 (one XCD per blockIdx % 8)
-    if (slots == 0) {
-        int dev = 0, cus = 0;
-        DS_HIP(hipGetDevice(&dev));
-        DS_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        slots = (cus > 0 ? cus : 256) * 2 / 8 * 8;
-    }
-    if (grid > slots) grid = slots;
-#endif
-    hipLaunchKernelGGL(self_attn_sp_kernel, dim3(grid), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(self_attn_sp_kernel, dim3(((p.Nq + 255) / 256) * p.B * p.heads), dim3(256), 0, stream, p);
     DS_LAUNCH_CHECK();
     return 0;
 }
