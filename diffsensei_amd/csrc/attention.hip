@@ -324,8 +324,9 @@ __global__ __launch_bounds__(NW * 64, 2) void ip_attn_kernel(const IPAttnParams 
             const int r = j * 8 + (lane >> 3);
             const int qrow = min((int)(blockIdx.x * qt + it) * ROWS + wave * 32 + r, p.N - 1);
             const int chunk = (lane & 7) ^ ((r >> 1) & 7);
-            __builtin_amdgcn_global_load_lds((glb_void*)(p.q + ((long)b * p.N + qrow) * p.ldq + h * 64 + chunk * 8),
-                                             (lds_void*)(dst + j * 1024), 16, 0, 0);
+            // (inline asm, round 5: behind the builtin the compiler turns every LDS wait of the kernel - the K / V panel fragment
+            // reads of the tile loop - into lgkmcnt(0): ds_common.h, `lds_dma16`)
+            lds_dma16_v(p.q + ((long)b * p.N + qrow) * p.ldq + h * 64 + chunk * 8, (unsigned)(size_t)(lds_void*)(dst + j * 1024));
         }
     };
     if constexpr (RING) {
