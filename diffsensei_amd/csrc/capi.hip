@@ -53,7 +53,7 @@ int ds_set_option(const char* key, int value) {
         return 0;
     }
     if (strcmp(key, "gn_variant") == 0) {
-        DS_REQUIRE(value >= 0 && value <= 1, "gn_variant must be 0 (auto) or 1 (round-3 geometry)");
+        DS_REQUIRE(value >= 0 && value <= 2, "gn_variant must be 0 (auto), 1 (round-3 geometry) or 2 (8 loads in flight, A/B)");
         ds_groupnorm_set_variant(value);
         return 0;
     }
