@@ -51,7 +51,8 @@ int ds_device_info(int* cu_count, int* lds_bytes, char* arch_name, int arch_name
  *                        ip_attn_kernel<8,true> where N % 256 == 0 - bit-identical results; faster back to back, slower inside the
  *                        UNet forward, so never automatic (A/B: profiles/r04_ipattn_ring_ab.txt, r04_forward_option_ab.txt)
  *   "gn_variant"         0 (default) GroupNorm on 512-thread blocks with >= 64 rows per block | 1 the round-3 geometry
- *                        (256 threads, 8-row chunks; A/B: profiles/r04_gn_geometry_ab.txt)
+ *                        (256 threads, 8-row chunks; A/B: profiles/r04_gn_geometry_ab.txt) | 2 as 0 with 8 loads in flight per
+ *                        lane (A/B: profiles/r05_gn_8_in_flight_ab.txt)
  *   "llm_gemv_variant"   0 auto (software-pipelined persistent GEMV) | 1 one column per wavefront | 2 un-pipelined streaming GEMV
  *   "gemm_debug"         bits 0..7: ablation builds of gemm_pp_kernel (only in a library built with -DDS_ABLATION; 0 otherwise) |
  *                        bit 8 (256): gemm_pp_kernel drains a tile's C stores before the next tile's first k-tile instead of
