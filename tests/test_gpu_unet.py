@@ -306,3 +306,18 @@ def test_unet_sdxl_small_batch_rows_are_position_independent(sdxl_model):
     for r in range(6):
         assert torch.equal(y[r], y[0 if r < 3 else 3]), r
     assert _rel(y[3], y[0]) > 1e-3
+    # with norm1 fused, the transposed to_v GEMM reads the RAW residual stream `t_hidden` at ceil8(N) rows per image -
+    # up to 7 rows behind the last image when N % 8 != 0 (324 tokens here).  The stream therefore carries 8 rows of slack that no
+    # producer may write and that must read as zero (they become the V^T pad columns: 0 x NaN would poison the P V MFMA).
+    checked = 0
+    for (role, level), t in eng.scratch.items():
+        if role != "t_hidden":
+            continue
+        H, W = eng.hw[level]
+        N, Cc = H * W, cfg.block_out_channels[level]
+        M = 6 * N
+        assert t.numel() >= (M + 8) * Cc, (level, t.numel(), (M + 8) * Cc)
+        slack = t[M * Cc:(M + 8) * Cc]
+        assert torch.count_nonzero(slack).item() == 0, f"level {level}: a producer wrote into the slack behind the hidden stream"
+        checked += N % 8 != 0
+    assert checked >= 1, "expected a level whose token count is not a multiple of 8"
