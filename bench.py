@@ -25,8 +25,8 @@ vs the 2.5 PFLOP/s dense fp16 MFMA peak), `cpu_baseline` (the whole `__call__` o
 oracle, the Euler loop interrupted after 2 of 20 steps and only the loop extrapolated; rank 0 at N=1 only) and `parity`
 (`path: "__call__"`: the SAME call - prompt, negative prompt, noise, weights, interrupt point - through `pipe(...)` on the
 GPU: relative L2 of the latents, and the uint8 image bytes compared.  The bench FAILS when the latents differ by more than
-3e-2 (bounded 2-step sample) / 6e-2 (`--cpu-full`, all 20 steps: fp16 storage vs fp32 compounds through CFG 7.5) or the
-image by more than 5e-2).
+6e-3 (bounded 2-step sample; measured 1.7e-3) / 1.2e-2 (`--cpu-full`, all 20 steps: fp16 storage vs fp32 compounds through
+CFG 7.5; measured 2.1e-3) or the image by more than 8e-3 (measured 1.9e-3); until round 5 these gates were 3e-2 / 6e-2 / 5e-2).
 """
 from __future__ import annotations
 
@@ -44,7 +44,6 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 MFMA_PEAK_TFLOPS = 2500.0      # dense fp16/bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
-FP8_PEAK_TFLOPS = 5000.0       # dense OCP fp8 on the MX-scaled instructions (same guide)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -194,7 +193,7 @@ def cpu_call_and_gpu_parity(pipe, req, cpu_full=False, parity=True, budget_steps
       extrapolated to 20 steps; encoders, VAE decode and postprocess are measured whole.  `--cpu-full`: all 20 steps.
     * `parity` (`path: "__call__"`): the SAME call - same prompt, negative prompt, initial noise, weights (the oracle's
       modules hold the engines' fp16-rounded weights), same interrupt point - through `pipe(...)` on the GPU, compared on
-      the latents (relative L2, tolerance 3e-2 for <= 4 steps / 6e-2 for the 20-step run: fp16 storage vs pure fp32
+      the latents (relative L2, tolerance 6e-3 for <= 4 steps / 1.2e-2 for the 20-step run: fp16 storage vs pure fp32
       compounding through CFG 7.5) and on the uint8 image bytes the call returns (`image_rel_l2` on pixels / 255, the
       fraction of bytes that differ at all and by more than 1 LSB, the largest difference)."""
     import numpy as np
@@ -251,8 +250,8 @@ def cpu_call_and_gpu_parity(pipe, req, cpu_full=False, parity=True, budget_steps
            "steps": n_run, "interrupted_after": None if n_run == steps else n_run,
            "rel_l2": round(((got_lat - rl).norm() / rl.norm()).item(), 6),
            "max_abs": round((got_lat - rl).abs().max().item(), 5),
-           "tolerance": 3e-2 if n_run <= 4 else 6e-2,
-           "image_rel_l2": round(float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-12)), 6), "image_tolerance": 5e-2,
+           "tolerance": 6e-3 if n_run <= 4 else 1.2e-2,
+           "image_rel_l2": round(float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-12)), 6), "image_tolerance": 8e-3,
            "u8_frac_differ": round(float((d != 0).mean()), 6), "u8_frac_gt_1lsb": round(float((np.abs(d) > 1).mean()), 6),
            "u8_max_diff": int(np.abs(d).max()), "u8_std_ref": round(float(ref["u8"][0].std()), 2),
            "vs": "oracle/pipeline_ref.call_oracle (fp32 torch + transformers modules, CPU) on the same weights / prompt / noise"}
@@ -371,10 +370,6 @@ def main():
                          "pt: [0,1] fp32 images left on the device (the round-1 region)")
     ap.add_argument("--refs", type=int, default=2, choices=(0, 1, 2, 3, 4),
                     help="character references in the request (BASELINE config 2: 1, config 5: 4)")
-    ap.add_argument("--attn", choices=("fp16", "fp8"), default="fp16",
-                    help="self-attention arithmetic: fp16 (the reference's; the metric line and, since round 5, BASELINE config 5 too) or "
-                         "fp8 = OCP e4m3 on the MX matrix instruction - measured, NOT adopted (BASELINE.md section 5: 5.4e-2 per op for no "
-                         "end-to-end gain over the round-5 fp16 kernel); kept as an opt-in A/B: --size 2048 --refs 4 --attn fp8 --num-samples 1")
     ap.add_argument("--no-dialog", action="store_true", help="no dialog boxes (BASELINE config 2)")
     ap.add_argument("--no-parity", action="store_true", help="skip the GPU-vs-oracle parity run on BASELINE configs[0]")
     ap.add_argument("--cpu-full", action="store_true",
@@ -420,8 +415,6 @@ def main():
     req = synthetic_request(device, args.size, seed=1234 + rank, output_type=out_type, refs=args.refs)
     if args.no_dialog:
         req["dialog_bbox"] = []
-    if args.attn != "fp16":
-        pipe.unet.attention_dtype = args.attn
 
     def one_step():
         r = req
@@ -476,7 +469,7 @@ def main():
         dom = max(table.items(), key=lambda kv: kv[1]["ms"])
         name, d = dom
         ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
-        peak = FP8_PEAK_TFLOPS if "fp8" in name else MFMA_PEAK_TFLOPS
+        peak = MFMA_PEAK_TFLOPS
         roofline = {"bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(ach / peak, 4), "traffic": None, "kernel": name,
                     "launches_per_forward": d["launches"], "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 2),
@@ -530,7 +523,7 @@ def main():
             "config": {"workload": f"{args.size}x{args.size}, 50-step Euler, CFG 7.5, {args.refs} character refs (padded to 4) + "
                                    f"{0 if args.no_dialog else 2} dialog boxes, num_samples={ns} per call (UNet batch {2 * ns}), "
                                    f"one call per step",
-                       "output": out_type, "self_attention": args.attn,
+                       "output": out_type, "self_attention": "fp16",
                        "timed_region": "2 SDXL text encoders (prompt + negative prompt), CLIP-H + ViT-MAE + Resampler "
                                        "character encoding, 50 x (UNet + CFG + scheduler step)" +
                                        ("; VAE decode excluded (output: latents)" if args.no_vae else

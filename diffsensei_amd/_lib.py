@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # DIFFSENSEI_LIB: load another build of the SAME library (A/B of compiler flags, tools/gpu_*): never a fallback - it must exist
@@ -24,7 +25,7 @@ class DsOp(C.Structure):
 OP = dict(GEMM=1, CONV3X3=2, GROUPNORM=3, LAYERNORM=4, SELF_ATTN=5, IP_ATTN=6, CONV_IN=7, CONV_OUT=8, SKINNY=9,
           TIMESTEP_EMBED=10, ADD_TIME_IDS=11, SAMPLER_STEP=12, PREP_INPUT=13, ADVANCE=14, NHWC2NCHW=15, NCHW2NHWC=16,
           PAD_ROWS=17, SMALL_ATTN=18, LLM_GEMV=19, LLM_ATTN=20, LLM_RMSNORM=21, LLM_EMBED=22, LLM_SELECT=23,
-          LLM_ADVANCE=24, QUANT_FP8=25, SELF_ATTN_FP8=26, LN_FINALIZE=27)
+          LLM_ADVANCE=24, LN_FINALIZE=27)
 
 # name -> (restype, argtypes).  Every symbol declared in include/diffsensei_hip.h appears here;
 # tests/test_capi_symbols.py checks the two lists against each other.
@@ -33,6 +34,7 @@ SIGNATURES = {
     "ds_version": (i32, []),
     "ds_device_info": (i32, [C.POINTER(i32), C.POINTER(i32), C.c_char_p, i32]),
     "ds_set_option": (i32, [C.c_char_p, i32]),
+    "ds_debug_counter": (i32, [C.c_char_p, i32, C.POINTER(C.c_longlong)]),
     "ds_gemm_f16": (i32, [vp, i64, vp, i64, i32, vp, i64, vp, vp, i64, vp, i64, i32, i32, i32, i32, vp]),
     "ds_gemm_ln_f16": (i32, [vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp, i32, i32, i32, i32, vp]),
     "ds_ln_finalize": (i32, [vp, vp, i32, i32, i32, f32, vp]),
@@ -58,8 +60,6 @@ SIGNATURES = {
     "ds_groupnorm_f16": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp]),
     "ds_layernorm_f16": (i32, [vp, vp, vp, vp, i32, i32, f32, vp]),
     "ds_self_attn_f16": (i32, [vp, i64, i64, vp, i64, i64, vp, i64, vp, i64, i64, i32, i32, i32, i32, f32, vp]),
-    "ds_quantize_fp8_e4m3_f16": (i32, [vp, i64, i64, vp, i32, i32, i32, f32, i32, vp]),
-    "ds_self_attn_fp8_f16": (i32, [vp, i64, i64, vp, vp, vp, i64, i64, i32, i32, i32, i32, f32, vp]),
     "ds_masked_ip_attn_f16": (i32, [vp, i64, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32,
                                     i32, f32, f32, vp, i64, i64, i64, vp]),
     "ds_ip_region_flags": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
@@ -100,6 +100,7 @@ SIGNATURES = {
 }
 
 _lib = None
+_tls = threading.local()   # which threads have had the environment's A/B options applied
 
 
 class DiffSenseiHipError(RuntimeError):
@@ -110,6 +111,8 @@ def load() -> C.CDLL:
     """Load libdiffsensei_hip.so (built by `python -m diffsensei_amd.build`); raise loudly when absent."""
     global _lib
     if _lib is not None:
+        if not getattr(_tls, "env_applied", False):
+            apply_env_options(_lib)
         return _lib
     if not os.path.exists(LIB_PATH):
         raise DiffSenseiHipError(
@@ -121,6 +124,19 @@ def load() -> C.CDLL:
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    apply_env_options(lib)
+    return lib
+
+
+def apply_env_options(lib=None) -> None:
+    """Apply DS_OPTIONS / DS_GEMM_VARIANT (A/B knobs from the environment) to the CALLING thread.
+
+    The library's knobs are thread-local (include/diffsensei_hip.h): a value set with ds_set_option changes only the launches
+    - and the host-side plan queries such as ds_gemm_ln_fusable - of the thread that set it.  The environment is a process-wide
+    request, so `load()` applies it once per thread, on that thread's first call: a plan built on one thread and launched from
+    another then sees the same dispatch on both.  An explicit ds_set_option still has to be made on the launching thread."""
+    lib = lib or _lib
+    _tls.env_applied = True
     for kv in filter(None, os.environ.get("DS_OPTIONS", "").split(",")):   # A/B runs: DS_OPTIONS=key=value,key=value
         k, _, val = kv.partition("=")
         if lib.ds_set_option(k.strip().encode(), int(val)) != 0:
@@ -129,7 +145,6 @@ def load() -> C.CDLL:
     if v is not None:  # tuning/A-B knob only; 0 = the library's own choice
         if lib.ds_set_option(b"gemm_variant", int(v)) != 0:
             raise DiffSenseiHipError(lib.ds_last_error().decode())
-    return lib
 
 
 def check(rc: int, what: str = "") -> None:

@@ -687,7 +687,11 @@ int ds_launch_self_attn(const SelfAttnParams& p, hipStream_t stream) {
     // 40.3 vs 47.9; B = 2, N = 1024 (160 blocks) 28.8 vs 30.5; B = 2, heads 20, N = 4096 226 vs 252; B = 2, N = 16384 1462 vs
     // 1633 - it wins at every shape of the UNet at every batch (rounds 3-4: only from ~1000 blocks on).  Smaller grids keep the
     // plain kernels: 64 query rows per wave when that still leaves >= 2 blocks per CU, 32 rows per wave otherwise.
-    switch (self_attn_choice(p.B, p.heads, p.Nq, p.Nk)) {
+    int choice = self_attn_choice(p.B, p.heads, p.Nq, p.Nk);
+    // self_attn_sp_kernel forms its K / V^T source offsets in 32 bits (lds_dma16 takes a base + an unsigned byte offset):
+    // a problem whose per-head K panel or 64 V^T rows span 4 GiB or more keeps the 64-bit-addressed flash kernel
+    if (choice == 2 && !((long)p.Nk * p.ldk * 2 < (1L << 32) && 64L * p.ldv * 2 < (1L << 32))) choice = 1;
+    switch (choice) {
         case 2: {
             SelfAttnParams q = p;
             q.xcd_map = g_attn_variant == 4 ? 0 : 1;   // 4: A/B only - the plain block order

@@ -39,6 +39,11 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 typedef _Float16 h2v __attribute__((ext_vector_type(2)));
 
+// Debug counter (ds_debug_counter("attn_sp_recentre")): how often the rare re-centring branch behind a step ran, per wave and
+// pair, since the last reset.  One atomic from one lane inside the rare branch - nothing in the steady state.  It exists so that
+// a model-level test can PROVE its inputs drove the branch (tests/test_gpu_outlier_magnitudes.py).
+__device__ unsigned long long g_sp_recentre_count = 0;
+
 // every LDS-DMA this wave has issued has landed, every wave of the block is here, and nothing moves across the point
 #define SP_SYNC()                                              \
     do {                                                       \
@@ -248,6 +253,7 @@ __global__ __launch_bounds__(256, 2) void self_attn_sp_kernel(const SelfAttnPara
     // accumulated is rescaled and the pair's probabilities are redone.  O[qb] holds pairs before (t, qb) only (this pair's P V
     // runs in the next step), so nothing of the redone pair is in it yet.
     auto recentre = [&](f32x16 (&S)[2], h8 (&P)[2][2], int qb, unsigned kc_base, int t, float& sum) {
+        if (lane_now() == 0) atomicAdd(&g_sp_recentre_count, 1ull);
         qk(S, qb, kc_base);
         if (ragged && t == nt - 1) mask_ragged(S, t);
         const float delta = fmaxf(cross_max(tile_max(S)), 0.f);
@@ -369,6 +375,19 @@ __global__ __launch_bounds__(256, 2) void self_attn_sp_kernel(const SelfAttnPara
 }
 
 }  // namespace
+
+// reads (and optionally clears) the re-centring counter of the current device; synchronises the device (debug / test use only)
+int ds_attn_sp_recentre_count(int reset, long long* value) {
+    unsigned long long v = 0;
+    DS_HIP(hipDeviceSynchronize());
+    DS_HIP(hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_sp_recentre_count), sizeof(v)));
+    if (reset) {
+        const unsigned long long z = 0;
+        DS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_sp_recentre_count), &z, sizeof(z)));
+    }
+    if (value) *value = (long long)v;
+    return 0;
+}
 
 int ds_launch_self_attn_sp(const SelfAttnParams& p, hipStream_t stream) {
     hipLaunchKernelGGL(self_attn_sp_kernel, dim3(((p.Nq + 255) / 256) * p.B * p.heads), dim3(256), 0, stream, p);

@@ -53,7 +53,7 @@ int ds_set_option(const char* key, int value) {
         return 0;
     }
     if (strcmp(key, "gn_variant") == 0) {
-        DS_REQUIRE(value >= 0 && value <= 2, "gn_variant must be 0 (auto), 1 (round-3 geometry) or 2 (8 loads in flight, A/B)");
+        DS_REQUIRE(value >= 0 && value <= 1, "gn_variant must be 0 (auto) or 1 (round-3 geometry)");
         ds_groupnorm_set_variant(value);
         return 0;
     }
@@ -91,6 +91,13 @@ int ds_set_option(const char* key, int value) {
         return 0;
     }
     ds_set_error("ds_set_option: unknown key '%s'", key);
+    return -1;
+}
+
+int ds_debug_counter(const char* name, int reset, long long* value) {
+    DS_REQUIRE(name != nullptr, "ds_debug_counter: null name");
+    if (strcmp(name, "attn_sp_recentre") == 0) return ds_attn_sp_recentre_count(reset, value);
+    ds_set_error("ds_debug_counter: unknown counter '%s'", name);
     return -1;
 }
 
@@ -294,21 +301,6 @@ int ds_self_attn_f16(const void* q, int64_t ldq, int64_t sq, const void* k, int6
     p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.sq = sq; p.sk = sk; p.so = so;
     p.B = B; p.heads = heads; p.Nq = Nq; p.Nk = Nk; p.scale = scale;
     return ds_launch_self_attn(p, S(stream));
-}
-
-int ds_quantize_fp8_e4m3_f16(const void* x, int64_t ldx, int64_t sx, void* out, int batch, int rows, int cols, float scale,
-                             int permute64, void* stream) {
-    return ds_launch_quantize_fp8(H(x), ldx, sx, reinterpret_cast<unsigned char*>(out), batch, rows, cols, scale, permute64,
-                                  S(stream));
-}
-
-int ds_self_attn_fp8_f16(const void* q, int64_t ldq, int64_t sq, const void* k8, const void* vt8, void* o, int64_t ldo,
-                         int64_t so, int B, int heads, int Nq, int Nk, float scale, void* stream) {
-    SelfAttnParams p;
-    p.q = H(q); p.o = HM(o); p.ldq = ldq; p.ldo = ldo; p.sq = sq; p.so = so;
-    p.B = B; p.heads = heads; p.Nq = Nq; p.Nk = Nk; p.scale = scale;
-    return ds_launch_self_attn_fp8(p, reinterpret_cast<const unsigned char*>(k8), reinterpret_cast<const unsigned char*>(vt8),
-                                   S(stream));
 }
 
 int ds_masked_ip_attn_f16(const void* q, int64_t ldq, const void* kt, const void* vtt, const void* ki,
@@ -573,16 +565,6 @@ static int run_op(const ds_op& o, hipStream_t st) {
                                         reinterpret_cast<int*>(p[2]), reinterpret_cast<int*>(p[3]), st);
         case DS_OP_LLM_ADVANCE:
             return ds_launch_llm_advance(reinterpret_cast<int*>(p[0]), i[0], st);
-        case DS_OP_QUANT_FP8:
-            return ds_launch_quantize_fp8(H(p[0]), l[0], l[1], reinterpret_cast<unsigned char*>(p[1]), i[0], i[1], i[2], o.f[0],
-                                          i[3], st);
-        case DS_OP_SELF_ATTN_FP8: {
-            SelfAttnParams a;
-            a.q = H(p[0]); a.o = HM(p[3]); a.ldq = l[0]; a.ldo = l[1]; a.sq = l[2]; a.so = l[3];
-            a.B = i[0]; a.heads = i[1]; a.Nq = i[2]; a.Nk = i[3]; a.scale = o.f[0];
-            return ds_launch_self_attn_fp8(a, reinterpret_cast<const unsigned char*>(p[1]),
-                                           reinterpret_cast<const unsigned char*>(p[2]), st);
-        }
         default:
             ds_set_error("plan: unknown opcode %d", o.code);
             return -4;
@@ -629,12 +611,6 @@ int ds_op_describe(const ds_op* op, char* name, int name_len, double* flops, dou
             fl = 4.0 * i[0] * (double)i[1] * i[2] * (double)i[3] * 64;
             by = 2.0 * i[0] * (double)i[1] * 64 * (2.0 * i[2] + 2.0 * i[3]);
             break;
-        case DS_OP_SELF_ATTN_FP8:
-            nm = "self_attn_fp8_kernel";
-            fl = 4.0 * i[0] * (double)i[1] * i[2] * (double)i[3] * 64;
-            by = 1.0 * i[0] * (double)i[1] * 64 * (4.0 * i[2] + 2.0 * i[3]);   // q, o f16; k8, vt8 bytes
-            break;
-        case DS_OP_QUANT_FP8: nm = "quantize_fp8_kernel"; by = 3.0 * i[0] * (double)i[1] * i[2]; break;
         case DS_OP_IP_ATTN:
             nm = "ip_attn_kernel";
             fl = 4.0 * i[0] * (double)i[1] * i[2] * (double)(i[3] + i[4]) * 64;

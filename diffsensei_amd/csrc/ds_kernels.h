@@ -97,11 +97,8 @@ struct SelfAttnParams {
 };
 int ds_launch_self_attn(const SelfAttnParams& p, hipStream_t stream);
 int ds_launch_self_attn_sp(const SelfAttnParams& p, hipStream_t stream);
+int ds_attn_sp_recentre_count(int reset, long long* value);   // debug counter of the rare re-centring branch (attention_sp.hip)
 const char* ds_self_attn_kernel_name(int B, int heads, int Nq, int Nk);  // which kernel ds_launch_self_attn picks for this shape  // attention_sp.hip: software-pipelined variant
-// attention_fp8.hip: e4m3 variant (k / vt of the params are unused; the quantized operands are passed separately)
-int ds_launch_quantize_fp8(const half_t* x, long ldx, long sx, unsigned char* out, int batch, int rows, int cols,
-                           float scale, int permute64, hipStream_t stream);
-int ds_launch_self_attn_fp8(const SelfAttnParams& p, const unsigned char* k8, const unsigned char* vt8, hipStream_t stream);
 void ds_attn_set_variant(int v);  // 0 auto, 1 force 32 query rows per wave, 2 force 64 rows per wave, 3 force the software-pipelined kernel
 void ds_ip_attn_set_min_blocks(int v);
 void ds_ip_attn_set_variant(int v);  // 0 auto, 1 four-wave register-staged kernel, 2 eight-wave LDS-DMA ring kernel (N % 256 == 0)

@@ -78,6 +78,10 @@ constexpr int HT = 16384;  // bytes of one half-tile: 128 rows x 64 k of f16
 // A/B (-DPP_EX=8, tools/build_variants.py), batch-64 forward, same box: gemm_pp_kernel 258.6 -> 257.4 ms
 // (profiles/r05_pp_ex16_pf_ab.txt).
 constexpr int EX_MAX = PP_EX;
+// every epilogue path issues (or pads to) at least EX_TAIL vector-memory instructions behind the next tile's prologue: plain 16
+// stores, unfused GEGLU 8 stores + 8 pad pieces, fused GEGLU (FUSE 9) 8 stores + bias + 2 LayerNorm pieces = 11, generic 16 pad
+// pieces.  A PP_EX above 16 would make `wait_newer` under-wait: a tile would read LDS before its DMA has landed.
+static_assert(EX_MAX >= 0 && EX_MAX <= 16, "PP_EX: no epilogue path leaves more than 16 vector-memory instructions in flight");
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 

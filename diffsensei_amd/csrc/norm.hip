@@ -47,7 +47,9 @@ __device__ __forceinline__ GnGeom gn_geom(int C, int HW) {
     return g;
 }
 
-template <typename T, int UNR = 4>   // UNR: independent 16-byte loads in flight per lane (gn_variant 2: 8)
+// (Eight loads in flight per lane instead of four - gn_variant 2 of round 5 - measured +1...2 % alone and noise inside the forward,
+// profiles/r05_gn_8_in_flight_ab.txt; removed in round 6.)
+template <typename T>
 __global__ __launch_bounds__(512) void gn_stats_kernel(GroupNormParams p) {
     __shared__ float red[512 * 16];
     const int C = p.C1 + p.C2;
@@ -62,23 +64,6 @@ __global__ __launch_bounds__(512) void gn_stats_kernel(GroupNormParams p) {
         const int ld = first ? p.C1 : p.C2;
         int row = g.row_start;
         const long step = (long)g.R * ld;
-        if constexpr (UNR == 8) {
-            for (; row + 7 * g.R < g.row_end; row += 8 * g.R) {  // 8 independent 16-byte loads in flight per lane
-                const T* q = src + (long)row * ld;
-                typename Elt<T>::v8 v[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const typename Elt<T>::v8*>(q + u * step);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float f[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) f[u] = (float)v[u][e];
-                    s[e] += ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
-                    ss[e] += (fmaf(f[0], f[0], f[1] * f[1]) + fmaf(f[2], f[2], f[3] * f[3])) +
-                             (fmaf(f[4], f[4], f[5] * f[5]) + fmaf(f[6], f[6], f[7] * f[7]));
-                }
-            }
-        }
         for (; row + 3 * g.R < g.row_end; row += 4 * g.R) {  // 4 independent 16-byte loads in flight per lane
             const T* q = src + (long)row * ld;
             const typename Elt<T>::v8 v0 = *reinterpret_cast<const typename Elt<T>::v8*>(q);
@@ -176,7 +161,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(GroupNormParams p, int
     }
 }
 
-template <typename T, int UNR = 4>
+template <typename T>
 __global__ __launch_bounds__(512) void gn_apply_kernel(GroupNormParams p, int nchunks_stats) {
     const int C = p.C1 + p.C2;
     const GnGeom g = gn_geom(C, p.HW);
@@ -206,17 +191,6 @@ __global__ __launch_bounds__(512) void gn_apply_kernel(GroupNormParams p, int nc
     };
     int row = g.row_start;
     const long step = (long)g.R * ld, dstep = (long)g.R * C;
-    if constexpr (UNR == 8) {
-        for (; row + 7 * g.R < g.row_end; row += 8 * g.R) {  // 8 independent 16-byte loads in flight per lane
-            const T* q = src + (long)row * ld;
-            typename Elt<T>::v8 v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const typename Elt<T>::v8*>(q + u * step);
-            T* d = dst + (long)row * C;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) *reinterpret_cast<typename Elt<T>::v8*>(d + u * dstep) = norm8(v[u]);
-        }
-    }
     for (; row + 3 * g.R < g.row_end; row += 4 * g.R) {  // 4 independent 16-byte loads in flight per lane
         const T* q = src + (long)row * ld;
         const typename Elt<T>::v8 v0 = *reinterpret_cast<const typename Elt<T>::v8*>(q);
@@ -347,10 +321,6 @@ int ds_launch_groupnorm(const GroupNormParams& p, hipStream_t stream) {
         hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, grid, dim3(threads), 0, stream, p);
         hipLaunchKernelGGL(gn_finalize_kernel<bf16_t>, dim3(p.B, p.groups), dim3(256), 0, stream, p, nch);
         hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, grid, dim3(threads), 0, stream, p, nch);
-    } else if (g_gn_variant == 2) {   // A/B: 8 loads in flight per lane
-        hipLaunchKernelGGL((gn_stats_kernel<half_t, 8>), grid, dim3(threads), 0, stream, p);
-        hipLaunchKernelGGL(gn_finalize_kernel<half_t>, dim3(p.B, p.groups), dim3(256), 0, stream, p, nch);
-        hipLaunchKernelGGL((gn_apply_kernel<half_t, 8>), grid, dim3(threads), 0, stream, p, nch);
     } else {
         hipLaunchKernelGGL(gn_stats_kernel<half_t>, grid, dim3(threads), 0, stream, p);
         hipLaunchKernelGGL(gn_finalize_kernel<half_t>, dim3(p.B, p.groups), dim3(256), 0, stream, p, nch);

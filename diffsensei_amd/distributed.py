@@ -348,10 +348,9 @@ def _from_wire(x, as_pil: Optional[bool]):
 
 
 def _normalise_local(results: dict, as_pil: Optional[bool]) -> dict:
-    """The world_size-1 / gather=False path returns the same TYPES a gather would (the result type used to depend
-    on the world size); with as_pil None that is the worker's own objects, untouched."""
-    if as_pil is None:
-        return results
+    """The world_size-1 / gather=False path returns the same TYPES a gather would (the result type used to
+    depend on the world size): every result takes the wire round trip without the wire - torch tensors come back as numpy
+    arrays, tuples as lists, PIL images as PIL images (or as `as_pil` asks) - exactly what rank 0 receives from eight ranks."""
     return {k: _from_wire(_to_wire(v), as_pil) for k, v in results.items()}
 
 

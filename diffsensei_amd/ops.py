@@ -596,28 +596,3 @@ def image_to_u8(image: Tensor) -> Tensor:
     out = torch.empty((B, H, W, 3), dtype=torch.uint8, device=image.device)
     check(_lib.load().ds_image_f32_to_u8_nhwc(_p(image), _p(out), B, H, W, _stream()), "ds_image_f32_to_u8_nhwc")
     return out
-
-
-def quantize_fp8(x: Tensor, scale: float = 1.0, permute64: bool = False) -> Tensor:
-    """x: [batch, rows, cols] f16 (contiguous) -> uint8 e4m3 bytes of clamp(x*scale, +-448); `permute64` stores every
-    64-column group in the contraction order of `self_attention_fp8` (for V^T)."""
-    _chk(x)
-    batch, rows, cols = x.shape
-    out = torch.empty((batch, rows, cols), dtype=torch.uint8, device=x.device)
-    check(_lib.load().ds_quantize_fp8_e4m3_f16(_p(x), cols, rows * cols, _p(out), batch, rows, cols, float(scale),
-                                               int(permute64), _stream()), "ds_quantize_fp8_e4m3_f16")
-    return out
-
-
-def self_attention_fp8(q: Tensor, k: Tensor, vt: Tensor, heads: int, scale: Optional[float] = None) -> Tensor:
-    """FP8 (e4m3) flash self-attention: q,k: [B,N,heads*64] f16; vt: [B,heads,64,Nk] f16 -> [B,N,heads*64] f16.
-    K and V^T are quantized here (two launches), then `ds_self_attn_fp8_f16`.  Nk % 64 == 0."""
-    _chk(q, k, vt)
-    B, Nq, Cc = q.shape
-    Nk = k.shape[1]
-    k8 = quantize_fp8(k)
-    vt8 = quantize_fp8(vt.reshape(B * heads, 64, Nk), permute64=True)
-    o = torch.empty_like(q)
-    check(_lib.load().ds_self_attn_fp8_f16(_p(q), Cc, Nq * Cc, _p(k8), _p(vt8), _p(o), Cc, Nq * Cc, B, heads, Nq, Nk,
-                                           scale if scale is not None else 0.125, _stream()), "ds_self_attn_fp8_f16")
-    return o

@@ -55,9 +55,8 @@ class UNetMangaModel:
         self._engines: Dict[Tuple, UNetEngine] = {}
         self._attn_processors: Dict[str, Any] = {n: AttnProcessor2_0() for n in attn_processor_names(self.config)}
         self._manga = False
-        # "fp16": the reference's arithmetic.  "fp8": self-attention in OCP e4m3 on the 2x-rate MX matrix instruction
-        # (BASELINE.json configs[4]); opt-in, stated tolerance in tests/test_gpu_attention_fp8.py
-        self.attention_dtype = os.environ.get("DIFFSENSEI_ATTENTION", "fp16")
+        # "fp16": the reference's arithmetic - the only value (the e4m3 variant of rounds 2-5 was retired in round 6)
+        self.attention_dtype = "fp16"
 
     # ---- construction (reference scripts/demo/gradio_wo_mllm.py:161-169)
     @classmethod

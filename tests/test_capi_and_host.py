@@ -57,6 +57,27 @@ def test_option_knobs_are_thread_local(hip_lib):
     assert other == [auto] and q() == auto
 
 
+def test_env_options_reach_every_thread(hip_lib, monkeypatch):
+    """DS_OPTIONS / DS_GEMM_VARIANT are a process-wide request but the knobs are thread-local, so `_lib.load()`
+    applies the environment once per thread (a plan built on one thread and launched from another must see one dispatch)."""
+    import threading
+    from diffsensei_amd import _lib
+    q = lambda: _lib.load().ds_gemm_ln_fusable(65536, 1280, 1280, 0, 1)
+    assert q() == 1
+    monkeypatch.setenv("DS_OPTIONS", "gemm_variant=1")
+    seen = []
+    t = threading.Thread(target=lambda: seen.append(q()))     # a NEW thread: its first load() applies the environment
+    t.start()
+    t.join()
+    assert seen == [0]
+    assert q() == 1            # this thread had its (empty) environment applied long ago and is not touched
+    monkeypatch.delenv("DS_OPTIONS")
+    t = threading.Thread(target=lambda: seen.append(q()))
+    t.start()
+    t.join()
+    assert seen == [0, 1]
+
+
 def test_ops_refuse_cpu_tensors(hip_lib):
     from diffsensei_amd import _lib, ops
     with pytest.raises(_lib.DiffSenseiHipError):

@@ -5,7 +5,9 @@ UNet, Euler loop, fp32 VAE decode, diffusers' postprocess rounding) - reference 
 Same prompt, negative prompt, references, boxes, initial noise and weights on both sides; the loop is interrupted after 2 of
 4 steps through the reference's own early-exit (`pipe._interrupt`, :314-315) raised from `callback_on_step_end`.
 This is the pytest twin of bench.py's `parity` object (which runs the SDXL-size models on BASELINE configs[0]).
-Tolerances: latents relative L2 <= 5e-2, image (uint8 / 255) relative L2 <= 5e-2, bytes off by more than 2 LSB <= 2 %.
+Tolerances (round 6: <= ~3-4x the measured 1.9e-3 / 2.1e-3 / no byte off by more than 1 LSB; until round 5 they were 5e-2 / 5e-2 /
+2 % by more than 2 LSB - gates that gated nothing): latents relative L2 <= 8e-3, image (uint8 / 255) relative L2 <= 8e-3,
+bytes off by more than 1 LSB <= 0.5 %, none by more than 2.
 """
 import numpy as np
 import pytest
@@ -92,4 +94,8 @@ def test_call_prompt_to_pil_vs_call_oracle(hip_lib):
           f"bytes differing {float((d != 0).mean()):.4f}, by > 1 LSB {float((d > 1).mean()):.5f}, max {int(d.max())}, "
           f"image std {ref['u8'].std():.1f}")
     assert u8.shape == ref["u8"].shape == (ns, size, size, 3)
-    assert e_lat <= 5e-2 and e_img <= 5e-2 and float((d > 2).mean()) <= 0.02, (e_lat, e_img, float((d > 2).mean()))
+    from tests._gates import gate
+    gate("__call__ latents rel-L2 vs call_oracle", e_lat, 8e-3)
+    gate("__call__ uint8 image rel-L2 vs call_oracle", e_img, 8e-3)
+    gate("__call__ share of bytes off by > 1 LSB", float((d > 1).mean()), 5e-3)
+    gate("__call__ largest byte difference", int(d.max()), 2)

@@ -4,7 +4,7 @@ test at their own shapes (missing 1 / weak 2, 3):
 
   * self-attention (reference: src/models/attention_processor.py:76-78) at (heads 10, N 16 384) and (heads 20, N 4 096) -
     2048 x 2048 - and (10, 9 216), (20, 2 304) - 1536 x 1536 -, every flash kernel the dispatch can pick there
-    (`self_attn_kernel<1>`, `<2>`, `self_attn_sp_kernel`, plus the fp8 kernel at its own tolerance), against fp32
+    (`self_attn_kernel<1>`, `<2>`, `self_attn_sp_kernel`), against fp32
     softmax(Q K^T / 8) V evaluated on the device in row blocks (the score matrix of one head is 1 GiB at N = 16 384);
   * masked IP-Adapter attention (attention_processor.py:235-258) on 128 x 128, 96 x 96 and 64 x 64 x 20-head grids vs the oracle;
   * one whole UNet forward at 1536 x 1536 (192 x 192 latents, CFG batch 2, 4 character boxes, 2 dialog boxes) vs
@@ -13,8 +13,8 @@ test at their own shapes (missing 1 / weak 2, 3):
   * the benched UNet batch with 64 DISTINCT items (seeds, boxes, dialog boxes, text embeddings all different): every row
     against the batch-2 forward of its own (unconditional, conditional) pair.
 
-Tolerances are the ones of the smaller shapes: max |err| <= 3e-3 max|ref| on attention outputs, rel-L2 <= 2e-2 on a UNet
-forward vs the fp16-storage oracle, <= 4e-3 between two launch plans of the same inputs.
+Tolerances are the ones of the smaller shapes: max |err| <= 3e-3 max|ref| on attention outputs, rel-L2 <= 5e-3 on a UNet
+forward vs the fp16-storage oracle (measured 1.53-1.55e-3; the gate was 2e-2 until round 5), <= 4e-3 between two launch plans of the same inputs.
 """
 import math
 import os
@@ -79,14 +79,6 @@ def test_self_attention_at_2048_and_1536_shapes(hip_lib, heads, N):
         assert r <= 2e-3, (var, r)
     assert torch.equal(got[1], got[2]), "32-row and 64-row flash kernels differ"
     assert torch.equal(got[0], got[1]) or torch.equal(got[0], got[3]), "automatic dispatch ran none of the tested kernels"
-    # fp8 kernel (opt-in, BASELINE configs[4] names it) at its own tolerance - the e4m3 error floor on white noise,
-    # tests/test_fp8_error_floor.py / test_gpu_attention_fp8.py: rel-L2 <= 7e-2 - on unit-variance Q like those tests
-    q1 = (q.float() / 3.0).half()
-    ref1 = _sdpa_rows_on_device(q1, k, v, heads)
-    y8 = ops.self_attention_fp8(q1, k, vt, heads).float().cpu()
-    r8 = _rel(y8, ref1)
-    print(f"self-attention heads {heads} N {N} fp8: rel-L2 {r8:.3e}")
-    assert torch.isfinite(y8).all() and r8 <= 7e-2, r8
 
 
 @pytest.mark.parametrize("B,heads,hw", [(1, 10, (128, 128)), (2, 20, (64, 64)), (2, 10, (96, 96)), (1, 20, (48, 48)),
@@ -186,7 +178,8 @@ def test_unet_sdxl_batch64_of_distinct_items(sdxl_model):
         assert d0 <= 4e-3 and d1 <= 4e-3, (s, d0, d1)
     # and the items really are different problems
     assert _rel(y64[1], y64[0]) > 0.5 and _rel(y64[33], y64[32]) > 0.5
-    print(f"batch 64 of distinct items vs 32 batch-2 forwards: worst row rel-L2 {worst:.3e}")
+    from tests._gates import gate
+    gate("batch 64 of distinct items vs 32 batch-2 forwards, worst row", worst, 4e-3)
 
 
 def _oracle_case(sdxl_model, H, W, seed):
@@ -204,13 +197,14 @@ def _oracle_case(sdxl_model, H, W, seed):
         r16 = o16.forward(x, 801.0, enc, te, tid, bbox, 1.0, db)
     e = _rel(y, r16)
     print(f"SDXL {H * 8} x {W * 8} forward (CFG batch 2, 4 boxes): rel-L2 vs fp16-storage oracle {e:.3e}")
-    assert e <= 2e-2, e
+    from tests._gates import gate
+    gate(f"SDXL UNet {H * 8}x{W * 8} vs fp16-storage oracle", e, 5e-3)
     assert _rel(y[1], y[0]) > 1e-3
 
 
 def test_unet_sdxl_forward_vs_oracle_1536(sdxl_model):
     """One whole UNet forward at 1536 x 1536 (192 x 192 latents: 9 216 / 2 304 tokens at the attention levels; the largest
-    bucket of BASELINE configs[3]) vs the CPU oracle with fp16-storage emulation, rel-L2 <= 2e-2 (reference path
+    bucket of BASELINE configs[3]) vs the CPU oracle with fp16-storage emulation, rel-L2 <= 5e-3 (reference path
     src/models/unet.py:116-347).  ~31 TFLOP on the host cores."""
     _oracle_case(sdxl_model, 192, 192, 41)
 

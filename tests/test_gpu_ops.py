@@ -652,7 +652,8 @@ def test_self_attention_sp_any_token_count(hip_lib, B, heads, N):
 
 @pytest.mark.parametrize("spike_at,gain", [(300, 6.0), (70, 10.0), (5, 8.0), (1000, 4.0)])
 def test_self_attention_sp_deferred_rescale(hip_lib, spike_at, gain):
-    """The deferred rescale (threshold 8 in base-2 logits) is a rare data-dependent branch: force it.  One key aligned with
+    """The deferred rescale (since round 5: a row is re-centred when a lane's 32-key partial sum of f16 probabilities exceeds
+    2^14 - or overflowed to inf) is a rare data-dependent branch: force it.  One key aligned with
     one query row makes that row's maximum jump by far more than the threshold at a chosen tile (first, second, late);
     a second case scales ALL scores so that many rows cross the threshold at different tiles, and a third keeps every score
     far BELOW the initial reference (the first tile must re-centre, or the f16 probabilities would underflow)."""

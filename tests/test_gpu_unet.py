@@ -2,11 +2,14 @@
 against the CPU oracle on identical seeded weights and inputs.
 
 Tolerances: the HIP path stores activations in fp16 like the reference's fp16 inference; it is compared with the
-oracle run in fp16-storage emulation (`q = half-roundtrip`) at relative L2 error <= 2e-2 on a full UNet forward
-(tiny config: 3 levels, 5 transformer blocks) and with the pure-fp32 oracle at <= 4e-2.
+oracle run in fp16-storage emulation (`q = half-roundtrip`) at relative L2 error <= 5e-3 on a full UNet forward (measured
+1.3-1.6e-3 at every size from the tiny config to 2048 x 2048; the gate was 2e-2 until round 5) and with the pure-fp32
+oracle at <= 6e-3.  Every model-level gate goes through tests/_gates.gate, which logs the measured value beside its tolerance.
 """
 import pytest
 import torch
+
+from tests._gates import gate
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -61,8 +64,8 @@ def test_unet_forward_vs_oracle(tiny, H, W):
         r16 = o16.forward(x, 801.0, enc, te, tid, bbox, H / W, db)
         r32 = o32.forward(x, 801.0, enc, te, tid, bbox, H / W, db)
     assert out.shape == x.shape and torch.isfinite(out).all()
-    assert _rel(out, r16) <= 2e-2, _rel(out, r16)
-    assert _rel(out, r32) <= 4e-2, _rel(out, r32)
+    gate(f"tiny UNet {H}x{W} vs fp16-storage oracle", _rel(out, r16), 5e-3)
+    gate(f"tiny UNet {H}x{W} vs fp32 oracle", _rel(out, r32), 6e-3)
     # conditioning reaches the output through the HIP path too
     out2 = model(x.to(DEV), 401.0, enc.to(DEV), cross_attention_kwargs={"bbox": bbox, "aspect_ratio": H / W},
                  added_cond_kwargs={"text_embeds": te, "time_ids": tid}, dialog_bbox=db).sample
@@ -90,7 +93,7 @@ def test_unet_forward_any_latent_size(tiny, H, W):
     with torch.no_grad():
         r16 = o16.forward(x, 801.0, enc, te, tid, bbox, H / W, db)
     assert out.shape == x.shape and torch.isfinite(out).all()
-    assert _rel(out, r16) <= 2e-2, _rel(out, r16)
+    gate(f"tiny UNet {H}x{W} (any latent size) vs fp16-storage oracle", _rel(out, r16), 5e-3)
 
 
 @pytest.mark.parametrize("kind", ["euler", "ddim"])
@@ -128,7 +131,7 @@ def test_sampling_loop_vs_oracle(tiny, kind):
         assert int(eng.ctr.item()) == steps
         results.append(eng.latents.clone())
     assert torch.equal(results[0], results[1]), "hipGraph replay differs from eager launches"
-    assert _rel(results[0], ref) <= 3e-2, _rel(results[0], ref)
+    gate(f"4 fused {kind} steps (CFG 7.5) vs oracle sample_loop", _rel(results[0], ref), 1.2e-2)
 
 
 def test_unet_model_api_surface(hip_lib):
@@ -175,8 +178,8 @@ def test_unet_sdxl_shapes_one_forward(sdxl_model):
 def test_unet_sdxl_forward_vs_oracle(sdxl_model):
     """PARITY AT A BASELINE SHAPE: the full SDXL-size UNet (2.9 B parameters incl. the IP projections) at 512x512
     (64x64 latents, BASELINE.json configs[0]'s resolution), CFG batch 2 with character boxes and a dialog box: the HIP launch
-    plan vs the CPU oracle on identical weights and inputs.  Tolerance: relative L2 <= 2e-2 against the oracle with fp16
-    storage emulation (what the reference's fp16 inference does between ops), <= 3e-2 against pure fp32."""
+    plan vs the CPU oracle on identical weights and inputs.  Tolerance: relative L2 <= 5e-3 against the oracle with fp16
+    storage emulation (what the reference's fp16 inference does between ops; measured 1.5e-3), <= 6e-3 against pure fp32."""
     from oracle.unet_ref import UNetOracle
     cfg, m = sdxl_model
     x, enc, te, tid, bbox, db = _inputs(cfg, 2, 64, 64, seed=11)
@@ -194,8 +197,8 @@ def test_unet_sdxl_forward_vs_oracle(sdxl_model):
     assert y.shape == r16.shape and torch.isfinite(y).all()
     e16, e32 = _rel(y, r16), _rel(y, r32)
     print(f"SDXL 512x512 forward: rel-L2 vs fp16-storage oracle {e16:.3e}, vs fp32 oracle {e32:.3e}")
-    assert e16 <= 2e-2, e16
-    assert e32 <= 3e-2, e32
+    gate("SDXL UNet 512x512 vs fp16-storage oracle", e16, 5e-3)
+    gate("SDXL UNet 512x512 vs fp32 oracle", e32, 6e-3)
     # the conditional row must differ from the unconditional one (boxes / dialog reach the output at this size too)
     assert _rel(y[1], y[0]) > 1e-3
 
@@ -203,7 +206,7 @@ def test_unet_sdxl_forward_vs_oracle(sdxl_model):
 def test_unet_sdxl_forward_vs_oracle_1024(sdxl_model):
     """PARITY AT THE METRIC'S SHAPE (BASELINE.json metric / configs[1], [2]): full SDXL-size weights, 1024x1024
     (128x128 latents), CFG batch 2, 2 character boxes + 2 dialog boxes - the HIP launch plan vs the CPU oracle with
-    fp16-storage emulation, relative L2 <= 2e-2 (reference path: src/pipelines/pipeline_diffsensei.py:322-329 ->
+    fp16-storage emulation, relative L2 <= 5e-3 (measured 1.52e-3; reference path: src/pipelines/pipeline_diffsensei.py:322-329 ->
     src/models/unet.py:116-347).  Then the SAME two rows inside UNet batches of 32 and of 64 - 64 is the batch `python bench.py`
     runs (num_samples 32; rows 0..31 = the unconditional row, 32..63 = the conditional row): those launch plans dispatch to
     the large-problem kernels (gemm_pp at M = 65536 / 262144 with the V^T projections folded into the persistent walk at
@@ -253,9 +256,9 @@ def test_unet_sdxl_forward_vs_oracle_1024(sdxl_model):
     e2, e32, e64 = _rel(y, r16), _rel(torch.stack([y32[0], y32[16]]), r16), _rel(y64, r16)
     print(f"SDXL 1024x1024 forward: rel-L2 vs fp16-storage oracle: batch 2 {e2:.3e}, rows of batch 32 {e32:.3e}, "
           f"rows of batch 64 (the benched batch) {e64:.3e}")
-    assert e2 <= 2e-2, e2
-    assert e32 <= 2e-2, e32
-    assert e64 <= 2e-2, e64
+    gate("SDXL UNet 1024x1024 batch 2 vs fp16-storage oracle", e2, 5e-3)
+    gate("SDXL UNet 1024x1024 rows of batch 32 vs fp16-storage oracle", e32, 5e-3)
+    gate("SDXL UNet 1024x1024 rows of batch 64 (the benched batch) vs fp16-storage oracle", e64, 5e-3)
     assert _rel(y[1], y[0]) > 1e-3
 
 
