@@ -35,6 +35,8 @@ SIGNATURES = {
     "ds_device_info": (i32, [C.POINTER(i32), C.POINTER(i32), C.c_char_p, i32]),
     "ds_set_option": (i32, [C.c_char_p, i32]),
     "ds_debug_counter": (i32, [C.c_char_p, i32, C.POINTER(C.c_longlong)]),
+    "ds_gemm_t160_fits": (i32, [i32, i32, i32, i32]),
+    "ds_conv3x3_gn_chunks": (i32, [i32, i32, i32, i32, i32]),
     "ds_gemm_f16": (i32, [vp, i64, vp, i64, i32, vp, i64, vp, vp, i64, vp, i64, i32, i32, i32, i32, vp]),
     "ds_gemm_ln_f16": (i32, [vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp, i32, i32, i32, i32, vp]),
     "ds_ln_finalize": (i32, [vp, vp, i32, i32, i32, f32, vp]),

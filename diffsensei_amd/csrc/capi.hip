@@ -44,7 +44,7 @@ int ds_device_info(int* cu_count, int* lds_bytes, char* arch_name, int arch_name
 int ds_set_option(const char* key, int value) {
     DS_REQUIRE(key != nullptr, "ds_set_option: null key");
     if (strcmp(key, "gemm_variant") == 0) {
-        DS_REQUIRE(value >= 0 && value <= 10, "gemm_variant must be 0..10");
+        DS_REQUIRE(value >= 0 && value <= 11, "gemm_variant must be 0..11");
         ds_gemm_set_variant(value);
         return 0;
     }
@@ -77,6 +77,11 @@ int ds_set_option(const char* key, int value) {
         ds_llm_gemv_set_variant(value);
         return 0;
     }
+    if (strcmp(key, "gemm_t160") == 0) {
+        DS_REQUIRE(value >= 0 && value <= 1, "gemm_t160 must be 0 (auto) or 1 (off)");
+        ds_gemm_set_t160(value);
+        return 0;
+    }
     if (strcmp(key, "gemm_ring") == 0) {
         DS_REQUIRE(value >= 0 && value <= 1, "gemm_ring must be 0 (auto) or 1 (off)");
         ds_gemm_set_ring(value);
@@ -93,6 +98,8 @@ int ds_set_option(const char* key, int value) {
     ds_set_error("ds_set_option: unknown key '%s'", key);
     return -1;
 }
+
+int ds_gemm_t160_fits(int M, int N, int K, int batch) { return ds_gemm_t160_shape(M, N, K, batch) ? 1 : 0; }
 
 int ds_debug_counter(const char* name, int reset, long long* value) {
     DS_REQUIRE(name != nullptr, "ds_debug_counter: null name");
@@ -172,7 +179,8 @@ int ds_gemm_f16_batched(const void* x, int64_t ldx, int64_t sx, const void* w, i
 
 static int conv3x3_impl(const void* x, const void* w, const void* bias, const void* rowbias, int64_t rowbias_ld,
                         const void* residual, void* y, int B, int H_, int W_, int Cin, int Cout, int stride,
-                        int upsample, hipStream_t stream, int dtype = DS_DTYPE_F16, int out_h = 0, int out_w = 0) {
+                        int upsample, hipStream_t stream, int dtype = DS_DTYPE_F16, int out_h = 0, int out_w = 0,
+                        float* gn_partial = nullptr, int* gn_chunks_out = nullptr) {
     DS_REQUIRE(stride == 1 || stride == 2, "conv3x3: stride must be 1 or 2");
     DS_REQUIRE(!(upsample && stride != 1), "conv3x3: upsample with stride 2 is not a thing");
     DS_REQUIRE((out_h == 0 && out_w == 0) || (upsample && out_h > 0 && out_w > 0),
@@ -191,7 +199,19 @@ static int conv3x3_impl(const void* x, const void* w, const void* bias, const vo
     p.M = B * p.Hout * p.Wout; p.N = Cout; p.K = 9 * Cin; p.K1 = p.K;
     p.rows_per_group = p.Hout * p.Wout;
     p.dtype = dtype;
+    p.gn_partial = gn_partial;
+    if (gn_chunks_out) {   // host query only (ds_conv3x3_gn_chunks): no launch
+        *gn_chunks_out = ds_gemm_conv_gn_chunks(p);
+        return 0;
+    }
     return ds_launch_gemm(p, 1, stream);
+}
+
+int ds_conv3x3_gn_chunks(int B, int H_, int W_, int Cin, int Cout) {
+    int n = 0;
+    if (B <= 0 || H_ <= 0 || W_ <= 0 || Cin <= 0 || Cout <= 0) return 0;
+    conv3x3_impl(nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, B, H_, W_, Cin, Cout, 1, 0, nullptr, DS_DTYPE_F16, 0, 0, nullptr, &n);
+    return n;
 }
 
 int ds_conv3x3_f16(const void* x, const void* w, const void* bias, const void* rowbias, int64_t rowbias_ld,
@@ -482,6 +502,7 @@ static int run_op(const ds_op& o, hipStream_t st) {
             g.ln_stats = reinterpret_cast<const float*>(p[7]); g.ln_c = H(p[8]); g.stats_out = reinterpret_cast<float*>(p[9]);
             g.ln_swapped = i[8]; g.ln_bstride = l[10];
             g.ln_partial = i[9]; g.ln_eps = i[9] ? o.f[0] : g.ln_eps; g.ln_rows = l[11];
+            g.ln_nstrips = i[10]; g.stats_strip = i[11];
             return ds_launch_gemm(g, i[5] > 0 ? i[5] : 1, st);
         }
         case DS_OP_LN_FINALIZE:
@@ -489,12 +510,13 @@ static int run_op(const ds_op& o, hipStream_t st) {
                                          o.f[0], st);
         case DS_OP_CONV3X3:
             return conv3x3_impl(p[0], p[1], p[3], p[4], i[7], p[5], p[2], i[0], i[1], i[2], i[3], i[4], i[5], i[6], st,
-                                DS_DTYPE_F16, i[8], i[9]);
+                                DS_DTYPE_F16, i[8], i[9], reinterpret_cast<float*>(p[6]));
         case DS_OP_GROUPNORM: {
             GroupNormParams g;
             g.x1 = H(p[0]); g.x2 = H(p[1]); g.y = HM(p[2]); g.gamma = H(p[3]); g.beta = H(p[4]);
             g.ws = reinterpret_cast<float*>(p[5]);
             g.B = i[0]; g.HW = i[1]; g.C1 = i[2]; g.C2 = p[1] ? i[3] : 0; g.groups = i[4]; g.silu = i[5]; g.eps = o.f[0];
+            g.pre_chunks = i[6];
             return ds_launch_groupnorm(g, st);
         }
         case DS_OP_LAYERNORM:
@@ -583,7 +605,8 @@ int ds_op_describe(const ds_op* op, char* name, int name_len, double* flops, dou
             GemmParams g;
             g.M = i[0]; g.N = i[1]; g.K = i[2];
             g.ln_stats = reinterpret_cast<const float*>(op->p[7]); g.stats_out = reinterpret_cast<float*>(op->p[9]);
-            g.ln_swapped = i[8]; g.epi = i[4]; g.ln_partial = i[9];
+            g.ln_swapped = i[8]; g.epi = i[4]; g.ln_partial = i[9]; g.stats_strip = i[11];
+            g.A2 = H(op->p[1]); g.rowbias = H(op->p[5]);
             g.lda = g.ldw = g.K1 = g.K; g.ldc = g.N;
             const int batch = i[5] > 0 ? i[5] : 1;
             nm = ds_gemm_kernel_name(g, batch);

@@ -45,6 +45,48 @@ __device__ __attribute__((aligned(256))) char g_halo_zero_page[256];
 
 __device__ __forceinline__ int swz(int row, int chunk) { return ((chunk ^ ((row >> 1) & 7)) << 4); }
 
+// GroupNorm statistics of the block's output tile (GemmParams::gn_partial).  Stage 2 of the epilogue gives thread t the 8
+// channels of chunk t & 15 on rows (t >> 4) + 16 j: it sums the values it STORES (f16, after the residual) and their squares in
+// fp32; the four lanes of a wave that share a chunk meet in two shuffles, the four waves in `red` (4 KiB of LDS behind the
+// staging tile), and threads 0..127 write one (sum, sum of squares) per channel: partial[b][tile][n0 + ch] - the layout of
+// gn_stats_kernel, so gn_finalize_kernel / gn_apply_kernel run unchanged.  A fixed summation order: deterministic, and an
+// image's statistics do not depend on its position in the batch.
+template <typename V8>
+__device__ __forceinline__ void gn_accumulate(const V8& v, float (&gs)[8], float (&gq)[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float f = (float)v[e];
+        gs[e] += f;
+        gq[e] = fmaf(f, f, gq[e]);
+    }
+}
+__device__ __forceinline__ void gn_emit(const GemmParams& p, float (&gs)[8], float (&gq)[8], char* red_bytes, int tid, int b,
+                                        int tile_in_image, int n0) {
+    float* const red = reinterpret_cast<float*>(red_bytes);
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        gs[e] += __shfl_xor(gs[e], 16, 64);
+        gq[e] += __shfl_xor(gq[e], 16, 64);
+        gs[e] += __shfl_xor(gs[e], 32, 64);
+        gq[e] += __shfl_xor(gq[e], 32, 64);
+    }
+    if (lane < 16) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            red[(wave * 128 + lane * 8 + e) * 2] = gs[e];
+            red[(wave * 128 + lane * 8 + e) * 2 + 1] = gq[e];
+        }
+    }
+    __syncthreads();
+    if (tid < 128 && n0 + tid < p.N) {
+        const float s = (red[tid * 2] + red[(128 + tid) * 2]) + (red[(256 + tid) * 2] + red[(384 + tid) * 2]);
+        const float q = (red[tid * 2 + 1] + red[(128 + tid) * 2 + 1]) + (red[(256 + tid) * 2 + 1] + red[(384 + tid) * 2 + 1]);
+        f32x2 o2 = {s, q};
+        *reinterpret_cast<f32x2*>(p.gn_partial + (((long)b * p.gn_chunks + tile_in_image) * p.N + n0 + tid) * 2) = o2;
+    }
+}
+
 template <typename T>  // half_t (UNet) or bf16_t (VAE decoder)
 __global__ __launch_bounds__(256, 3) void conv_halo_kernel(const GemmParams p) {
     typedef typename Elt<T>::v8 V8;
@@ -210,6 +252,9 @@ __global__ __launch_bounds__(256, 3) void conv_halo_kernel(const GemmParams p) {
     }
     __syncthreads();
     const T* const Rp = reinterpret_cast<const T*>(p.residual);
+    float gs[8], gq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) gs[e] = gq[e] = 0.f;
 #pragma unroll 1
     for (int j0 = 0; j0 < 8; j0 += 4) {
         long mrow[4];
@@ -241,8 +286,10 @@ __global__ __launch_bounds__(256, 3) void conv_halo_kernel(const GemmParams p) {
                 }
             }
             if (ok[u]) *reinterpret_cast<V8*>(reinterpret_cast<T*>(p.C) + mrow[u] * p.ldc + ncol[u]) = v;
+            if (p.gn_partial && ok[u]) gn_accumulate(v, gs, gq);
         }
     }
+    if (p.gn_partial) gn_emit(p, gs, gq, smem + 128 * CS_STRIDE, tid, b, ty * tiles_x + tx, n0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -254,11 +301,14 @@ __global__ __launch_bounds__(256, 3) void conv_halo_kernel(const GemmParams p) {
 // 76 KiB -> two blocks per CU.  The patch is single-buffered: at a slice boundary the block waits for the new patch
 // while the co-resident block computes.
 // ---------------------------------------------------------------------------------------------------------------
+static_assert(128 * CS_STRIDE + 4096 <= PROWS * 128 + BN * 128, "conv_halo_kernel: staging tile + GroupNorm partials exceed its LDS");
 constexpr int PH2 = 16;
 constexpr int HROWS2 = (PH2 + 2) * HWD;   // 324 patch pixels
 constexpr int NPIECE2 = (HROWS2 + 7) / 8;  // 41 LDS-DMA pieces of 8 rows
 constexpr int PPW2 = (NPIECE2 + 3) / 4;    // 11 per wave
 constexpr int PBYTES2 = PPW2 * 4 * 1024;   // 44 KiB
+
+static_assert(256 * CS_STRIDE + 4096 <= PBYTES2 + 2 * BN * 128, "conv_halo256_kernel: staging tile + GroupNorm partials exceed its LDS");
 
 template <int V>
 struct IC2 {
@@ -479,6 +529,9 @@ __global__ __launch_bounds__(256, 2) void conv_halo256_kernel(const GemmParams p
     else body(IC2<0>{});
     __syncthreads();
     const T* const Rp = reinterpret_cast<const T*>(p.residual);
+    float gs[8], gq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) gs[e] = gq[e] = 0.f;
 #pragma unroll 1
     for (int j0 = 0; j0 < 16; j0 += 4) {
         long mrow[4];
@@ -510,8 +563,10 @@ __global__ __launch_bounds__(256, 2) void conv_halo256_kernel(const GemmParams p
                 }
             }
             if (ok[u]) *reinterpret_cast<V8*>(reinterpret_cast<T*>(p.C) + mrow[u] * p.ldc + ncol[u]) = v;
+            if (p.gn_partial && ok[u]) gn_accumulate(v, gs, gq);
         }
     }
+    if (p.gn_partial) gn_emit(p, gs, gq, smem + 256 * CS_STRIDE, tid, b, ty * tiles_x + tx, n0);
 }
 
 static thread_local int g_halo_variant = 0;  // 0 auto, 1 force the 8 x 16 kernel, 2 force the 16 x 16 kernel (where its shape rule holds)
@@ -529,18 +584,37 @@ bool ds_conv_halo_applicable(const GemmParams& p) {
     return batch * p.Hin * p.Win * p.Cin < (1L << 31);
 }
 
+// 16 x 16 patches once they still fill the chip twice over (two blocks per CU): large batches / resolutions
+static bool halo_big(const GemmParams& p) {
+    const int batch = p.M / (p.Hout * p.Wout);
+    const int ty16 = (p.Hout + PH2 - 1) / PH2, txs = (p.Wout + PW - 1) / PW;
+    const long tiles256 = (long)batch * ty16 * txs * ((p.N + BN - 1) / BN);
+    return g_halo_variant == 2 || (g_halo_variant == 0 && tiles256 >= 1024);
+}
+
+// Pixel tiles per image of the variant ds_launch_conv_halo runs on this problem = partial-sum chunks the GroupNorm behind it
+// has to add up; 0 when the statistics cannot come from the convolution (the GroupNorm workspace holds 128 chunks per image).
+int ds_conv_halo_gn_chunks(const GemmParams& p) {
+    if (!ds_conv_halo_applicable(p) || p.dtype != DS_DTYPE_F16) return 0;
+    const int ph = halo_big(p) ? PH2 : PH;
+    const long n = (long)((p.Hout + ph - 1) / ph) * ((p.Wout + PW - 1) / PW);
+    return n <= 128 ? (int)n : 0;
+}
+
 int ds_launch_conv_halo(const GemmParams& p0, hipStream_t stream) {
     GemmParams p = p0;
     DS_REQUIRE(ds_conv_halo_applicable(p), "conv_halo: shape not supported");
     const int batch = p.M / (p.Hout * p.Wout);
     p.tiles_n = (p.N + BN - 1) / BN;
-    // 16 x 16 patches once they still fill the chip twice over (two blocks per CU): large batches / resolutions
     const int ty8 = (p.Hout + PH - 1) / PH, ty16 = (p.Hout + PH2 - 1) / PH2, txs = (p.Wout + PW - 1) / PW;
-    const long tiles256 = (long)batch * ty16 * txs * p.tiles_n;
-    const bool big = g_halo_variant == 2 || (g_halo_variant == 0 && tiles256 >= 1024);
+    const bool big = halo_big(p);
+    if (p.gn_partial) {
+        p.gn_chunks = ds_conv_halo_gn_chunks(p);
+        DS_REQUIRE(p.gn_chunks > 0, "conv_halo: GroupNorm statistics requested for a problem with more than 128 pixel tiles per image");
+    }
     if (big) {
         p.tiles_m = batch * ty16 * txs;
-        const size_t lds2 = PBYTES2 + 2 * BN * 128;  // 76 KiB; the 256 x 272 B epilogue tile fits inside
+        const size_t lds2 = PBYTES2 + 2 * BN * 128;  // 76 KiB; the 256 x 272 B epilogue tile (68 KiB) + 4 KiB of GroupNorm partials fit inside
         static unsigned long long attr_devs = 0;
         if (ds_first_on_device(attr_devs)) {
             DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo256_kernel<half_t>),
@@ -555,7 +629,7 @@ int ds_launch_conv_halo(const GemmParams& p0, hipStream_t stream) {
         return 0;
     }
     p.tiles_m = batch * ty8 * txs;
-    const size_t lds = PROWS * 128 + BN * 128;  // 40 KiB; the 128 x 272 B epilogue tile fits inside
+    const size_t lds = PROWS * 128 + BN * 128;  // 40 KiB; the 128 x 272 B epilogue tile (34 KiB) + 4 KiB of GroupNorm partials fit inside
     dim3 grid(p.tiles_m * p.tiles_n);
     if (p.dtype == DS_DTYPE_BF16) hipLaunchKernelGGL(conv_halo_kernel<bf16_t>, grid, dim3(256), lds, stream, p);
     else hipLaunchKernelGGL(conv_halo_kernel<half_t>, grid, dim3(256), lds, stream, p);

@@ -36,21 +36,38 @@ struct GemmParams {
     int ln_partial = 0;                // consumer on the 128-wide LDS-DMA kernels (gemm.hip, "Fused LayerNorm"): ln_stats points at the
     float ln_eps = 1e-5f;              //   producer's PARTIALS [K/64][rows] float2 and the epilogue finalises its own rows (eps = ln_eps)
     long ln_rows = 0;                  //   operand-swapped form only: rows of the normalised matrix over all batch items (stride of the partials)
+    int ln_nstrips = 0;                // consumer of partials: strips per row to sum (0 = K / 64; 2 K / 64 behind a 32-column producer)
+    int stats_strip = 0;               // producer: columns per statistics strip (0 = 64).  32 is what gemm_t160_kernel emits - its
+                                       //   160-column tiles hold no whole 64-column strips -, [N/32][M] float2; the launch planner
+                                       //   requests it explicitly (and tells the consumers: ln_nstrips), a direct caller never gets it
+    // ---- GroupNorm statistics out of the producing convolution (conv_halo.hip, round 6): the halo-patch kernels also write, per
+    // (image, pixel tile, output channel), the (sum, sum of squares) of the f16 values they store - the partial-sum layout of
+    // gn_stats_kernel, [B][gn_chunks][Cout] float2 - so the GroupNorm that follows skips its statistics pass (one read of x less)
+    float* gn_partial = nullptr;
+    int gn_chunks = 0;                 // pixel tiles per image of the kernel variant the dispatch picks (ds_conv_halo_gn_chunks)
     int dtype = DS_DTYPE_F16;  // element type of A / W / C / bias / residual (the pointers are 2-byte opaque): bf16 = VAE path
     int debug = 0;  // ablation only (ds_set_option "gemm_debug"): 1 skip MFMA, 2 skip tile loads — results are garbage
 };
 int ds_launch_gemm(const GemmParams& p, int batch, hipStream_t stream);
+int ds_gemm_conv_gn_chunks(const GemmParams& p);  // gemm.hip: GroupNorm partial chunks per image the conv dispatch would emit (0: none)
 int ds_gemm_ln_kind(int M, int N, int K, int batch, int epi);  // fused LayerNorm: 1 = gemm_pp_kernel, 2 = 128-wide kernels, 0 = none
 bool ds_gemm_pp_applicable(const GemmParams& p);  // gemm_pp.hip: 256 x 256 ping-pong kernel takes this shape
 int ds_launch_gemm_pp(const GemmParams& p, int batch, hipStream_t stream);
 bool ds_conv_halo_applicable(const GemmParams& p);  // conv_halo.hip: halo-patch 3x3 convolution takes this shape
 int ds_launch_conv_halo(const GemmParams& p, hipStream_t stream);
+int ds_conv_halo_gn_chunks(const GemmParams& p);  // pixel tiles per image of the variant ds_launch_conv_halo would run; 0: no statistics (too many tiles / not applicable)
 void ds_conv_halo_set_variant(int v);  // 0 auto, 1 8x16-pixel blocks, 2 16x16-pixel blocks
 const char* ds_gemm_kernel_name(const GemmParams& p, int batch);  // the instantiation ds_launch_gemm dispatches to
 void ds_gemm_set_debug(int v);
 void ds_gemm_set_ring(int v);     // 0 auto (ring-buffered kernel for small grids), 1 never
 void ds_gemm_pp_set_even(int v);  // experiment: 1 = persistent grid shrunk so that every round of tiles is full
 void ds_gemm_set_variant(int v);  // 0 auto, 1 register staging only, 2 glds (BM <= 128), 3 glds, BM = 256 when large
+// gemm_t160.hip: 64 x 160 tiles, one block per CU, for the small-batch projections of the 1280-channel level
+bool ds_gemm_t160_shape(int M, int N, int K, int batch);           // the automatic dispatch rule (host logic only)
+bool ds_gemm_t160_possible(const GemmParams& p, int batch);        // what the kernel can run at all (gemm_variant 11)
+bool ds_gemm_t160_applicable(const GemmParams& p, int batch);      // possible && shape rule
+int ds_launch_gemm_t160(const GemmParams& p, hipStream_t stream);
+void ds_gemm_set_t160(int v);     // 0 auto, 1 never
 
 // ---- VAE decoder only (vae.hip) ---------------------------------------------------------------------
 int ds_launch_wide_attn(const void* q, const void* k, const void* vt, void* o, int B, int N, int n_valid, int dtype,
@@ -73,6 +90,8 @@ struct GroupNormParams {
     int silu = 0;
     int dtype = DS_DTYPE_F16;  // bf16: VAE decoder path (x, y, gamma, beta are 2-byte opaque pointers)
     float out_scale = 1.0f;    // y = act(norm(x)) * out_scale (the VAE decoder's scaled-fp16 mode; exact for powers of two)
+    int pre_chunks = 0;        // > 0: ws already holds [B][pre_chunks][C] float2 partial sums (written by the producing convolution,
+                               //      GemmParams::gn_partial): no statistics launch
 };
 size_t ds_groupnorm_ws_floats(int B, int C);
 void ds_groupnorm_set_variant(int v);  // 0 auto (round-4 geometry), 1 round-3 geometry (A/B)

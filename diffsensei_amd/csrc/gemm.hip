@@ -21,7 +21,7 @@
 #include "ds_common.h"
 #include "ds_kernels.h"
 
-static thread_local int g_gemm_variant = 0;  // 0 auto; A/B: 1 register staging, 2 two-buffer glds, 3 ping-pong 256x256, 7 two-buffer BM 64, 8/9 one-buffer glds (BM 128/64), 10 halo conv
+static thread_local int g_gemm_variant = 0;  // 0 auto; A/B: 1 register staging, 2 two-buffer glds, 3 ping-pong 256x256, 7 two-buffer BM 64, 8/9 one-buffer glds (BM 128/64), 10 halo conv, 11 64x160 tiles (gemm_t160.hip)
 void ds_gemm_set_variant(int v) { g_gemm_variant = v; }
 static thread_local int g_gemm_ring = 0;  // 0 auto, 1 never use the ring-buffered small-grid kernel (A/B)
 void ds_gemm_set_ring(int v) { g_gemm_ring = v; }
@@ -116,7 +116,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x16 (&acc)[WR /
     for (int mi = 0; mi < MI; ++mi) ln_mean[mi] = 0.f, ln_rstd[mi] = 1.f;
     if constexpr (LNF) {
         if (ln_in) {
-            const int strips = p.K >> 6;
+            const int strips = p.ln_nstrips > 0 ? p.ln_nstrips : (p.K >> 6);
             float sa[MI][2], qa[MI][2];
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) sa[mi][0] = sa[mi][1] = qa[mi][0] = qa[mi][1] = 0.f;
@@ -162,7 +162,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x16 (&acc)[WR /
     if constexpr (LNF) {
         if (ln_col) {
             if (tid < BN) {
-                const int strips = p.K >> 6;
+                const int strips = p.ln_nstrips > 0 ? p.ln_nstrips : (p.K >> 6);
                 const long row = min(bz * p.ln_bstride + n0 + tid, p.ln_rows - 1);
                 const f32x2* part = reinterpret_cast<const f32x2*>(p.ln_stats) + row;
                 float sa[4] = {0.f, 0.f, 0.f, 0.f}, qa[4] = {0.f, 0.f, 0.f, 0.f};
@@ -768,7 +768,7 @@ int launch_ring(const GemmParams& p0, int batch, hipStream_t stream) {
     return 0;
 }
 
-enum Kind { K_REG, K_GLDS2, K_GLDS1, K_PP, K_HALO, K_RING };
+enum Kind { K_REG, K_GLDS2, K_GLDS1, K_PP, K_HALO, K_RING, K_T160 };
 struct Choice {
     Kind kind;
     int bm;   // rows of the block tile
@@ -801,6 +801,9 @@ Choice choose(const GemmParams& p, int batch) {
         case 3:
             if (ds_gemm_pp_applicable(p)) { c.kind = K_PP; c.bm = 256; return c; }
             break;
+        case 11:
+            if (ds_gemm_t160_possible(p, batch)) { c.kind = K_T160; c.bm = 64; return c; }
+            break;
         case 2: c.kind = K_GLDS2; return c;
         case 7: c.kind = K_GLDS2; c.bm = 64; return c;
         case 8: c.kind = K_GLDS1; return c;
@@ -813,6 +816,10 @@ Choice choose(const GemmParams& p, int batch) {
     }
     if (conv) {
         c.kind = K_GLDS1;
+        c.bm = 64;
+    } else if (ds_gemm_t160_applicable(p, batch)) {
+        // 64 x 160 tiles = exactly one block per CU where the 64 x 128 grid leaves a quarter of the CUs with two (gemm_t160.hip)
+        c.kind = K_T160;
         c.bm = 64;
     } else if (small) {
         c.kind = K_GLDS1;
@@ -870,7 +877,7 @@ int ds_gemm_ln_kind(int M, int N, int K, int batch, int epi) {
     if (g_gemm_variant != 0) return 0;
     const Kind k = choose(p, batch).kind;
     if (k == K_PP) return (M % 256 == 0 && N % 256 == 0) ? 1 : 0;
-    if ((k == K_GLDS1 || k == K_GLDS2 || k == K_RING) && K % 64 == 0) return 2;   // (a PRODUCER also needs N % 128 == 0 and no batch)
+    if ((k == K_GLDS1 || k == K_GLDS2 || k == K_RING || k == K_T160) && K % 64 == 0) return 2;   // (a PRODUCER also needs N % 128 == 0 and no batch)
     return 0;
 }
 
@@ -884,6 +891,7 @@ const char* ds_gemm_kernel_name(const GemmParams& p, int batch) {
         case K_PP: return "gemm_pp_kernel<0,0>";
         case K_HALO: return "conv_halo_kernel";
         case K_RING: return c.bm == 4 ? "gemm_glds_kernel<64,false,4>" : "gemm_glds_kernel<64,false,3>";
+        case K_T160: return "gemm_t160_kernel";
         case K_GLDS1:
             if (c.bm == 128) return conv ? "gemm_glds_kernel<128,true,1>" : "gemm_glds_kernel<128,false,1>";
             return conv ? "gemm_glds_kernel<64,true,1>" : "gemm_glds_kernel<64,false,1>";
@@ -894,6 +902,12 @@ const char* ds_gemm_kernel_name(const GemmParams& p, int batch) {
             if (c.bm == 128) return conv ? "gemm_f16_kernel<128,true>" : "gemm_f16_kernel<128,false>";
             return conv ? "gemm_f16_kernel<64,true>" : "gemm_f16_kernel<64,false>";
     }
+}
+
+// GroupNorm statistics out of a 3x3 convolution: only the halo-patch kernels emit them, so the answer follows the dispatch
+int ds_gemm_conv_gn_chunks(const GemmParams& p) {
+    if (!p.conv || choose(p, 1).kind != K_HALO) return 0;
+    return ds_conv_halo_gn_chunks(p);
 }
 
 int ds_launch_gemm(const GemmParams& p_in, int batch, hipStream_t stream) {
@@ -913,6 +927,8 @@ int ds_launch_gemm(const GemmParams& p_in, int batch, hipStream_t stream) {
     }
     if (p.epi == EPI_GEGLU) DS_REQUIRE(p.N % 128 == 0, "geglu: packed N (%d) must be a multiple of 128", p.N);
     Choice c = choose(p, batch);
+    DS_REQUIRE(!p.gn_partial || (conv && c.kind == K_HALO && p.dtype == DS_DTYPE_F16),
+               "conv3x3: GroupNorm statistics come out of the halo-patch kernels only (ask ds_conv3x3_gn_chunks first)");
     if (p.ln_stats || p.ln_c || p.stats_out) {
         // Fused LayerNorm.  The planner asks ds_gemm_ln_fusable which form the dispatch gives a shape and builds the pair
         // accordingly; a direct call is served by whichever family implements the role it names:
@@ -922,7 +938,7 @@ int ds_launch_gemm(const GemmParams& p_in, int batch, hipStream_t stream) {
         DS_REQUIRE(!conv && p.dtype == DS_DTYPE_F16 && !p.A2 && !p.rowbias, "gemm: fused LayerNorm is a plain f16 GEMM feature");
         const bool pp_ok = ds_gemm_pp_applicable(p) && (p.ln_swapped || (p.M % 256 == 0 && p.N % 256 == 0));
         const bool wide_ok = batch == 1 && p.N % 128 == 0 && p.K % 64 == 0;
-        const bool wide_kind = c.kind == K_GLDS1 || c.kind == K_GLDS2 || c.kind == K_RING;
+        const bool wide_kind = c.kind == K_GLDS1 || c.kind == K_GLDS2 || c.kind == K_RING || c.kind == K_T160;
         auto force_wide = [&]() {
             if (!wide_kind) { c.kind = K_GLDS1; c.bm = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) < 384 ? 64 : 128; }
         };
@@ -957,6 +973,7 @@ int ds_launch_gemm(const GemmParams& p_in, int batch, hipStream_t stream) {
         case K_PP: return ds_launch_gemm_pp(p, batch, stream);
         case K_HALO: return ds_launch_conv_halo(p, stream);
         case K_RING: return c.bm == 4 ? launch_ring<4>(p, batch, stream) : launch_ring<3>(p, batch, stream);
+        case K_T160: return ds_launch_gemm_t160(p, stream);
         case K_GLDS1:
             if (c.bm == 128)
                 return conv ? launch_glds1<128, true>(p, batch, stream) : launch_glds1<128, false>(p, batch, stream);

@@ -1,0 +1,302 @@
+// fp16 MFMA GEMM for the SMALL-BATCH projections of the 1280-channel level: C[M,N] = A[M,K] W[N,K]^T (+bias, +residual, fused-
+// LayerNorm producer / consumer), block tile 64 x 160 x 64, five waves, a ring of five LDS stages filled by LDS-DMA.
+// Same GemmParams and epilogue semantics as gemm.hip (the reference call sites are listed there: the nn.Linear projections of
+// diffusers' BasicTransformerBlock reached from reference src/models/unet.py:244-338 / attention_processor.py:56-84,207-261).
+//
+// Why a third tile shape (round 6; VERDICT r5 item 2: the reference's own call shape - one request, num_samples 1,
+// scripts/demo/gradio_wo_mllm.py:45-62 - ran its dominant kernel at 0.13 of the matrix peak for four rounds).  At UNet batch 2 and
+// 1024 x 1024 the level-2 projections are M = 2048, N = 1280, K = 1280 | 5120.  The 64 x 128 ring kernel (gemm_glds_kernel<64,
+// false,3>) cuts that into 32 x 10 = 320 blocks for 256 CUs: 64 CUs hold two blocks, 192 hold one, and the launch lasts as long
+// as a doubly-loaded CU needs - whose L2 -> LDS fill runs at ~72 GB/s while the other three quarters of the chip idle at half
+// that (profiles/r05_weight_prefetch_potential.txt: 20.0 / 52.6 us with hot weights for 0.56 / 2.2 MB of fill per block pair).
+// Cross-CU split-K to even that out is priced out on this part (a seam costs 5-13 us, MI355X_MICROARCH.md "splitk-seam";
+// measured in round 2: 35 -> 144 us).  A 64 x 160 tile gives 32 x 8 = EXACTLY 256 blocks - one per CU, no reduction, no
+// workspace - with 6 % fewer fill bytes per flop; the single block then has to keep the CU's fill path busy by itself, hence
+// five stages (four k-tiles = 112 KiB in flight per CU; 141 KiB of LDS).
+//
+// Structure.  Five waves; wave w owns the 32-column strip w of the tile and all 64 rows (2 accumulator blocks of
+// v_mfma_f32_32x32x16_f16, operands swapped like every GEMM here: a lane ends with tile row l & 31 and 4-column groups).
+// A k-tile is 28 one-KiB LDS-DMA pieces (8 of A, 20 of W); wave w moves pieces w, w + 5, ... (six per wave: waves 3 and 4 pad
+// with a dummy piece, so the counted vmcnt waits are the same for everyone).  One barrier per k-tile, as in the ring kernel.
+// Epilogue through LDS (row stride 336 B: conflict-free 8-byte writes), then 16-byte stores of whole 320-byte row segments.
+// Fused LayerNorm: producer statistics come per row and 32-COLUMN strip (a 160-column tile does not hold whole 64-column strips:
+// GemmParams::stats_strip = 32 is an explicit request of the launch planner, and consumers are told the strip count:
+// GemmParams::ln_nstrips); the consumer form finalises its own rows from the partial sums like the 128-wide kernels (gemm.hip).
+#include "ds_common.h"
+#include "ds_kernels.h"
+
+static thread_local int g_t160 = 0;  // 0 auto, 1 never (A/B: ds_set_option "gemm_t160")
+void ds_gemm_set_t160(int v) { g_t160 = v; }
+
+namespace {
+
+constexpr int TM = 64, TN = 160;
+constexpr int STAGE_B = (TM + TN) * 128;   // 28 KiB: A rows 0..63 (8 pieces), then W rows 0..159 (20 pieces)
+constexpr int CS = 336;                    // bytes per row of the epilogue staging tile (160 f16 + 8 pad)
+typedef __attribute__((address_space(3))) void lds_void;
+
+__device__ __forceinline__ int swz(int row, int chunk) { return ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+template <int STAGES>
+__global__ __launch_bounds__(320, 1) void gemm_t160_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    int tm, tn;
+    tile_coords(tile, p.tiles_m, p.tiles_n, tm, tn);
+    const int m0 = tm * TM, n0 = tn * TN;
+    const unsigned lds0 = (unsigned)(size_t)(lds_void*)smem;
+    const unsigned dummy = lds0 + STAGES * STAGE_B;   // one KiB nobody reads: the sixth piece of waves 3 and 4
+
+    // ---- staging: piece q = wave + 5 j covers LDS rows 8 q .. 8 q + 7 of the stage (A rows first); the DMA destination is
+    // lane-linear, so the XOR swizzle goes on the lane's SOURCE chunk.  Rows past M re-read the last row (never stored).
+    unsigned off[6];
+    {
+        const int lrow = lane >> 3, slot = lane & 7;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int q = wave + 5 * j;
+            if (q < 8) {
+                const int row = q * 8 + lrow;
+                const int chunk = slot ^ ((row >> 1) & 7);
+                const int mr = min(m0 + row, p.M - 1) - m0;
+                off[j] = (unsigned)(mr * (int)p.lda + chunk * 8) * 2u;
+            } else if (q < 28) {
+                const int row = (q - 8) * 8 + lrow;
+                const int chunk = slot ^ ((row >> 1) & 7);
+                off[j] = (unsigned)(row * (int)p.ldw + chunk * 8) * 2u;
+            } else {
+                off[j] = (unsigned)(min(lrow, p.M - 1 - m0) * (int)p.lda + slot * 8) * 2u;   // dummy: the tile's first rows again
+            }
+        }
+    }
+    const half_t* const a_tile = p.A + (long)m0 * p.lda;
+    const half_t* const w_tile = p.W + (long)n0 * p.ldw;
+    auto issue = [&](int kt, int buf) {
+        const half_t* const a = a_tile + kt * 64;
+        const half_t* const w = w_tile + kt * 64;
+        const unsigned dst = lds0 + (unsigned)buf * STAGE_B;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int q = wave + 5 * j;
+            lds_dma16(q < 8 || q >= 28 ? (const void*)a : (const void*)w, off[j], q < 28 ? dst + (unsigned)q * 1024u : dummy);
+        }
+    };
+
+    // ---- fragment addresses (bytes into a stage)
+    unsigned fa[4], fb[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        fa[kk] = l31 * 128 + swz(l31, kk * 2 + lhi);
+        const int rb = wave * 32 + l31;
+        fb[kk] = TM * 128 + rb * 128 + swz(rb, kk * 2 + lhi);
+    }
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
+
+    const int nk = p.K / 64;
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+        if (s < nk) issue(s, s);
+    int buf = 0, fill = STAGES - 1;
+    for (int kt = 0; kt < nk; ++kt) {
+        // k-tile kt has landed once all but the newer k-tiles' pieces (six per wave and k-tile) are done
+        const int newer = min(STAGES - 2, nk - 1 - kt);
+        static_assert(STAGES == 5, "the counted waits below cover up to three newer k-tiles");
+        if (newer >= 3) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+        else if (newer == 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (newer == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // ... for every wave; and every wave has retired its reads of k-tile kt - 1
+        asm volatile("" ::: "memory");
+        if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1, fill);
+        const char* const st = smem + buf * STAGE_B;
+        h8 af[4][2], bf[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            bf[kk] = *reinterpret_cast<const h8*>(st + fb[kk]);
+            af[kk][0] = *reinterpret_cast<const h8*>(st + fa[kk]);
+            af[kk][1] = *reinterpret_cast<const h8*>(st + fa[kk] + 32 * 128);
+        }
+        // all twelve fragment reads are in flight before the first MFMA (left alone the scheduler, saving registers this kernel
+        // has plenty of, put every read right in front of its MFMA: eight exposed LDS round trips per k-tile); the compiler's
+        // counted lgkmcnt waits then release the MFMAs in read order
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[kk], af[kk][mi], acc[mi], 0, 0, 0);
+        buf = buf + 1 == STAGES ? 0 : buf + 1;
+        fill = fill + 1 == STAGES ? 0 : fill + 1;
+    }
+    __syncthreads();   // the last stage has been read by everyone: the staging tile of the epilogue may overwrite it
+
+    // ---- epilogue, stage 1: bias (or the fused-LayerNorm consumer form), round to f16, park the tile in LDS as [m][n].
+    // D layout (operands swapped): register r of a block is tile column (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of the wave's strip.
+    char* const sC = smem;
+    const int nw = n0 + wave * 32;
+    h4 bq[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bq[g] = h4{0, 0, 0, 0};
+    if (p.bias) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const h4*>(p.bias + nw + 8 * g + 4 * lhi);
+    }
+    const bool ln_in = p.ln_stats != nullptr;
+    float ln_mean[2] = {0.f, 0.f}, ln_rstd[2] = {1.f, 1.f};
+    h8 cq[4];
+    if (ln_in) {
+        // consumer: (mean, rstd) of the lane's two rows from the producer's partial sums, every load in flight at once; the
+        // summation order is the one of gemm.hip's consumer / ln_finalize_kernel (four interleaved chains, (0 + 1) + (2 + 3)):
+        // the two half-waves hold the same rows and take two chains each
+        const int strips = p.ln_nstrips > 0 ? p.ln_nstrips : (p.K >> 6);
+        float sa[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, qa[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+        constexpr int JJ = 5;
+        for (int base = 0; base < strips; base += 4 * JJ) {
+            f32x2 t[2][2][JJ];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const int m = min(m0 + mi * 32 + l31, p.M - 1);
+                const f32x2* part = reinterpret_cast<const f32x2*>(p.ln_stats) + m;
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+                    for (int jj = 0; jj < JJ; ++jj) {
+                        const int j = base + 2 * lhi + cc + 4 * jj;
+                        t[mi][cc][jj] = part[(long)min(j, strips - 1) * p.M];
+                    }
+            }
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+                    for (int jj = 0; jj < JJ; ++jj) {
+                        const bool in = base + 2 * lhi + cc + 4 * jj < strips;
+                        sa[mi][cc] += in ? t[mi][cc][jj][0] : 0.f;
+                        qa[mi][cc] += in ? t[mi][cc][jj][1] : 0.f;
+                    }
+        }
+        const float inv_c = 1.0f / (float)p.K;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const float s2 = sa[mi][0] + sa[mi][1], q2 = qa[mi][0] + qa[mi][1];
+            const float s = s2 + __shfl_xor(s2, 32, 64), q = q2 + __shfl_xor(q2, 32, 64);
+            ln_mean[mi] = s * inv_c;
+            ln_rstd[mi] = rsqrtf(fmaxf(fmaf(-ln_mean[mi], ln_mean[mi], q * inv_c), 0.f) + p.ln_eps);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) cq[g] = *reinterpret_cast<const h8*>(p.ln_c + 2 * (nw + 8 * g + 4 * lhi));
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int ml = mi * 32 + l31;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float v[4];
+            if (ln_in) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float nc = (float)cq[g][2 * e] + (float)cq[g][2 * e + 1];   // -c_n
+                    v[e] = fmaf(fmaf(ln_mean[mi], nc, acc[mi][4 * g + e]), ln_rstd[mi], (float)bq[g][e]);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[mi][4 * g + e] + (float)bq[g][e];
+            }
+            h4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (half_t)v[e];
+            *reinterpret_cast<h4*>(sC + ml * CS + (wave * 32 + 8 * g + 4 * lhi) * 2) = o;
+        }
+    }
+    __syncthreads();
+    // ---- stage 2: thread t takes 16-byte chunk t % 20 of rows t / 20 + 16 j: 320-byte row segments per 20 lanes
+    const int c = tid % 20, r16 = tid / 20;
+    const int n = n0 + c * 8;
+    h8 rv[4];
+    if (p.residual) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = min(m0 + r16 + 16 * j, p.M - 1);
+            rv[j] = *reinterpret_cast<const h8*>(p.residual + (long)m * p.ldr + n);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = r16 + 16 * j, m = m0 + row;
+        h8 v = *reinterpret_cast<const h8*>(sC + row * CS + c * 16);
+        if (p.residual) v = v + rv[j];   // v_pk_add_f16: the same number as (f16)((float)a + (float)b) (tests/test_f16_add_equivalence.py)
+        if (m < p.M) *reinterpret_cast<h8*>(p.C + (long)m * p.ldc + n) = v;
+        if (p.stats_out) {
+            // producer: (sum, sum of squares) of the 32-column strip c >> 2 of this row = the four lanes of a quad
+            float s1 = 0.f, q1 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float f = (float)v[e];
+                s1 += f;
+                q1 = fmaf(f, f, q1);
+            }
+            s1 += ds_dpp_f32<0xB1>(s1);
+            q1 += ds_dpp_f32<0xB1>(q1);
+            s1 += ds_dpp_f32<0x4E>(s1);
+            q1 += ds_dpp_f32<0x4E>(q1);
+            if ((c & 3) == 0 && m < p.M) {
+                f32x2 o2 = {s1, q1};
+                *reinterpret_cast<f32x2*>(p.stats_out + 2 * ((long)(n >> 5) * p.M + m)) = o2;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// Shape rule (pure host logic; the launch planner asks it through ds_gemm_t160_shape before it requests 32-column statistics):
+// a plain f16 GEMM whose 64 x 160 grid covers between 5/8 and all of the CUs with one block each, while the 64 x 128 grid
+// would leave some CUs with two blocks and the rest with one.
+bool ds_gemm_t160_shape(int M, int N, int K, int batch) {
+    if (g_t160 == 1 || batch != 1 || M <= 0 || N <= 0 || K < 256 || N % TN != 0 || K % 64 != 0) return false;
+    const long b160 = (long)((M + TM - 1) / TM) * (N / TN);
+    const long b128 = (long)((M + 63) / 64) * ((N + 127) / 128);
+    return b160 <= 256 && b160 >= 160 && b128 > 256;
+}
+
+// what the kernel can run at all (ds_set_option "gemm_variant" 11 forces it on every such problem: parity tests, A/B)
+bool ds_gemm_t160_possible(const GemmParams& p, int batch) {
+    if (p.conv || p.A2 || p.rowbias || p.epi != EPI_NONE || p.dtype != DS_DTYPE_F16 || p.ln_swapped || batch != 1) return false;
+    if (p.M <= 0 || p.N % TN != 0 || p.K % 64 != 0 || p.K <= 0) return false;
+    if (p.ln_stats && !p.ln_partial) return false;            // finalised statistics are gemm_pp_kernel's consumer form
+    if (p.stats_out && p.stats_strip != 32) return false;     // 64-column statistics need whole 64-column strips per tile
+    if (p.lda * 63 + 64 >= (1L << 30) || p.ldw * 159 + 64 >= (1L << 30)) return false;   // 32-bit lane offsets
+    return true;
+}
+
+bool ds_gemm_t160_applicable(const GemmParams& p, int batch) {
+    return ds_gemm_t160_possible(p, batch) && ds_gemm_t160_shape(p.M, p.N, p.K, batch);
+}
+
+int ds_launch_gemm_t160(const GemmParams& p0, hipStream_t stream) {
+    GemmParams p = p0;
+    constexpr int STAGES = 5;
+    DS_REQUIRE(p.N % TN == 0 && p.K % 64 == 0 && !p.A2 && !p.rowbias && p.epi == EPI_NONE,
+               "gemm_t160: shape M=%d N=%d K=%d not supported", p.M, p.N, p.K);
+    DS_REQUIRE(!p.stats_out || p.stats_strip == 32, "gemm_t160: emits 32-column statistics only (stats_strip = %d)", p.stats_strip);
+    DS_REQUIRE(!p.ln_stats || (p.ln_partial && p.ln_c && !p.ln_swapped), "gemm_t160: consumes partial LayerNorm sums in the row form only");
+    p.tiles_m = (p.M + TM - 1) / TM;
+    p.tiles_n = p.N / TN;
+    const size_t lds = (size_t)STAGES * STAGE_B + 1024;
+    auto kern = gemm_t160_kernel<STAGES>;
+    static unsigned long long attr_devs = 0;
+    if (ds_first_on_device(attr_devs))
+        DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(320), lds, stream, p);
+    DS_LAUNCH_CHECK();
+    return 0;
+}

@@ -311,6 +311,12 @@ int ds_launch_groupnorm(const GroupNormParams& p, hipStream_t stream) {
     // block up to 128 chunks - gave the 32 x 32-token level at UNet batch 64 blocks of 20 KiB that wrote 10 KiB of partial
     // sums each: 84 MB of partials beside a 168 MB tensor.)  g_gn_variant 1 = the round-3 geometry (A/B).
     int nch = gn_chunks(p.HW), threads = 256;
+    // Statistics already in the workspace (written by the producing convolution's epilogue, conv_halo.hip: one partial pair per
+    // channel and pixel tile): no statistics launch - the finalize launch adds up `pre_chunks` partials per channel, and the
+    // normalisation pass is the only one that reads x.
+    const int stat_chunks = p.pre_chunks > 0 ? p.pre_chunks : 0;
+    DS_REQUIRE(stat_chunks <= GN_MAX_CHUNKS && (stat_chunks == 0 || (p.x2 == nullptr && p.dtype == DS_DTYPE_F16)),
+               "groupnorm: precomputed statistics need a single f16 source and <= %d chunks per image (got %d)", GN_MAX_CHUNKS, stat_chunks);
     if (g_gn_variant != 1) {
         const int want = (1024 + p.B * nslab - 1) / (p.B * nslab), by_rows = (p.HW + 63) / 64;
         nch = min(nch, max(want, by_rows));
@@ -321,6 +327,9 @@ int ds_launch_groupnorm(const GroupNormParams& p, hipStream_t stream) {
         hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, grid, dim3(threads), 0, stream, p);
         hipLaunchKernelGGL(gn_finalize_kernel<bf16_t>, dim3(p.B, p.groups), dim3(256), 0, stream, p, nch);
         hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, grid, dim3(threads), 0, stream, p, nch);
+    } else if (stat_chunks > 0) {
+        hipLaunchKernelGGL(gn_finalize_kernel<half_t>, dim3(p.B, p.groups), dim3(256), 0, stream, p, stat_chunks);
+        hipLaunchKernelGGL(gn_apply_kernel<half_t>, grid, dim3(threads), 0, stream, p, stat_chunks);
     } else {
         hipLaunchKernelGGL(gn_stats_kernel<half_t>, grid, dim3(threads), 0, stream, p);
         hipLaunchKernelGGL(gn_finalize_kernel<half_t>, dim3(p.B, p.groups), dim3(256), 0, stream, p, nch);

@@ -59,6 +59,13 @@ def pack_ln_fused(w: Tensor, bias: Optional[Tensor], gamma: Tensor, beta: Tensor
     return gw.contiguous(), torch.stack([hi, lo], dim=1).contiguous(), bp.to(torch.float16).contiguous()
 
 
+def gn_fusion_enabled() -> bool:
+    """DIFFSENSEI_GN_FUSION=0 keeps the three-launch GroupNorm behind conv1 of every resnet (A/B runs): by default conv1's
+    epilogue emits the partial sums norm2 needs (csrc/conv_halo.hip) and the GroupNorm reads its input once."""
+    import os
+    return os.environ.get("DIFFSENSEI_GN_FUSION", "1") != "0"
+
+
 def ln_fusion_enabled() -> bool:
     """DIFFSENSEI_LN_FUSION=0 keeps the stand-alone LayerNorm launches everywhere (A/B runs)."""
     import os
@@ -420,22 +427,31 @@ class UNetEngine:
         return Plan(ops, self.keep)
 
     # -- building blocks of the forward plan
-    def _gn(self, ops, x1, x2, y, gamma, beta, HW, C1, C2, eps, silu):
-        ops.append(make_op("GROUPNORM", i=(self.B, HW, C1, C2, self.cfg.norm_num_groups, int(silu)), f=(eps,),
+    def _gn(self, ops, x1, x2, y, gamma, beta, HW, C1, C2, eps, silu, pre_chunks=0):
+        """pre_chunks > 0: the producing convolution left that many partial-sum chunks per image in the workspace (`_conv(...,
+        gn_stats=True)`): the GroupNorm skips its statistics launch and reads x once."""
+        ops.append(make_op("GROUPNORM", i=(self.B, HW, C1, C2, self.cfg.norm_num_groups, int(silu), int(pre_chunks)), f=(eps,),
                            p=(x1, x2, y, gamma, beta, self.gn_ws)))
 
-    def _conv(self, ops, x, wname, y, H, W, Cin, Cout, stride=1, upsample=0, rowbias=None, residual=None, out_hw=(0, 0)):
+    def _conv(self, ops, x, wname, y, H, W, Cin, Cout, stride=1, upsample=0, rowbias=None, residual=None, out_hw=(0, 0),
+              gn_stats=False):
+        """gn_stats: the convolution's epilogue also writes the GroupNorm partial sums of its output into the workspace
+        (csrc/conv_halo.hip; the caller has asked `ds_conv3x3_gn_chunks` first and passes the count to the GroupNorm op)."""
         w = self.pk.w
         ops.append(make_op("CONV3X3", i=(self.B, H, W, Cin, Cout, stride, upsample, self.pk.temb_total, out_hw[0], out_hw[1]),
-                           p=(x, w[wname + ".weight"], y, w[wname + ".bias"], rowbias, residual)))
+                           p=(x, w[wname + ".weight"], y, w[wname + ".bias"], rowbias, residual, self.gn_ws if gn_stats else None)))
 
     def _gemm(self, ops, x, wt, y, M, N, K, bias=None, residual=None, geglu=False, x2=None, K1=0, ln_stats=None, ln_c=None,
-              stats_out=None, ln_partial=False):
+              stats_out=None, ln_partial=False, ln_nstrips=0, stats_strip=0):
         """ln_stats / ln_c: this GEMM consumes a fused LayerNorm (x is the raw residual stream, wt / bias the `_ln` copies);
         ln_partial: ln_stats are the producer's partial sums and the kernel finalises its own rows (the 128-wide kernels);
-        stats_out: it emits the row statistics of what it stores (csrc/gemm_pp.hip, "LayerNorm"; csrc/gemm.hip, "Fused LayerNorm")."""
+        stats_out: it emits the row statistics of what it stores (csrc/gemm_pp.hip, "LayerNorm"; csrc/gemm.hip, "Fused LayerNorm");
+        stats_strip: columns per statistics strip the producer is asked for (0 = 64; 32 where gemm_t160_kernel runs the producer),
+        ln_nstrips: strips per row a consumer of partial sums adds up (0 = K / 64)."""
         n_out = N // 2 if geglu else N
-        ops.append(make_op("GEMM", i=(M, N, K, K1 if x2 is not None else K, int(geglu), 1, 0, 1, 0, int(ln_partial)), f=(1e-5,),
+        ops.append(make_op("GEMM", i=(M, N, K, K1 if x2 is not None else K, int(geglu), 1, 0, 1, 0, int(ln_partial),
+                                      int(ln_nstrips) if ln_stats is not None else 0, int(stats_strip) if stats_out is not None else 0),
+                           f=(1e-5,),
                            l=(K1 if x2 is not None else K, (K - K1) if x2 is not None else 0, K, n_out, n_out),
                            p=(x, x2, wt, y, bias, None, residual, ln_stats, ln_c, stats_out)))
 
@@ -448,8 +464,12 @@ class UNetEngine:
         t1 = self._buf("res_t1", r.level, M, r.cout)
         self._gn(ops, x1, x2, gn, w[p + ".norm1.weight"], w[p + ".norm1.bias"], HW, c1, c2, cfg.norm_eps, True)
         rowbias = self.temb_all.data_ptr() + 2 * self.pk.temb_off[p]
-        self._conv(ops, gn, p + ".conv1", t1, H, W, r.cin, r.cout, rowbias=rowbias)
-        self._gn(ops, t1, None, gn, w[p + ".norm2.weight"], w[p + ".norm2.bias"], HW, r.cout, 0, cfg.norm_eps, True)
+        # conv1 -> norm2: the statistics of t1 come out of conv1's epilogue where a halo-patch kernel runs it (every resnet of the
+        # UNet at every size up to 128 pixel tiles per image; DIFFSENSEI_GN_FUSION=0 keeps the three-launch GroupNorm: A/B)
+        nch = int(_lib.load().ds_conv3x3_gn_chunks(self.B, H, W, r.cin, r.cout)) if gn_fusion_enabled() else 0
+        self.gn_fused = getattr(self, "gn_fused", 0) + (nch > 0)
+        self._conv(ops, gn, p + ".conv1", t1, H, W, r.cin, r.cout, rowbias=rowbias, gn_stats=nch > 0)
+        self._gn(ops, t1, None, gn, w[p + ".norm2.weight"], w[p + ".norm2.bias"], HW, r.cout, 0, cfg.norm_eps, True, pre_chunks=nch)
         if r.has_shortcut:
             sc = self._buf("res_sc", r.level, M, r.cout)
             self._gemm(ops, x1, w[p + ".conv_shortcut.weight"], sc, M, r.cout, r.cin, bias=w[p + ".conv_shortcut.bias"],
@@ -504,8 +524,13 @@ class UNetEngine:
         k_qk, k_ffd, k_v = kind(M, 2 * Cc, Cc), kind(M, Cc, 4 * Cc), kind(Cc, Np, Cc, 0, B)
         fuse1 = (fuse and f"{p}.transformer_blocks.0.attn1.qk.weight_ln" in w and pays(k_qk) and pays(k_ffd) and pays(k_v)
                  and (k_v == 2 or (Np == N and can(Cc, N, Cc, 0, B))))
+        # Statistics strips: 64 columns, or 32 where the producers of this level (N = Cc, K = Cc | 4 Cc: proj_in, both
+        # out-projections, the FF down-projection) run gemm_t160_kernel - its 160-column tiles hold no whole 64-column strips
+        # (csrc/gemm_t160.hip; the rule does not depend on K, so every producer of a level emits the same format)
+        sw = 32 if (int(lib.ds_gemm_t160_fits(M, Cc, Cc, 1)) and int(lib.ds_gemm_t160_fits(M, Cc, 4 * Cc, 1))) else 64
+        nstr = Cc // sw
         if fuse:
-            part = self._buf32("ln_part", a.level, (Cc // 64) * M * 2)
+            part = self._buf32("ln_part", a.level, nstr * M * 2)
             st = self._buf32("ln_stats", a.level, M * 2)
         self.ln_fused_blocks = getattr(self, "ln_fused_blocks", 0) + (a.depth if fuse else 0)
         self.ln_fused_launches = getattr(self, "ln_fused_launches", 0) + a.depth * ((3 if fuse1 else 2) if fuse else 0)
@@ -514,16 +539,16 @@ class UNetEngine:
             ((1 if fin1 else 0) + (k_proj == 1) + (k_ff == 1)) if fuse else 0)
         self._gn(ops, x, None, tn, w[p + ".norm.weight"], w[p + ".norm.bias"], N, Cc, 0, 1e-6, False)
         self._gemm(ops, tn, w[p + ".proj_in.weight"], h, M, Cc, Cc, bias=w[p + ".proj_in.bias"],
-                   stats_out=part if fuse1 else None)
+                   stats_out=part if fuse1 else None, stats_strip=sw)
         for k in range(a.depth):
             t = f"{p}.transformer_blocks.{k}"
             # ---- attn1 (AttnProcessor2_0): q|k projection, V^T projection, flash attention, out-proj + residual
             if fuse1:    # norm1: statistics of h came out of proj_in / the previous block's FF down-projection
                 if fin1:
-                    ops.append(make_op("LN_FINALIZE", i=(M, Cc // 64, Cc), f=(1e-5,), p=(part, st)))
+                    ops.append(make_op("LN_FINALIZE", i=(M, nstr, Cc), f=(1e-5,), p=(part, st)))
                 self._gemm(ops, h, w[t + ".attn1.qk.weight_ln"], qk, M, 2 * Cc, Cc, bias=w[t + ".attn1.qk.bias_ln"],
-                           ln_stats=st if k_qk == 1 else part, ln_c=w[t + ".attn1.qk.c_ln"], ln_partial=k_qk == 2)
-                ops.append(make_op("GEMM", i=(Cc, Np, Cc, Cc, 0, B, 0, 1, 1, int(k_v == 2)), f=(1e-5,),
+                           ln_stats=st if k_qk == 1 else part, ln_c=w[t + ".attn1.qk.c_ln"], ln_partial=k_qk == 2, ln_nstrips=nstr)
+                ops.append(make_op("GEMM", i=(Cc, Np, Cc, Cc, 0, B, 0, 1, 1, int(k_v == 2), nstr), f=(1e-5,),
                                    l=(Cc, 0, Cc, Np, 0, 0, 0, N * Cc, Cc * Np, 0, N, M),
                                    p=(w[t + ".attn1.to_v.weight_ln"], None, h, vt, None, None, None, st if k_v == 1 else part,
                                       w[t + ".attn1.to_v.cb_ln"], None)))
@@ -536,13 +561,13 @@ class UNetEngine:
                                l=(2 * Cc, 2 * Cc, Np, Cc, N * 2 * Cc, N * 2 * Cc, N * Cc),
                                p=(qk, qk.data_ptr() + 2 * Cc, vt, ao)))
             self._gemm(ops, ao, w[t + ".attn1.to_out.0.weight"], h, M, Cc, Cc, bias=w[t + ".attn1.to_out.0.bias"],
-                       residual=h, stats_out=part if fuse else None)
+                       residual=h, stats_out=part if fuse else None, stats_strip=sw)
             # ---- attn2 (MaskedIPAttnProcessor2_0): q projection, fused text+masked-IP attention, out-proj + residual
             if fuse:
                 if k_proj == 1:
-                    ops.append(make_op("LN_FINALIZE", i=(M, Cc // 64, Cc), f=(1e-5,), p=(part, st)))
+                    ops.append(make_op("LN_FINALIZE", i=(M, nstr, Cc), f=(1e-5,), p=(part, st)))
                 self._gemm(ops, h, w[t + ".attn2.to_q.weight_ln"], q2, M, Cc, Cc, bias=w[t + ".attn2.to_q.bias_ln"],
-                           ln_stats=st if k_proj == 1 else part, ln_c=w[t + ".attn2.to_q.c_ln"], ln_partial=k_proj == 2)
+                           ln_stats=st if k_proj == 1 else part, ln_c=w[t + ".attn2.to_q.c_ln"], ln_partial=k_proj == 2, ln_nstrips=nstr)
             else:
                 ops.append(make_op("LAYERNORM", i=(M, Cc), f=(1e-5,), p=(h, tn, w[t + ".norm2.weight"], w[t + ".norm2.bias"])))
                 self._gemm(ops, tn, w[t + ".attn2.to_q.weight"], q2, M, Cc, Cc)
@@ -555,19 +580,20 @@ class UNetEngine:
                 p=(q2, self.k_txt.data_ptr() + 2 * off, self.v_txt.data_ptr() + 2 * off * LP,
                    self.k_ip.data_ptr() + 2 * off, self.v_ip.data_ptr() + 2 * off * LP, self.bbox, ao, self.ip_scale)))
             self._gemm(ops, ao, w[t + ".attn2.to_out.0.weight"], h, M, Cc, Cc, bias=w[t + ".attn2.to_out.0.bias"],
-                       residual=h, stats_out=part if fuse else None)
+                       residual=h, stats_out=part if fuse else None, stats_strip=sw)
             # ---- GEGLU feed-forward + residual
             if fuse:
                 if k_ff == 1:
-                    ops.append(make_op("LN_FINALIZE", i=(M, Cc // 64, Cc), f=(1e-5,), p=(part, st)))
+                    ops.append(make_op("LN_FINALIZE", i=(M, nstr, Cc), f=(1e-5,), p=(part, st)))
                 self._gemm(ops, h, w[t + ".ff.net.0.proj.weight_ln"], ff, M, 8 * Cc, Cc, bias=w[t + ".ff.net.0.proj.bias_ln"],
-                           geglu=True, ln_stats=st if k_ff == 1 else part, ln_c=w[t + ".ff.net.0.proj.c_ln"], ln_partial=k_ff == 2)
+                           geglu=True, ln_stats=st if k_ff == 1 else part, ln_c=w[t + ".ff.net.0.proj.c_ln"], ln_partial=k_ff == 2,
+                           ln_nstrips=nstr)
             else:
                 ops.append(make_op("LAYERNORM", i=(M, Cc), f=(1e-5,), p=(h, tn, w[t + ".norm3.weight"], w[t + ".norm3.bias"])))
                 self._gemm(ops, tn, w[t + ".ff.net.0.proj.weight"], ff, M, 8 * Cc, Cc, bias=w[t + ".ff.net.0.proj.bias"],
                            geglu=True)
             self._gemm(ops, ff, w[t + ".ff.net.2.weight"], h, M, Cc, 4 * Cc, bias=w[t + ".ff.net.2.bias"], residual=h,
-                       stats_out=part if (fuse1 and k + 1 < a.depth) else None)
+                       stats_out=part if (fuse1 and k + 1 < a.depth) else None, stats_strip=sw)
         self._gemm(ops, h, w[p + ".proj_out.weight"], out, M, Cc, Cc, bias=w[p + ".proj_out.bias"], residual=x)
 
     def _build_forward(self) -> List[DsOp]:

@@ -37,7 +37,9 @@ int ds_device_info(int* cu_count, int* lds_bytes, char* arch_name, int arch_name
  * between them (GEMM families, conv block sizes, flash attention <1> / <2>, ip_attn variants, hipGraph vs eager); the ones that
  * re-associate a sum - self_attn_sp_kernel vs the flash kernels, gn_variant 1's chunking - are compared at a stated tolerance.
  *   "gemm_variant"       0 auto | 1 register-staged only | 2, 7 two-buffer LDS-DMA | 8, 9 one-buffer LDS-DMA |
- *                        3 256x256 ping-pong (gemm_pp_kernel) | 10 halo-patch conv
+ *                        3 256x256 ping-pong (gemm_pp_kernel) | 10 halo-patch conv | 11 64x160 tiles (gemm_t160_kernel)
+ *   "gemm_t160"          0 (default) small-batch projections whose 64x160 grid is one block per CU run gemm_t160_kernel |
+ *                        1 never (A/B)
  *   "gemm_pp_even"       1 (default) gemm_pp_kernel's persistent grid = ceil(tiles / rounds) blocks, every round full |
  *                        0 one block per CU with a partial last round
  *   "gemm_ring"          0 (default) grids of <= 512 64x128 blocks (num_samples 1) use the ring-buffered
@@ -67,6 +69,16 @@ int ds_set_option(const char* key, int value);
  *                       (tests/test_gpu_outlier_magnitudes.py).
  * *value receives the count; reset != 0 clears it afterwards.  Returns 0, or -1 for an unknown name. */
 int ds_debug_counter(const char* name, int reset, long long* value);
+/* Host-side query of the dispatch rule (no GPU work): 1 when a plain f16 GEMM of this shape runs gemm_t160_kernel (64 x 160
+ * tiles, one block per CU: the M = 2048, N = 1280 projections of a batch-1 request at 1024 x 1024).  A launch planner asks
+ * before it requests that kernel's 32-column LayerNorm statistics (DsOp GEMM i[11] = 32) and tells the consumers to sum
+ * N / 32 strips (i[10]); a direct ds_gemm_ln_* call always gets the 64-column format. */
+int ds_gemm_t160_fits(int M, int N, int K, int batch);
+/* Host-side query: partial-sum chunks per image that a stride-1 3x3 convolution of this shape writes for the GroupNorm behind
+ * it (DsOp CONV3X3 p[6] = the GroupNorm workspace; DsOp GROUPNORM i[6] = this number: the GroupNorm then skips its statistics
+ * pass).  0: this convolution cannot (not a halo-patch kernel shape, or more than 128 pixel tiles per image).  Replaces the
+ * first read of conv1's output by diffusers' ResnetBlock2D.norm2 [3P], reached from reference src/models/unet.py:244-338. */
+int ds_conv3x3_gn_chunks(int B, int H, int W, int Cin, int Cout);
 
 /* ------------------------------------------------------------------------------------------------
  * Operators.  Each replaces the torch call(s) named in its comment.
@@ -339,10 +351,12 @@ int ds_resize_v_norm_u8(const uint8_t* tmp, int Ht, int Wt, const int32_t* first
  * ---------------------------------------------------------------------------------------------- */
 enum ds_opcode {
     DS_OP_GEMM = 1,          /* p: x, x2, w, y, bias, rowbias, residual, ln_stats, ln_c, stats_out (fused LayerNorm, see ds_gemm_ln_f16; i[8] = operand-swapped form, l[10] = ln_bstride; i[9] = ln_stats holds PARTIAL sums, f[0] = eps, l[11] = ln_rows: ds_gemm_ln_partial_f16 / ds_gemm_ln_swapped_partial_f16)   l: ldx ldx2 ldw ldy ldr sx sx2 sw sy sr
-                                i: M N K K1 epilogue batch rowbias_ld rows_per_group */
-    DS_OP_CONV3X3 = 2,       /* p: x, w, y, bias, rowbias, residual       i: B H W Cin Cout stride upsample rowbias_ld
-                                                                           Hout Wout (upsample only; 0 0 = 2H x 2W) */
-    DS_OP_GROUPNORM = 3,     /* p: x1, x2, y, gamma, beta, ws             i: B HW C1 C2 groups silu   f: eps */
+                                i: M N K K1 epilogue batch rowbias_ld rows_per_group; i[10] = strips a consumer of partial sums adds per
+                                row (0 = K / 64), i[11] = columns per statistics strip a producer emits (0 = 64; 32: ds_gemm_t160_fits) */
+    DS_OP_CONV3X3 = 2,       /* p: x, w, y, bias, rowbias, residual, gn_partial (optional: GroupNorm workspace, see ds_conv3x3_gn_chunks)
+                                i: B H W Cin Cout stride upsample rowbias_ld Hout Wout (upsample only; 0 0 = 2H x 2W) */
+    DS_OP_GROUPNORM = 3,     /* p: x1, x2, y, gamma, beta, ws             i: B HW C1 C2 groups silu pre_chunks (0, or the number of
+                                partial-sum chunks per image the producing convolution left in ws)   f: eps */
     DS_OP_LAYERNORM = 4,     /* p: x, y, gamma, beta                      i: rows C                   f: eps */
     DS_OP_SELF_ATTN = 5,     /* p: q, k, vt, o   l: ldq ldk ldv ldo sq sk so   i: B heads Nq Nk       f: scale */
     DS_OP_IP_ATTN = 6,       /* p: q, kt, vtt, ki, vti, bbox, o, ip_scale_dev   l: ldq ldo ldk sk sv

@@ -420,3 +420,68 @@ def test_bench_under_torchrun_env_mismatch_is_an_error_not_a_hang():
     r, lines = _run_bench(["--gpus", "2", "--dry-run"], env_extra={"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"}, drop=())
     assert r.returncode != 0 and not lines
     assert "WORLD_SIZE=1" in r.stderr
+
+
+# ------------------------------------------------------------------------------------------ world size 8
+def _worker_c3_world8(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from diffsensei_amd.distributed import PanelRequest, init_from_env, run_sharded_batched
+    init_from_env("gloo")
+    calls = []
+
+    class StubPipe:   # stands for DiffSenseiPipeline.generate_batch: one "image" per request, tagged with the serving rank
+        def generate_batch(self, requests, output_type="pil"):
+            calls.append([(r["height"], r["prompt"]) for r in requests])
+            return [torch.full((2, 2), float(rank)) for _ in requests]
+
+    sizes = [512, 768, 1024, 1536] * 8      # BASELINE.json configs[3]: mixed-resolution bucket, 32 requests, 8 GPUs
+    reqs = [PanelRequest(i, s, s, 50, 1, payload={"prompt": f"p{i}", "guidance_scale": 7.5}) for i, s in enumerate(sizes)]
+    out = run_sharded_batched(reqs, StubPipe(), max_panels=16, output_type="pt", gather=True)
+    dist.barrier()
+    mine = sum(PanelRequest(0, h, h, 50, 1).cost() for c in calls for (h, _) in c)
+    q.put((rank, calls, mine, None if out is None else {k: float(v[0][0]) for k, v in out.items()}))
+    dist.destroy_process_group()
+
+
+def test_configs3_queue_over_8_ranks_every_request_once_and_balanced():
+    """BASELINE.json configs[3] - 32 requests over the buckets {512, 768, 1024, 1536}^2 on 8 ranks - through the real
+    `run_sharded_batched` (LPT sharding, per-rank BucketBatcher, uint8 / array gather to rank 0) with a stub pipeline on 8 gloo
+    processes: every request is served exactly once, by the rank the result says, never in a mixed-bucket batch, and the LPT
+    shards are within 10 % of each other in modelled cost.  (The N = 2 / 4 / 8 CURVE stays unmeasured: no multi-GPU box in reach.)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_c3_world8, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    served = {}
+    for rank, calls, _, out in res:
+        assert (out is None) == (rank != 0)
+        for batch in calls:
+            assert len({h for h, _ in batch}) == 1 and len(batch) <= 16
+            for _, pr in batch:
+                assert pr not in served, f"{pr} served twice"
+                served[pr] = rank
+    assert sorted(served) == sorted(f"p{i}" for i in range(32))
+    out0 = res[0][3]
+    assert sorted(out0) == list(range(32))
+    assert all(int(out0[i]) == served[f"p{i}"] for i in range(32))       # the gathered result comes from the rank that served it
+    loads = [m for _, _, m, _ in res]
+    assert min(loads) > 0 and max(loads) / min(loads) <= 1.10, loads
+
+
+def test_bench_gpus8_dry_run_one_line_from_rank0():
+    """`python bench.py --gpus 8 --dry-run` with no torchrun environment: the script starts its own 8 ranks (gloo here), runs the
+    barrier-bracketed timing with the MAX over ranks and prints ONE JSON line with n_gpus 8 from rank 0."""
+    r, lines = _run_bench(["--gpus", "8", "--steps", "2", "--warmup", "1", "--dry-run"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1, r.stdout
+    ln = lines[0]
+    assert ln["n_gpus"] == 8 and ln["steps"] == 2 and ln["warmup"] == 1 and ln["dry_run"] is True and ln["scaling"] == "weak"

@@ -1,8 +1,9 @@
 """GPU: character encoders and the whole `DiffSenseiPipeline.__call__` (tiny widths, true token counts) vs the CPU
 oracle: transformers CLIP-vision / ViT-MAE in fp32, oracle Resampler, oracle sampling loop.
 
-Tolerance: fp16 engine vs fp32 reference modules, relative L2 <= 2e-2 for encoder outputs, <= 5e-2 for the latents
-after 3 full denoise steps (error compounds through CFG at guidance 7.5).
+Tolerance (round 6: <= ~3-4x measured, every value logged by tests/_gates.gate): fp16 engine vs fp32 reference modules,
+relative L2 <= 4e-3 for the character-encoder outputs (measured 0.7-1.1e-3), <= 1.2e-2 for the latents after 3 full denoise
+steps (measured 3.7e-3; the error compounds through CFG at guidance 7.5).  Until round 5: 2e-2 / 5e-2.
 """
 import numpy as np
 import pytest
@@ -42,8 +43,8 @@ def test_clip_and_mae_engines_vs_transformers(encoders):
     ce, me = ClipVisionEngine.from_transformers(clip, DEV), ViTMAEEngine.from_transformers(mae, DEV)
     got_c, got_m = ce.penultimate_hidden(px), me.cls_embedding(px)
     assert got_c.shape == ref_c.shape == (3, 257, 160) and got_m.shape == ref_m.shape == (3, 128)
-    gate("test_gpu_pipeline:1 " + '_rel(got_c, ref_c)', _rel(got_c, ref_c), 2e-2)
-    gate("test_gpu_pipeline:2 " + '_rel(got_m, ref_m)', _rel(got_m, ref_m), 2e-2)
+    gate("test_gpu_pipeline:1 " + '_rel(got_c, ref_c)', _rel(got_c, ref_c), 4e-3)
+    gate("test_gpu_pipeline:2 " + '_rel(got_m, ref_m)', _rel(got_m, ref_m), 4e-3)
 
 
 def test_pipeline_call_vs_oracle(encoders):
@@ -109,7 +110,7 @@ def test_pipeline_call_vs_oracle(encoders):
         sch = EulerDiscreteOracle().set_timesteps(steps)
         ref = sample_loop(UNetOracle(cfg, sd, q=hq), EulerDiscreteOracle(), hq(lat0.float() * sch.init_noise_sigma),
                           hq(enc), hq(te), tid, bbox, db, 7.5, steps, 0.6, q=hq)
-    gate("test_gpu_pipeline:3 " + '_rel(results[0], ref)', _rel(results[0], ref), 5e-2)
+    gate("test_gpu_pipeline:3 " + '_rel(results[0], ref)', _rel(results[0], ref), 1.2e-2)
 
 
 class _FakeTokenizer:

@@ -90,7 +90,7 @@ def test_text_only_request_runs_the_ip_branch(pipe):
     lat0 = torch.randn(1, 4, 16, 16, generator=torch.Generator().manual_seed(1)).half()
     out = p(ip_images=[], ip_bbox=[], dialog_bbox=[], ip_scale=0.6, latents=lat0.clone(), **common).images
     ref = _oracle(cfg, sd, rs, clip, mae, common, [], [], [], 1, lat0)
-    gate("test_gpu_pipeline_variants:1 " + '_rel(out, ref)', _rel(out, ref), 5e-2)
+    gate("test_gpu_pipeline_variants:1 " + '_rel(out, ref)', _rel(out, ref), 1.2e-2)
 
 
 def test_guidance_scale_one_uses_the_negative_boxes_like_the_reference(pipe):
@@ -129,7 +129,7 @@ def test_guidance_scale_one_uses_the_negative_boxes_like_the_reference(pipe):
         sch = EulerDiscreteOracle().set_timesteps(3)
         ref = sample_loop(UNetOracle(cfg, sd, q=hq), EulerDiscreteOracle(), hq(lat0.float() * sch.init_noise_sigma), hq(enc),
                           hq(te), tid, torch.zeros(1, 4, 4), db, 1.0, 3, 0.6, q=hq)
-    gate("test_gpu_pipeline_variants:2 " + '_rel(out, ref)', _rel(out, ref), 3e-2)
+    gate("test_gpu_pipeline_variants:2 " + '_rel(out, ref)', _rel(out, ref), 3e-3)
 
 
 def test_call_at_a_size_that_is_only_a_multiple_of_8(pipe):
@@ -220,7 +220,7 @@ def test_mllm_handoff_ip_image_embeds(pipe):
     out = p(ip_images=[], ip_image_embeds=emb.to(DEV), ip_bbox=[list(b) for b in boxes], dialog_bbox=[], ip_scale=0.6,
             latents=lat0.clone(), **common).images
     ref = _oracle(cfg, sd, rs, clip, mae, common, [], boxes, [], 1, lat0, ip_embeds=emb)
-    gate("test_gpu_pipeline_variants:3 " + '_rel(out, ref)', _rel(out, ref), 5e-2)
+    gate("test_gpu_pipeline_variants:3 " + '_rel(out, ref)', _rel(out, ref), 1.2e-2)
     plain = p(ip_images=[], ip_bbox=[], dialog_bbox=[], ip_scale=0.6, latents=lat0.clone(), **common).images
     assert _rel(out, plain) > 1e-3          # the supplied character tokens matter
 
@@ -237,14 +237,14 @@ def test_ddim_and_plan_reuse_and_ip_scale(pipe):
     p.scheduler = DDIMScheduler()
     out_d = p(ip_scale=0.6, latents=lat0.clone(), **kw, **common).images
     ref_d = _oracle(cfg, sd, rs, clip, mae, common, imgs, boxes, dialog, 2, lat0, ddim=True)
-    gate("test_gpu_pipeline_variants:4 " + '_rel(out_d, ref_d)', _rel(out_d, ref_d), 5e-2)
+    gate("test_gpu_pipeline_variants:4 " + '_rel(out_d, ref_d)', _rel(out_d, ref_d), 1.2e-2)
     p.scheduler = EulerDiscreteScheduler()
     a = p(ip_scale=0.6, latents=lat0.clone(), **kw, **common).images
     b = p(ip_scale=0.0, latents=lat0.clone(), **kw, **common).images      # same captured graph, new device scalar
     c = p(ip_scale=0.6, latents=lat0.clone(), **kw, **common).images
     assert torch.equal(a, c) and _rel(a, b) > 1e-3
     ref_b = _oracle(cfg, sd, rs, clip, mae, common, imgs, boxes, dialog, 2, lat0, ip_scale=0.0)
-    gate("test_gpu_pipeline_variants:5 " + '_rel(b, ref_b)', _rel(b, ref_b), 5e-2)
+    gate("test_gpu_pipeline_variants:5 " + '_rel(b, ref_b)', _rel(b, ref_b), 1.2e-2)
     # seeded generator -> reproducible latents, like the reference's only determinism knob
     g1 = p(ip_scale=0.6, generator=torch.Generator().manual_seed(7), **kw, **common).images
     g2 = p(ip_scale=0.6, generator=torch.Generator().manual_seed(7), **kw, **common).images
@@ -317,14 +317,14 @@ def test_mllm_prepass_end_to_end(pipe):
                           max_new, n_img)
     assert ref["output_ids"][:n_img + 1].tolist() == chain[1:], "oracle: forced image block"
     want = R.blend_ip_embeds(ref["img_gen_feat"], toks, mllm_scale, cfg.max_num_ips, cfg.num_vision_tokens)
-    gate("test_gpu_pipeline_variants:6 " + '_rel(got, want)', _rel(got, want), 3e-2)
+    gate("test_gpu_pipeline_variants:6 " + '_rel(got, want)', _rel(got, want), 5e-3)
     # ... and into the sampler exactly like gradio.py:112-129 (`ip_images=[]`, `ip_image_embeds=`)
     boxes = [[0.0, 0.0, 0.5, 1.0], [0.5, 0.0, 1.0, 1.0], [0.0] * 4, [0.0] * 4]    # gradio.py:85-89 pads the boxes to 4
     lat0 = torch.randn(1, 4, 16, 16, generator=torch.Generator().manual_seed(4)).half()
     out = p(ip_images=[], ip_image_embeds=got, ip_bbox=[list(b) for b in boxes], dialog_bbox=[], ip_scale=0.6,
             latents=lat0.clone(), **common).images
     ref_lat = _oracle(cfg, sd, rs, clip, mae, common, [], boxes, [], 1, lat0, ip_embeds=hq(want))
-    gate("test_gpu_pipeline_variants:7 " + '_rel(out, ref_lat)', _rel(out, ref_lat), 5e-2)
+    gate("test_gpu_pipeline_variants:7 " + '_rel(out, ref_lat)', _rel(out, ref_lat), 1.2e-2)
 
 
 def test_callback_may_return_replaced_latents(pipe):
