@@ -36,10 +36,11 @@ struct GemmParams {
     int ln_partial = 0;                // consumer on the 128-wide LDS-DMA kernels (gemm.hip, "Fused LayerNorm"): ln_stats points at the
     float ln_eps = 1e-5f;              //   producer's PARTIALS [K/64][rows] float2 and the epilogue finalises its own rows (eps = ln_eps)
     long ln_rows = 0;                  //   operand-swapped form only: rows of the normalised matrix over all batch items (stride of the partials)
-    int ln_nstrips = 0;                // consumer of partials: strips per row to sum (0 = K / 64; 2 K / 64 behind a 32-column producer)
-    int stats_strip = 0;               // producer: columns per statistics strip (0 = 64).  32 is what gemm_t160_kernel emits - its
-                                       //   160-column tiles hold no whole 64-column strips -, [N/32][M] float2; the launch planner
-                                       //   requests it explicitly (and tells the consumers: ln_nstrips), a direct caller never gets it
+    int ln_nstrips = 0;                // consumer of partials: entries per row to sum (0 = K / 64; 3 K / 160 behind a gemm_t160_kernel producer)
+    int stats_strip = 0;               // producer: statistics format (0 = one entry per 64 columns).  160 is what gemm_t160_kernel emits - its
+                                       //   160-column tiles hold no whole 64-column strips -: three entries per tile (columns 0..63, 64..127,
+                                       //   128..159), [3 N / 160][M] float2; the launch planner requests it explicitly (and tells the
+                                       //   consumers: ln_nstrips), a direct caller never gets it
     // ---- GroupNorm statistics out of the producing convolution (conv_halo.hip, round 6): the halo-patch kernels also write, per
     // (image, pixel tile, output channel), the (sum, sum of squares) of the f16 values they store - the partial-sum layout of
     // gn_stats_kernel, [B][gn_chunks][Cout] float2 - so the GroupNorm that follows skips its statistics pass (one read of x less)

@@ -120,7 +120,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x16 (&acc)[WR /
             float sa[MI][2], qa[MI][2];
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) sa[mi][0] = sa[mi][1] = qa[mi][0] = qa[mi][1] = 0.f;
-            constexpr int JJ = MI == 1 ? 5 : 3;   // strips per chain and round: 20 (K = 1280 in one round) or, with two rows per lane, 12
+            constexpr int JJ = MI == 1 ? 6 : 3;   // strips per chain and round: 24 (K = 1280 in one round, 20 or 24 entries) or, with two rows per lane, 12
             for (int base = 0; base < strips; base += 4 * JJ) {
                 f32x2 t[MI][2][JJ];
 #pragma unroll
@@ -157,7 +157,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x16 (&acc)[WR /
         }
     }
     // operand-swapped form: the statistics of the block's 128 columns = rows bz * ln_bstride + n0 .. of the normalised matrix are
-    // finalised once by threads 0..127 (one L2 round trip per 20 strips) into a table behind the staging tile
+    // finalised once by threads 0..127 (one L2 round trip per 24 entries) into a table behind the staging tile
     f32x2* const ln_tab = reinterpret_cast<f32x2*>(smem + HR * CS_STRIDE);
     if constexpr (LNF) {
         if (ln_col) {
@@ -166,16 +166,16 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x16 (&acc)[WR /
                 const long row = min(bz * p.ln_bstride + n0 + tid, p.ln_rows - 1);
                 const f32x2* part = reinterpret_cast<const f32x2*>(p.ln_stats) + row;
                 float sa[4] = {0.f, 0.f, 0.f, 0.f}, qa[4] = {0.f, 0.f, 0.f, 0.f};
-                for (int base = 0; base < strips; base += 20) {
-                    f32x2 t[4][5];
+                for (int base = 0; base < strips; base += 24) {
+                    f32x2 t[4][6];
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
 #pragma unroll
-                        for (int jj = 0; jj < 5; ++jj) t[q][jj] = part[(long)min(base + q + 4 * jj, strips - 1) * p.ln_rows];
+                        for (int jj = 0; jj < 6; ++jj) t[q][jj] = part[(long)min(base + q + 4 * jj, strips - 1) * p.ln_rows];
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
 #pragma unroll
-                        for (int jj = 0; jj < 5; ++jj) {
+                        for (int jj = 0; jj < 6; ++jj) {
                             const bool in = base + q + 4 * jj < strips;
                             sa[q] += in ? t[q][jj][0] : 0.f;
                             qa[q] += in ? t[q][jj][1] : 0.f;

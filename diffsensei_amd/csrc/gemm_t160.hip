@@ -14,14 +14,27 @@
 // workspace - with 6 % fewer fill bytes per flop; the single block then has to keep the CU's fill path busy by itself, hence
 // five stages (four k-tiles = 112 KiB in flight per CU; 141 KiB of LDS).
 //
-// Structure.  Five waves; wave w owns the 32-column strip w of the tile and all 64 rows (2 accumulator blocks of
-// v_mfma_f32_32x32x16_f16, operands swapped like every GEMM here: a lane ends with tile row l & 31 and 4-column groups).
-// A k-tile is 28 one-KiB LDS-DMA pieces (8 of A, 20 of W); wave w moves pieces w, w + 5, ... (six per wave: waves 3 and 4 pad
-// with a dummy piece, so the counted vmcnt waits are the same for everyone).  One barrier per k-tile, as in the ring kernel.
+// Structure.  Eight waves.  Waves 0..4 compute: wave w owns the 32-column strip w of the tile and all 64 rows (2 accumulator
+// blocks of v_mfma_f32_32x32x16_f16, operands swapped like every GEMM here: a lane ends with tile row l & 31 and 4-column
+// groups).  ALL eight waves stage: a k-tile is 28 one-KiB LDS-DMA pieces (8 of A, 20 of W), wave w moves pieces w, w + 8, w + 16
+// (and w + 24 for w < 4) - waves 5..7 do nothing else: every SIMD issues the same share of the fill and nobody pads.
+// What bounds it (measured, profiles/r06_lds_fill_rate.txt + r06_t160_forward_ab_b2*.txt): a k-tile takes 0.64 us = 28 KiB at
+// ~47 GB/s per CU, which is what the L2 -> LDS path of a CU delivers to ONE block whatever is in flight (microbenchmark
+// tools/ubench/lds_fill_rate.hip: 45 GB/s per CU from 4 issuing waves, 56 from 8, 61 from 16 on L2-resident operands, the same
+// at 4 or 24 KiB in flight per wave; 35-47 out of the Infinity Cache) - the chip-wide ~12 TB/s that the 128 x 128 GEMMs
+// (12.2 TB/s) and the 256 x 256 ping-pong kernel (10.3) also sit under.  The first version of this kernel - five waves, six
+// pieces each, two of them dummies - measured the same 50.9 / 21.2 us at K = 5120 / 1280 as this one (51.2 / 21.2): the helper
+// waves are kept because they cost nothing and remove the padding, not because they pay.  At UNet batch 2 a projection is
+// therefore bound by its fill bytes (M N K 2 (1/64 + 1/160) = 147 MB at K = 1280: 12 us) plus ~9 us of launch, first round
+// trip and epilogue; a smaller bytes-per-flop needs tiles that no longer give every CU a block.
+// One barrier per k-tile, as in the ring kernel.
 // Epilogue through LDS (row stride 336 B: conflict-free 8-byte writes), then 16-byte stores of whole 320-byte row segments.
-// Fused LayerNorm: producer statistics come per row and 32-COLUMN strip (a 160-column tile does not hold whole 64-column strips:
-// GemmParams::stats_strip = 32 is an explicit request of the launch planner, and consumers are told the strip count:
-// GemmParams::ln_nstrips); the consumer form finalises its own rows from the partial sums like the 128-wide kernels (gemm.hip).
+// Fused LayerNorm: a 160-column tile does not hold whole 64-column strips, so the producer emits THREE partial pairs per row and
+// tile - columns 0..63, 64..127, 128..159 - i.e. 3 N / 160 entries per row instead of N / 64 (24 instead of 20 at N = 1280; a
+// consumer only ever adds the entries up, so their widths need not be equal).  The format is an explicit request of the launch
+// planner (GemmParams::stats_strip = 160), and consumers are told the entry count (GemmParams::ln_nstrips); the consumer form
+// finalises its own rows from the partial sums like the 128-wide kernels (gemm.hip).  (First version: five 32-column entries
+// per tile = 40 per row - the consumers' epilogues then needed twice the load rounds: +0.3 ms per batch-2 forward.)
 #include "ds_common.h"
 #include "ds_kernels.h"
 
@@ -33,12 +46,15 @@ namespace {
 constexpr int TM = 64, TN = 160;
 constexpr int STAGE_B = (TM + TN) * 128;   // 28 KiB: A rows 0..63 (8 pieces), then W rows 0..159 (20 pieces)
 constexpr int CS = 336;                    // bytes per row of the epilogue staging tile (160 f16 + 8 pad)
+constexpr int RED_OFF = 24 * 1024;         // LayerNorm partials of the tile's five 32-column pieces, behind the 21-KiB staging tile
 typedef __attribute__((address_space(3))) void lds_void;
 
 __device__ __forceinline__ int swz(int row, int chunk) { return ((chunk ^ ((row >> 1) & 7)) << 4); }
 
+constexpr int NWAVES = 8, NCOMP = 5;   // waves per block / of them computing (one per 32-column strip)
+
 template <int STAGES>
-__global__ __launch_bounds__(320, 1) void gemm_t160_kernel(const GemmParams p) {
+__global__ __launch_bounds__(NWAVES * 64, 1) void gemm_t160_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -48,27 +64,25 @@ __global__ __launch_bounds__(320, 1) void gemm_t160_kernel(const GemmParams p) {
     tile_coords(tile, p.tiles_m, p.tiles_n, tm, tn);
     const int m0 = tm * TM, n0 = tn * TN;
     const unsigned lds0 = (unsigned)(size_t)(lds_void*)smem;
-    const unsigned dummy = lds0 + STAGES * STAGE_B;   // one KiB nobody reads: the sixth piece of waves 3 and 4
+    const bool compute = wave < NCOMP;   // wave-uniform
 
-    // ---- staging: piece q = wave + 5 j covers LDS rows 8 q .. 8 q + 7 of the stage (A rows first); the DMA destination is
+    // ---- staging: piece q = wave + 8 j covers LDS rows 8 q .. 8 q + 7 of the stage (A rows first); the DMA destination is
     // lane-linear, so the XOR swizzle goes on the lane's SOURCE chunk.  Rows past M re-read the last row (never stored).
-    unsigned off[6];
+    unsigned off[4];
     {
         const int lrow = lane >> 3, slot = lane & 7;
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            const int q = wave + 5 * j;
+        for (int j = 0; j < 4; ++j) {
+            const int q = wave + NWAVES * j;
             if (q < 8) {
                 const int row = q * 8 + lrow;
                 const int chunk = slot ^ ((row >> 1) & 7);
                 const int mr = min(m0 + row, p.M - 1) - m0;
                 off[j] = (unsigned)(mr * (int)p.lda + chunk * 8) * 2u;
-            } else if (q < 28) {
-                const int row = (q - 8) * 8 + lrow;
+            } else {
+                const int row = (min(q, 27) - 8) * 8 + lrow;
                 const int chunk = slot ^ ((row >> 1) & 7);
                 off[j] = (unsigned)(row * (int)p.ldw + chunk * 8) * 2u;
-            } else {
-                off[j] = (unsigned)(min(lrow, p.M - 1 - m0) * (int)p.lda + slot * 8) * 2u;   // dummy: the tile's first rows again
             }
         }
     }
@@ -79,9 +93,9 @@ __global__ __launch_bounds__(320, 1) void gemm_t160_kernel(const GemmParams p) {
         const half_t* const w = w_tile + kt * 64;
         const unsigned dst = lds0 + (unsigned)buf * STAGE_B;
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            const int q = wave + 5 * j;
-            lds_dma16(q < 8 || q >= 28 ? (const void*)a : (const void*)w, off[j], q < 28 ? dst + (unsigned)q * 1024u : dummy);
+        for (int j = 0; j < 4; ++j) {
+            const int q = wave + NWAVES * j;
+            if (q < 28) lds_dma16(q < 8 ? (const void*)a : (const void*)w, off[j], dst + (unsigned)q * 1024u);   // (wave-uniform)
         }
     };
 
@@ -106,17 +120,27 @@ __global__ __launch_bounds__(320, 1) void gemm_t160_kernel(const GemmParams p) {
         if (s < nk) issue(s, s);
     int buf = 0, fill = STAGES - 1;
     for (int kt = 0; kt < nk; ++kt) {
-        // k-tile kt has landed once all but the newer k-tiles' pieces (six per wave and k-tile) are done
+        // k-tile kt has landed once all but the newer k-tiles' pieces (four per k-tile for waves 0..3, three for waves 4..7) are done
         const int newer = min(STAGES - 2, nk - 1 - kt);
         static_assert(STAGES == 5, "the counted waits below cover up to three newer k-tiles");
-        if (newer >= 3) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-        else if (newer == 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else if (newer == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (wave < 4) {
+            if (newer >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else if (newer == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (newer == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            if (newer >= 3) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+            else if (newer == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if (newer == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();   // ... for every wave; and every wave has retired its reads of k-tile kt - 1
         asm volatile("" ::: "memory");
         if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1, fill);
         const char* const st = smem + buf * STAGE_B;
+        buf = buf + 1 == STAGES ? 0 : buf + 1;
+        fill = fill + 1 == STAGES ? 0 : fill + 1;
+        if (!compute) continue;   // waves 5..7 only stage
         h8 af[4][2], bf[4];
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
@@ -133,14 +157,13 @@ __global__ __launch_bounds__(320, 1) void gemm_t160_kernel(const GemmParams p) {
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
                 acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[kk], af[kk][mi], acc[mi], 0, 0, 0);
-        buf = buf + 1 == STAGES ? 0 : buf + 1;
-        fill = fill + 1 == STAGES ? 0 : fill + 1;
     }
     __syncthreads();   // the last stage has been read by everyone: the staging tile of the epilogue may overwrite it
 
     // ---- epilogue, stage 1: bias (or the fused-LayerNorm consumer form), round to f16, park the tile in LDS as [m][n].
     // D layout (operands swapped): register r of a block is tile column (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of the wave's strip.
     char* const sC = smem;
+    if (compute) {
     const int nw = n0 + wave * 32;
     h4 bq[4];
 #pragma unroll
@@ -158,7 +181,7 @@ __global__ __launch_bounds__(320, 1) void gemm_t160_kernel(const GemmParams p) {
         // the two half-waves hold the same rows and take two chains each
         const int strips = p.ln_nstrips > 0 ? p.ln_nstrips : (p.K >> 6);
         float sa[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, qa[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-        constexpr int JJ = 5;
+        constexpr int JJ = 6;   // 24 entries (a gemm_t160_kernel producer at N = 1280) in one round of loads
         for (int base = 0; base < strips; base += 4 * JJ) {
             f32x2 t[2][2][JJ];
 #pragma unroll
@@ -217,10 +240,12 @@ __global__ __launch_bounds__(320, 1) void gemm_t160_kernel(const GemmParams p) {
             *reinterpret_cast<h4*>(sC + ml * CS + (wave * 32 + 8 * g + 4 * lhi) * 2) = o;
         }
     }
+    }   // compute waves
     __syncthreads();
     // ---- stage 2: thread t takes 16-byte chunk t % 20 of rows t / 20 + 16 j: 320-byte row segments per 20 lanes
     const int c = tid % 20, r16 = tid / 20;
     const int n = n0 + c * 8;
+    if (tid < NCOMP * 64) {
     h8 rv[4];
     if (p.residual) {
 #pragma unroll
@@ -236,7 +261,8 @@ __global__ __launch_bounds__(320, 1) void gemm_t160_kernel(const GemmParams p) {
         if (p.residual) v = v + rv[j];   // v_pk_add_f16: the same number as (f16)((float)a + (float)b) (tests/test_f16_add_equivalence.py)
         if (m < p.M) *reinterpret_cast<h8*>(p.C + (long)m * p.ldc + n) = v;
         if (p.stats_out) {
-            // producer: (sum, sum of squares) of the 32-column strip c >> 2 of this row = the four lanes of a quad
+            // producer: (sum, sum of squares) of the 32-column piece c >> 2 of this row = the four lanes of a quad (20 lanes per
+            // row: quads are the largest lane groups that never straddle a row or a wave) -> LDS behind the staging tile
             float s1 = 0.f, q1 = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -248,10 +274,19 @@ __global__ __launch_bounds__(320, 1) void gemm_t160_kernel(const GemmParams p) {
             q1 += ds_dpp_f32<0xB1>(q1);
             s1 += ds_dpp_f32<0x4E>(s1);
             q1 += ds_dpp_f32<0x4E>(q1);
-            if ((c & 3) == 0 && m < p.M) {
-                f32x2 o2 = {s1, q1};
-                *reinterpret_cast<f32x2*>(p.stats_out + 2 * ((long)(n >> 5) * p.M + m)) = o2;
-            }
+            if ((c & 3) == 0) *reinterpret_cast<f32x2*>(smem + RED_OFF + (row * 5 + (c >> 2)) * 8) = f32x2{s1, q1};
+        }
+    }
+    }   // threads 0..319
+    if (p.stats_out) {
+        // three entries per row and tile: pieces (0 + 1), (2 + 3), 4; wave e writes entry e of the 64 rows (512 contiguous bytes)
+        __syncthreads();
+        if (tid < 192) {
+            const int e = tid >> 6, row = tid & 63, m = m0 + row;
+            const f32x2* const r5 = reinterpret_cast<const f32x2*>(smem + RED_OFF) + row * 5;
+            f32x2 o2 = r5[2 * e];
+            if (e < 2) o2 = o2 + r5[2 * e + 1];
+            if (m < p.M) *reinterpret_cast<f32x2*>(p.stats_out + 2 * ((long)(tn * 3 + e) * p.M + m)) = o2;
         }
     }
 }
@@ -273,7 +308,7 @@ bool ds_gemm_t160_possible(const GemmParams& p, int batch) {
     if (p.conv || p.A2 || p.rowbias || p.epi != EPI_NONE || p.dtype != DS_DTYPE_F16 || p.ln_swapped || batch != 1) return false;
     if (p.M <= 0 || p.N % TN != 0 || p.K % 64 != 0 || p.K <= 0) return false;
     if (p.ln_stats && !p.ln_partial) return false;            // finalised statistics are gemm_pp_kernel's consumer form
-    if (p.stats_out && p.stats_strip != 32) return false;     // 64-column statistics need whole 64-column strips per tile
+    if (p.stats_out && p.stats_strip != 160) return false;    // 64-column statistics need whole 64-column strips per tile
     if (p.lda * 63 + 64 >= (1L << 30) || p.ldw * 159 + 64 >= (1L << 30)) return false;   // 32-bit lane offsets
     return true;
 }
@@ -287,16 +322,16 @@ int ds_launch_gemm_t160(const GemmParams& p0, hipStream_t stream) {
     constexpr int STAGES = 5;
     DS_REQUIRE(p.N % TN == 0 && p.K % 64 == 0 && !p.A2 && !p.rowbias && p.epi == EPI_NONE,
                "gemm_t160: shape M=%d N=%d K=%d not supported", p.M, p.N, p.K);
-    DS_REQUIRE(!p.stats_out || p.stats_strip == 32, "gemm_t160: emits 32-column statistics only (stats_strip = %d)", p.stats_strip);
+    DS_REQUIRE(!p.stats_out || p.stats_strip == 160, "gemm_t160: emits its own statistics format only (stats_strip = %d, expected 160)", p.stats_strip);
     DS_REQUIRE(!p.ln_stats || (p.ln_partial && p.ln_c && !p.ln_swapped), "gemm_t160: consumes partial LayerNorm sums in the row form only");
     p.tiles_m = (p.M + TM - 1) / TM;
     p.tiles_n = p.N / TN;
-    const size_t lds = (size_t)STAGES * STAGE_B + 1024;
+    const size_t lds = (size_t)STAGES * STAGE_B;
     auto kern = gemm_t160_kernel<STAGES>;
     static unsigned long long attr_devs = 0;
     if (ds_first_on_device(attr_devs))
         DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(320), lds, stream, p);
+    hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(NWAVES * 64), lds, stream, p);
     DS_LAUNCH_CHECK();
     return 0;
 }

@@ -446,8 +446,8 @@ class UNetEngine:
         """ln_stats / ln_c: this GEMM consumes a fused LayerNorm (x is the raw residual stream, wt / bias the `_ln` copies);
         ln_partial: ln_stats are the producer's partial sums and the kernel finalises its own rows (the 128-wide kernels);
         stats_out: it emits the row statistics of what it stores (csrc/gemm_pp.hip, "LayerNorm"; csrc/gemm.hip, "Fused LayerNorm");
-        stats_strip: columns per statistics strip the producer is asked for (0 = 64; 32 where gemm_t160_kernel runs the producer),
-        ln_nstrips: strips per row a consumer of partial sums adds up (0 = K / 64)."""
+        stats_strip: statistics format the producer is asked for (0 / 64 = one entry per 64 columns; 160 = gemm_t160_kernel's three per tile),
+        ln_nstrips: entries per row a consumer of partial sums adds up (0 = K / 64)."""
         n_out = N // 2 if geglu else N
         ops.append(make_op("GEMM", i=(M, N, K, K1 if x2 is not None else K, int(geglu), 1, 0, 1, 0, int(ln_partial),
                                       int(ln_nstrips) if ln_stats is not None else 0, int(stats_strip) if stats_out is not None else 0),
@@ -524,11 +524,11 @@ class UNetEngine:
         k_qk, k_ffd, k_v = kind(M, 2 * Cc, Cc), kind(M, Cc, 4 * Cc), kind(Cc, Np, Cc, 0, B)
         fuse1 = (fuse and f"{p}.transformer_blocks.0.attn1.qk.weight_ln" in w and pays(k_qk) and pays(k_ffd) and pays(k_v)
                  and (k_v == 2 or (Np == N and can(Cc, N, Cc, 0, B))))
-        # Statistics strips: 64 columns, or 32 where the producers of this level (N = Cc, K = Cc | 4 Cc: proj_in, both
-        # out-projections, the FF down-projection) run gemm_t160_kernel - its 160-column tiles hold no whole 64-column strips
-        # (csrc/gemm_t160.hip; the rule does not depend on K, so every producer of a level emits the same format)
-        sw = 32 if (int(lib.ds_gemm_t160_fits(M, Cc, Cc, 1)) and int(lib.ds_gemm_t160_fits(M, Cc, 4 * Cc, 1))) else 64
-        nstr = Cc // sw
+        # Statistics entries per row: one per 64 columns, or three per 160 columns where the producers of this level (N = Cc,
+        # K = Cc | 4 Cc: proj_in, both out-projections, the FF down-projection) run gemm_t160_kernel - its 160-column tiles hold no
+        # whole 64-column strips (csrc/gemm_t160.hip; the rule does not depend on K, so every producer of a level emits one format)
+        sw = 160 if (int(lib.ds_gemm_t160_fits(M, Cc, Cc, 1)) and int(lib.ds_gemm_t160_fits(M, Cc, 4 * Cc, 1))) else 64
+        nstr = 3 * (Cc // 160) if sw == 160 else Cc // 64
         if fuse:
             part = self._buf32("ln_part", a.level, nstr * M * 2)
             st = self._buf32("ln_stats", a.level, M * 2)

@@ -71,8 +71,9 @@ int ds_set_option(const char* key, int value);
 int ds_debug_counter(const char* name, int reset, long long* value);
 /* Host-side query of the dispatch rule (no GPU work): 1 when a plain f16 GEMM of this shape runs gemm_t160_kernel (64 x 160
  * tiles, one block per CU: the M = 2048, N = 1280 projections of a batch-1 request at 1024 x 1024).  A launch planner asks
- * before it requests that kernel's 32-column LayerNorm statistics (DsOp GEMM i[11] = 32) and tells the consumers to sum
- * N / 32 strips (i[10]); a direct ds_gemm_ln_* call always gets the 64-column format. */
+ * before it requests that kernel's LayerNorm statistics format (DsOp GEMM i[11] = 160: three partial pairs per row and
+ * 160-column tile - columns 0..63, 64..127, 128..159) and tells the consumers to add 3 N / 160 entries (i[10]); a direct
+ * ds_gemm_ln_* call always gets the 64-column format. */
 int ds_gemm_t160_fits(int M, int N, int K, int batch);
 /* Host-side query: partial-sum chunks per image that a stride-1 3x3 convolution of this shape writes for the GroupNorm behind
  * it (DsOp CONV3X3 p[6] = the GroupNorm workspace; DsOp GROUPNORM i[6] = this number: the GroupNorm then skips its statistics
@@ -352,7 +353,7 @@ int ds_resize_v_norm_u8(const uint8_t* tmp, int Ht, int Wt, const int32_t* first
 enum ds_opcode {
     DS_OP_GEMM = 1,          /* p: x, x2, w, y, bias, rowbias, residual, ln_stats, ln_c, stats_out (fused LayerNorm, see ds_gemm_ln_f16; i[8] = operand-swapped form, l[10] = ln_bstride; i[9] = ln_stats holds PARTIAL sums, f[0] = eps, l[11] = ln_rows: ds_gemm_ln_partial_f16 / ds_gemm_ln_swapped_partial_f16)   l: ldx ldx2 ldw ldy ldr sx sx2 sw sy sr
                                 i: M N K K1 epilogue batch rowbias_ld rows_per_group; i[10] = strips a consumer of partial sums adds per
-                                row (0 = K / 64), i[11] = columns per statistics strip a producer emits (0 = 64; 32: ds_gemm_t160_fits) */
+                                row (0 = K / 64), i[11] = statistics format a producer emits (0 = one entry per 64 columns; 160: ds_gemm_t160_fits) */
     DS_OP_CONV3X3 = 2,       /* p: x, w, y, bias, rowbias, residual, gn_partial (optional: GroupNorm workspace, see ds_conv3x3_gn_chunks)
                                 i: B H W Cin Cout stride upsample rowbias_ld Hout Wout (upsample only; 0 0 = 2H x 2W) */
     DS_OP_GROUPNORM = 3,     /* p: x1, x2, y, gamma, beta, ws             i: B HW C1 C2 groups silu pre_chunks (0, or the number of

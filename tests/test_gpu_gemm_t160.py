@@ -41,7 +41,8 @@ def _gemm_op(lib, x, w, bias=None, residual=None, ln_partial=None, ln_c=None, ln
     M, K = x.shape
     N = w.shape[0]
     y = torch.empty((M, N), dtype=torch.float16, device=x.device)
-    part = torch.zeros((N // stats_strip, M, 2), dtype=torch.float32, device=x.device) if stats_strip else None
+    nent = 3 * (N // 160) if stats_strip == 160 else (N // stats_strip if stats_strip else 0)
+    part = torch.zeros((nent, M, 2), dtype=torch.float32, device=x.device) if stats_strip else None
     op = make_op("GEMM", i=(M, N, K, K, 0, 1, 0, 1, 0, int(ln_partial is not None), ln_nstrips, stats_strip), f=(1e-5,),
                  l=(K, 0, K, N, N), p=(x, None, w, y, bias, None, residual, ln_partial, ln_c, part))
     name = C.create_string_buffer(128)
@@ -103,9 +104,9 @@ def test_t160_is_the_automatic_choice_at_the_batch1_shapes_only(hip_lib):
 
 @pytest.mark.parametrize("M,K", [(2048, 1280), (2048, 5120), (1999, 1280)])
 def test_t160_producer_statistics_and_consumer_chain(hip_lib, M, K):
-    """The launch plan's sequence at UNet batch 2: out-projection + residual emitting 32-COLUMN statistics (i[11] = 32) ->
-    attn2.to_q consuming the 40 partial strips per row (i[10] = 40), on gemm_t160_kernel both; and the same partials consumed by the
-    128-wide kernels (q|k / GEGLU consumers at this batch).  vs fp32 LayerNorm + linear; the stored producer output must be
+    """The launch plan's sequence at UNet batch 2: out-projection + residual emitting gemm_t160_kernel's statistics format
+    (i[11] = 160: entries of 64 | 64 | 32 columns per tile) -> attn2.to_q consuming the 24 entries per row (i[10] = 24), on
+    gemm_t160_kernel both; and the same partials consumed by the 128-wide kernels (q|k / GEGLU consumers at this batch).  vs fp32 LayerNorm + linear; the stored producer output must be
     bit-identical to the GEMM without statistics."""
     from diffsensei_amd import _lib, ops
     from diffsensei_amd.engine import pack_ln_fused
@@ -116,23 +117,26 @@ def test_t160_producer_statistics_and_consumer_chain(hip_lib, M, K):
     h0 = (_r((M, Cc), g) * 2 + 0.5).half()
     wq, gamma, beta = _r((Cc, Cc), g, 1 / math.sqrt(Cc)), (1 + 0.2 * torch.randn(Cc, generator=g)).half(), _r((Cc,), g, 0.2)
     dv = lambda t: t.to(DEV)
-    h, part, name = _forced(lib, 11 if M % 64 else 0, lambda: _gemm_op(lib, dv(a), dv(wo), dv(bo), dv(h0), stats_strip=32))
+    h, part, name = _forced(lib, 11 if M % 64 else 0, lambda: _gemm_op(lib, dv(a), dv(wo), dv(bo), dv(h0), stats_strip=160))
     assert name == "gemm_t160_kernel" or M % 64
     plain = _forced(lib, 11, lambda: ops.gemm(dv(a), dv(wo), dv(bo), dv(h0)))
     assert torch.equal(h, plain), "statistics emission changed the stored output"
     hf = h.float().cpu()
-    strips = hf.view(M, Cc // 32, 32)
-    assert part.shape == (Cc // 32, M, 2)
-    assert torch.allclose(part[..., 0].t().cpu(), strips.sum(-1), rtol=1e-5, atol=1e-3)
-    assert torch.allclose(part[..., 1].t().cpu(), (strips * strips).sum(-1), rtol=1e-5, atol=1e-3)
+    assert part.shape == (3 * (Cc // 160), M, 2)
+    tiles = hf.view(M, Cc // 160, 160)
+    ent = torch.stack([tiles[..., :64], tiles[..., 64:128]], 2)                       # [M, tiles, 2, 64]
+    want_s = torch.cat([ent.sum(-1), tiles[..., 128:].sum(-1, keepdim=True)], 2).reshape(M, -1)
+    want_q = torch.cat([(ent * ent).sum(-1), (tiles[..., 128:] ** 2).sum(-1, keepdim=True)], 2).reshape(M, -1)
+    assert torch.allclose(part[..., 0].t().cpu(), want_s, rtol=1e-5, atol=1e-3)
+    assert torch.allclose(part[..., 1].t().cpu(), want_q, rtol=1e-5, atol=1e-3)
     # consumer: LayerNorm(h) @ wq^T on the raw h
     gw, c2, b2 = pack_ln_fused(dv(wq), None, dv(gamma), dv(beta))
     ref = F.linear(F.layer_norm(hf, (Cc,), gamma.float(), beta.float(), 1e-5), wq.float())
-    q_t160, _, nm = _forced(lib, 11, lambda: _gemm_op(lib, h, gw, b2, None, ln_partial=part, ln_c=c2, ln_nstrips=Cc // 32))
+    q_t160, _, nm = _forced(lib, 11, lambda: _gemm_op(lib, h, gw, b2, None, ln_partial=part, ln_c=c2, ln_nstrips=3 * (Cc // 160)))
     assert nm == "gemm_t160_kernel"
     assert lib.ds_set_option(b"gemm_t160", 1) == 0
     try:
-        q_wide, _, nm2 = _gemm_op(lib, h, gw, b2, None, ln_partial=part, ln_c=c2, ln_nstrips=Cc // 32)
+        q_wide, _, nm2 = _gemm_op(lib, h, gw, b2, None, ln_partial=part, ln_c=c2, ln_nstrips=3 * (Cc // 160))
     finally:
         lib.ds_set_option(b"gemm_t160", 0)
     assert nm2.startswith("gemm_glds_kernel")

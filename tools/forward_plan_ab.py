@@ -49,7 +49,7 @@ def table(eng, reps=3):
         if rep:
             for k in range(n):
                 acc[k] += evs[k].elapsed_time(evs[k + 1])
-    t = {}
+    t, shapes = {}, {}
     name = C.create_string_buffer(96)
     fl, by = C.c_double(), C.c_double()
     for k, op in enumerate(ops):
@@ -57,6 +57,13 @@ def table(eng, reps=3):
         d = t.setdefault(name.value.decode(), [0, 0.0])
         d[0] += 1
         d[1] += acc[k] / reps
+        if op.code == 1:      # GEMM: also per shape (M N K, + = residual, s = statistics out, c = LayerNorm consumer)
+            key = f"  {name.value.decode()} M={op.i[0]} N={op.i[1]} K={op.i[2]}" + (" batch=%d" % op.i[5] if op.i[5] > 1 else "") + \
+                  (" geglu" if op.i[4] == 1 else "") + (" +res" if op.p[6] else "") + (" stats" if op.p[9] else "") + (" ln" if op.p[7] else "")
+            d = shapes.setdefault(key, [0, 0.0])
+            d[0] += 1
+            d[1] += acc[k] / reps
+    t["__shapes__"] = shapes
     return t, sum(acc) / reps, n
 
 
@@ -75,5 +82,8 @@ print(f"UNet batch {B}, {LAT * 8} x {LAT * 8}: {KEY}={MODES[1]} vs {MODES[0]} ou
 for mode in MODES:
     best = min(tabs[mode], key=lambda t: t[1])
     print(f"{KEY}={mode}: forward {best[1]:.2f} ms (rounds: {[round(t[1], 2) for t in tabs[mode]]}), {best[2]} launches")
+    shapes = best[0].pop("__shapes__")
     for k, (n, ms) in sorted(best[0].items(), key=lambda kv: -kv[1][1])[:10]:
         print(f"    {k:34s} {n:4d} launches {ms:9.3f} ms")
+    for k, (n, ms) in sorted(shapes.items(), key=lambda kv: -kv[1][1])[:12]:
+        print(f"    {k:78s} x{n:4d} {ms / n * 1e3:8.1f} us  {ms:8.3f} ms")
