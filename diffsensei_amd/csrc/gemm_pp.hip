@@ -149,7 +149,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // accumulator block, rstd applied to the accumulators / as the multiplier of the bias fma); 4 consumer in the operand-swapped
 // form; 2 producer (row statistics out of the plain epilogue).  Separate instantiations - each compiles only the epilogue it
 // runs - because the kernel sits exactly at its 256-register budget.
-template <typename T, int DBG, int FUSE = 0>  // T: half_t (UNet) or bf16_t (VAE decoder).  DBG: ablation builds only: 1 = no MFMA, 2 = no tile loads, 4 = no fragment reads (garbage results), 8 = no s_setprio, 16 = clock probe written over C[0..15]; 0 in production
+template <typename T, int DBG, int FUSE = 0>  // T: half_t (UNet) or bf16_t (VAE decoder).  DBG: ablation builds only: 1 = no MFMA, 2 = no tile loads, 4 = no fragment reads (garbage results), 8 = no s_setprio, 16 = clock probe written over C[0..15], 128 = no epilogue; 0 in production
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     typedef typename Elt<T>::v8 V8;
     typedef typename Elt<T>::v4 V4;
@@ -530,6 +530,17 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
         // column (r&3) + 8*(r>>2) + 4*(lane>>5) of its 32-column strip.
         // (the lane-derived epilogue constants are rebuilt from an opaque copy so they are not kept live - spilled -
         // across the main loop)
+        bool fast = true;
+        // DBG 128 (ablation build only): NO epilogue - the accumulators are only marked as used, nothing is converted, staged or
+        // stored.  time(DBG 0) - time(DBG 128) is everything a perfect overlap of the tile boundary with MFMAs could recover
+        // (tools/pp_boundary_ablation.py, profiles/r06_pp_boundary_ablation.txt).
+        if constexpr ((DBG & 128) != 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[i][j]));
+            fast = false;   // -> pad_tail(EX_TAIL) below: no store was issued
+        } else {
         const int cm0 = __builtin_amdgcn_readfirstlane(m0), cn0 = __builtin_amdgcn_readfirstlane(n0);
         const int cbz = __builtin_amdgcn_readfirstlane(bz);   // this tile's batch item (set_tile below moves on to the next tile's)
         T* const Cg = reinterpret_cast<T*>(p.C) + (long)cbz * p.sC;
@@ -543,7 +554,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
         // 32-row piece are in flight while the previous piece is transposed through LDS and stored.
         // (the fused-LayerNorm instantiations only ever see interior tiles without a row bias: the launcher checks it, and the
         // generic epilogues are not compiled into them - the kernel has no registers to spare for paths it never takes)
-        const bool fast = FUSE != 0 ? true : is_fast(cm0, cn0);
+        fast = FUSE != 0 ? true : is_fast(cm0, cn0);
         const int nwg = cn0 + (wc >> 1) * 128 + (wc & 1) * 32;  // GEGLU: the wave's hidden strip; its gates 64 columns further
         const int nwp = cn0 + wc * 64;                          // plain: the wave's 64 adjacent columns
         // The bias slice of this tile has been sitting in the first 128 bytes of the wave's transposition tile since the
@@ -935,6 +946,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
                 }
             }
         }
+        }   // DBG 128
         if (!more) break;
         // ---- hand over to the next tile: its coordinates become the current ones, its bias / LayerNorm pieces go out behind
         // this tile's C stores (the previous contents of `ep` have been consumed), the lane-derived staging and fragment offsets
@@ -1006,7 +1018,7 @@ int ds_launch_gemm_pp(const GemmParams& p0, int batch, hipStream_t stream) {
         {1, gemm_pp_kernel<half_t, 1>},   {2, gemm_pp_kernel<half_t, 2>},   {3, gemm_pp_kernel<half_t, 3>},
         {4, gemm_pp_kernel<half_t, 4>},   {6, gemm_pp_kernel<half_t, 6>},   {8, gemm_pp_kernel<half_t, 8>},   {16, gemm_pp_kernel<half_t, 16>},
         {17, gemm_pp_kernel<half_t, 17>}, {18, gemm_pp_kernel<half_t, 18>}, {20, gemm_pp_kernel<half_t, 20>}, {22, gemm_pp_kernel<half_t, 22>},
-        {24, gemm_pp_kernel<half_t, 24>}, {32, gemm_pp_kernel<half_t, 32>}, {48, gemm_pp_kernel<half_t, 48>}, {49, gemm_pp_kernel<half_t, 49>}, {64, gemm_pp_kernel<half_t, 64>},
+        {24, gemm_pp_kernel<half_t, 24>}, {32, gemm_pp_kernel<half_t, 32>}, {48, gemm_pp_kernel<half_t, 48>}, {49, gemm_pp_kernel<half_t, 49>}, {64, gemm_pp_kernel<half_t, 64>}, {128, gemm_pp_kernel<half_t, 128>},
 #endif
         {-2, gemm_pp_kernel<half_t, 0, 1>},  // -2 / -5 / -3: fused LayerNorm, consumer (plain / GEGLU epilogue) / producer
         {-5, gemm_pp_kernel<half_t, 0, 9>},
