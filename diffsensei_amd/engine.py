@@ -455,14 +455,19 @@ class UNetEngine:
                            l=(K1 if x2 is not None else K, (K - K1) if x2 is not None else 0, K, n_out, n_out),
                            p=(x, x2, wt, y, bias, None, residual, ln_stats, ln_c, stats_out)))
 
-    def _resnet(self, ops, r: ResnetSpec, x1: Tensor, x2: Optional[Tensor], c1: int, c2: int, out: Tensor):
+    def _resnet(self, ops, r: ResnetSpec, x1: Tensor, x2: Optional[Tensor], c1: int, c2: int, out: Tensor, in_chunks: int = 0,
+                out_stats: bool = False) -> int:
+        """in_chunks > 0: the convolution that produced x1 (single source) left norm1's partial sums in the GroupNorm workspace;
+        out_stats: the NEXT op is a GroupNorm over `out` alone (a transformer's norm, or the next resnet's norm1), so conv2
+        leaves that norm's partial sums - returns their chunk count (0: not emitted)."""
         cfg, w = self.cfg, self.pk.w
         H, W = self.hw[r.level]
         HW, M = H * W, self.B * H * W
         p = r.prefix
         gn = self._buf("gn", r.level, M, max(r.cin, r.cout))
         t1 = self._buf("res_t1", r.level, M, r.cout)
-        self._gn(ops, x1, x2, gn, w[p + ".norm1.weight"], w[p + ".norm1.bias"], HW, c1, c2, cfg.norm_eps, True)
+        assert in_chunks == 0 or x2 is None
+        self._gn(ops, x1, x2, gn, w[p + ".norm1.weight"], w[p + ".norm1.bias"], HW, c1, c2, cfg.norm_eps, True, pre_chunks=in_chunks)
         rowbias = self.temb_all.data_ptr() + 2 * self.pk.temb_off[p]
         # conv1 -> norm2: the statistics of t1 come out of conv1's epilogue where a halo-patch kernel runs it (every resnet of the
         # UNet at every size up to 128 pixel tiles per image; DIFFSENSEI_GN_FUSION=0 keeps the three-launch GroupNorm: A/B)
@@ -478,9 +483,12 @@ class UNetEngine:
         else:
             assert x2 is None
             res = x1
-        self._conv(ops, gn, p + ".conv2", out, H, W, r.cout, r.cout, residual=res)
+        nch2 = int(_lib.load().ds_conv3x3_gn_chunks(self.B, H, W, r.cout, r.cout)) if (out_stats and gn_fusion_enabled()) else 0
+        self.gn_fused = getattr(self, "gn_fused", 0) + (nch2 > 0)
+        self._conv(ops, gn, p + ".conv2", out, H, W, r.cout, r.cout, residual=res, gn_stats=nch2 > 0)
+        return nch2
 
-    def _transformer(self, ops, a: AttnSpec, x: Tensor, out: Tensor):
+    def _transformer(self, ops, a: AttnSpec, x: Tensor, out: Tensor, in_chunks: int = 0):
         cfg, w, B = self.cfg, self.pk.w, self.B
         H, W = self.hw[a.level]
         N, Cc = H * W, a.channels
@@ -537,7 +545,7 @@ class UNetEngine:
         fin1 = fuse1 and (k_qk == 1 or k_v == 1)     # a finalize launch only where a gemm_pp_kernel consumer reads (mean, rstd)
         self.ln_finalize_launches = getattr(self, "ln_finalize_launches", 0) + a.depth * (
             ((1 if fin1 else 0) + (k_proj == 1) + (k_ff == 1)) if fuse else 0)
-        self._gn(ops, x, None, tn, w[p + ".norm.weight"], w[p + ".norm.bias"], N, Cc, 0, 1e-6, False)
+        self._gn(ops, x, None, tn, w[p + ".norm.weight"], w[p + ".norm.bias"], N, Cc, 0, 1e-6, False, pre_chunks=in_chunks)
         self._gemm(ops, tn, w[p + ".proj_in.weight"], h, M, Cc, Cc, bias=w[p + ".proj_in.bias"],
                    stats_out=part if fuse1 else None, stats_strip=sw)
         for k in range(a.depth):
@@ -630,14 +638,19 @@ class UNetEngine:
         # ---- 3. down (:244-265)
         for blk in topo.down:
             lvl = blk["level"]
+            nch = 0   # GroupNorm partial chunks the previous op (a resnet's conv2) left for THIS op's first norm
             for j, r in enumerate(blk["resnets"]):
                 out = new_act(lvl, r.cout, r.prefix)
-                self._resnet(ops, r, cur, None, cur_c, 0, out)
+                # conv2's output goes straight into a single-source GroupNorm when a transformer follows, or (attention-free
+                # level) the block's next resnet: conv2 then emits that norm's statistics (csrc/conv_halo.hip)
+                feeds_gn = bool(blk["attns"]) or j + 1 < len(blk["resnets"])
+                nch = self._resnet(ops, r, cur, None, cur_c, 0, out, in_chunks=nch, out_stats=feeds_gn)
                 cur, cur_c = out, r.cout
                 if blk["attns"]:
                     out2 = new_act(lvl, r.cout, blk["attns"][j].prefix)
-                    self._transformer(ops, blk["attns"][j], cur, out2)
+                    self._transformer(ops, blk["attns"][j], cur, out2, in_chunks=nch)
                     cur = out2
+                    nch = 0
                 skips.append((cur, cur_c, lvl))
             if blk["downsample"]:
                 h_, w_ = self.hw[lvl]
@@ -649,9 +662,9 @@ class UNetEngine:
         mid = topo.mid
         lvl = mid["level"]
         out = new_act(lvl, cur_c, "mid0")
-        self._resnet(ops, mid["resnets"][0], cur, None, cur_c, 0, out)
+        nch = self._resnet(ops, mid["resnets"][0], cur, None, cur_c, 0, out, out_stats=True)
         out2 = new_act(lvl, cur_c, "mid_attn")
-        self._transformer(ops, mid["attns"][0], out, out2)
+        self._transformer(ops, mid["attns"][0], out, out2, in_chunks=nch)
         out3 = new_act(lvl, cur_c, "mid1")
         self._resnet(ops, mid["resnets"][1], out2, None, cur_c, 0, out3)
         cur = out3
@@ -662,11 +675,11 @@ class UNetEngine:
                 sk, sk_c, sk_l = skips.pop()
                 assert sk_l == lvl and cur_c + sk_c == r.cin, (r.prefix, cur_c, sk_c, r.cin)
                 out = new_act(lvl, r.cout, r.prefix)
-                self._resnet(ops, r, cur, sk, cur_c, sk_c, out)
+                nch = self._resnet(ops, r, cur, sk, cur_c, sk_c, out, out_stats=bool(blk["attns"]))
                 cur, cur_c = out, r.cout
                 if blk["attns"]:
                     out2 = new_act(lvl, r.cout, blk["attns"][j].prefix)
-                    self._transformer(ops, blk["attns"][j], cur, out2)
+                    self._transformer(ops, blk["attns"][j], cur, out2, in_chunks=nch)
                     cur = out2
             if blk["upsample"]:
                 h_, w_ = self.hw[lvl]
