@@ -63,6 +63,11 @@ def table(eng, reps=3):
             d = shapes.setdefault(key, [0, 0.0])
             d[0] += 1
             d[1] += acc[k] / reps
+        if op.code == 2:      # CONV3X3: per shape (B H W Cin Cout, s2 = stride 2, up = fused upsample)
+            key = f"  {name.value.decode()} conv B={op.i[0]} {op.i[1]}x{op.i[2]} {op.i[3]}->{op.i[4]}" + (" s2" if op.i[5] == 2 else "") + (" up" if op.i[6] else "")
+            d = shapes.setdefault(key, [0, 0.0])
+            d[0] += 1
+            d[1] += acc[k] / reps
     t["__shapes__"] = shapes
     return t, sum(acc) / reps, n
 
@@ -85,5 +90,5 @@ for mode in MODES:
     shapes = best[0].pop("__shapes__")
     for k, (n, ms) in sorted(best[0].items(), key=lambda kv: -kv[1][1])[:10]:
         print(f"    {k:34s} {n:4d} launches {ms:9.3f} ms")
-    for k, (n, ms) in sorted(shapes.items(), key=lambda kv: -kv[1][1])[:12]:
+    for k, (n, ms) in sorted(shapes.items(), key=lambda kv: -kv[1][1])[:int(os.environ.get('AB_SHAPES', '12'))]:
         print(f"    {k:78s} x{n:4d} {ms / n * 1e3:8.1f} us  {ms:8.3f} ms")

@@ -6,7 +6,7 @@ out=gpurun_out
 mkdir -p "$out"
 export TMPDIR=/tmp
 python -c "import __graft_entry__ as g; g.build()" > "$out/final_run.log" 2>&1
-timeout 900 python -m pytest tests -m gpu -x -q > "$out/final_pytest_gpu.log" 2>&1
+timeout 1400 python -m pytest tests -m gpu -x -q -p no:cacheprovider > "$out/final_pytest_gpu.log" 2>&1
 echo "pytest rc=$? $(tail -1 $out/final_pytest_gpu.log)" | tee -a "$out/final_run.log"
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" >> "$out/final_run.log" 2>&1
 echo "smoke rc=$?" | tee -a "$out/final_run.log"
