@@ -68,8 +68,13 @@ int ds_set_option(const char* key, int value) {
         return 0;
     }
     if (strcmp(key, "conv_halo_variant") == 0) {
-        DS_REQUIRE(value >= 0 && value <= 2, "conv_halo_variant must be 0..2");
+        DS_REQUIRE(value >= 0 && value <= 4, "conv_halo_variant must be 0..4");
         ds_conv_halo_set_variant(value);
+        return 0;
+    }
+    if (strcmp(key, "conv_deep_blocks") == 0) {
+        DS_REQUIRE(value >= 0 && value <= 8, "conv_deep_blocks must be 0..8");
+        ds_conv_halo_set_deep_blocks(value);
         return 0;
     }
     if (strcmp(key, "llm_gemv_variant") == 0) {

@@ -87,6 +87,99 @@ __device__ __forceinline__ void gn_emit(const GemmParams& p, float (&gs)[8], flo
     }
 }
 
+// Epilogue of the two 8 x 16-pixel kernels (conv_halo_kernel, conv_halo_deep_kernel): the caller has passed its last barrier.
+template <typename T>
+__device__ __forceinline__ void conv_halo_epilogue8(const GemmParams& p, f32x16 (&acc)[2][2], char* smem, int tid, int wm, int wn,
+                                                    int l31, int lhi, int b, int oy0, int ox0, int n0, int tile_in_image) {
+    typedef typename Elt<T>::v8 V8;
+    typedef typename Elt<T>::v4 V4;
+    // ---- epilogue: bias (+ per-image bias), round to f16, park the 128 x 128 tile in LDS, then whole 16-byte pieces
+    // of output rows (+ residual).  D layout (operands swapped): lane holds row ..+(lane&31); register r is column
+    // (r&3) + 8*(r>>2) + 4*(lane>>5) of its 32-column fragment.
+    // (no branch / s_waitcnt per 4 values: biases fetched once with clamped addresses, residual pieces requested in
+    // batches of four before they are needed - see conv_halo256_kernel)
+    char* const sC = smem;
+    V4 b0[2][4], b1[2][4];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) b0[ni][g] = b1[ni][g] = V4{0, 0, 0, 0};
+    if (p.bias) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                b0[ni][g] = *reinterpret_cast<const V4*>(p.bias + min(n0 + wn * 64 + ni * 32 + 8 * g + 4 * lhi, p.N - 4));
+    }
+    if (p.rowbias) {
+        const half_t* rb = p.rowbias + (long)b * p.rowbias_ld;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                b1[ni][g] = *reinterpret_cast<const V4*>(rb + min(n0 + wn * 64 + ni * 32 + 8 * g + 4 * lhi, p.N - 4));
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int ms = wm * 64 + mi * 32 + l31;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int nl = wn * 64 + ni * 32 + 8 * g + 4 * lhi;
+                V4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[mi][ni][4 * g + e];
+                    v += (float)b0[ni][g][e];
+                    v += (float)b1[ni][g][e];
+                    o[e] = (T)v;
+                }
+                *reinterpret_cast<V4*>(sC + ms * CS_STRIDE + nl * 2) = o;
+            }
+    }
+    __syncthreads();
+    const T* const Rp = reinterpret_cast<const T*>(p.residual);
+    float gs[8], gq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) gs[e] = gq[e] = 0.f;
+#pragma unroll 1
+    for (int j0 = 0; j0 < 8; j0 += 4) {
+        long mrow[4];
+        int ncol[4];
+        bool ok[4];
+        V8 rv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int id = tid + 256 * (j0 + u);
+            const int row = id >> 4, c = id & 15;
+            const int oy = oy0 + (row >> 4), ox = ox0 + (row & 15);
+            ok[u] = (n0 + c * 8 < p.N) & (oy < p.Hout) & (ox < p.Wout);
+            mrow[u] = ((long)b * p.Hout + min(oy, p.Hout - 1)) * p.Wout + min(ox, p.Wout - 1);
+            ncol[u] = min(n0 + c * 8, p.N - 8);
+            if (Rp) rv[u] = *reinterpret_cast<const V8*>(Rp + mrow[u] * p.ldr + ncol[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int id = tid + 256 * (j0 + u);
+            const int row = id >> 4, c = id & 15;
+            V8 v = *reinterpret_cast<const V8*>(sC + row * CS_STRIDE + c * 16);
+            if (Rp) {
+                // f16: one v_pk_add_f16 per two values - the same number as (f16)((float)a + (float)b), which never rounds twice
+                // (tests/test_f16_add_equivalence.py); bf16 (VAE decoder) keeps the f32 form
+                if constexpr (std::is_same<T, half_t>::value) v = v + rv[u];
+                else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (T)((float)v[e] + (float)rv[u][e]);
+                }
+            }
+            if (ok[u]) *reinterpret_cast<V8*>(reinterpret_cast<T*>(p.C) + mrow[u] * p.ldc + ncol[u]) = v;
+            if (p.gn_partial && ok[u]) gn_accumulate(v, gs, gq);
+        }
+    }
+    if (p.gn_partial) gn_emit(p, gs, gq, smem + 128 * CS_STRIDE, tid, b, tile_in_image, n0);
+}
+
 template <typename T>  // half_t (UNet) or bf16_t (VAE decoder)
 __global__ __launch_bounds__(256, 3) void conv_halo_kernel(const GemmParams p) {
     typedef typename Elt<T>::v8 V8;
@@ -205,91 +298,7 @@ __global__ __launch_bounds__(256, 3) void conv_halo_kernel(const GemmParams p) {
     }
     __syncthreads();
 
-    // ---- epilogue: bias (+ per-image bias), round to f16, park the 128 x 128 tile in LDS, then whole 16-byte pieces
-    // of output rows (+ residual).  D layout (operands swapped): lane holds row ..+(lane&31); register r is column
-    // (r&3) + 8*(r>>2) + 4*(lane>>5) of its 32-column fragment.
-    // (no branch / s_waitcnt per 4 values: biases fetched once with clamped addresses, residual pieces requested in
-    // batches of four before they are needed - see conv_halo256_kernel)
-    char* const sC = smem;
-    V4 b0[2][4], b1[2][4];
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) b0[ni][g] = b1[ni][g] = V4{0, 0, 0, 0};
-    if (p.bias) {
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-                b0[ni][g] = *reinterpret_cast<const V4*>(p.bias + min(n0 + wn * 64 + ni * 32 + 8 * g + 4 * lhi, p.N - 4));
-    }
-    if (p.rowbias) {
-        const half_t* rb = p.rowbias + (long)b * p.rowbias_ld;
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-                b1[ni][g] = *reinterpret_cast<const V4*>(rb + min(n0 + wn * 64 + ni * 32 + 8 * g + 4 * lhi, p.N - 4));
-    }
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-        const int ms = wm * 64 + mi * 32 + l31;
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int nl = wn * 64 + ni * 32 + 8 * g + 4 * lhi;
-                V4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float v = acc[mi][ni][4 * g + e];
-                    v += (float)b0[ni][g][e];
-                    v += (float)b1[ni][g][e];
-                    o[e] = (T)v;
-                }
-                *reinterpret_cast<V4*>(sC + ms * CS_STRIDE + nl * 2) = o;
-            }
-    }
-    __syncthreads();
-    const T* const Rp = reinterpret_cast<const T*>(p.residual);
-    float gs[8], gq[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) gs[e] = gq[e] = 0.f;
-#pragma unroll 1
-    for (int j0 = 0; j0 < 8; j0 += 4) {
-        long mrow[4];
-        int ncol[4];
-        bool ok[4];
-        V8 rv[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int id = tid + 256 * (j0 + u);
-            const int row = id >> 4, c = id & 15;
-            const int oy = oy0 + (row >> 4), ox = ox0 + (row & 15);
-            ok[u] = (n0 + c * 8 < p.N) & (oy < p.Hout) & (ox < p.Wout);
-            mrow[u] = ((long)b * p.Hout + min(oy, p.Hout - 1)) * p.Wout + min(ox, p.Wout - 1);
-            ncol[u] = min(n0 + c * 8, p.N - 8);
-            if (Rp) rv[u] = *reinterpret_cast<const V8*>(Rp + mrow[u] * p.ldr + ncol[u]);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int id = tid + 256 * (j0 + u);
-            const int row = id >> 4, c = id & 15;
-            V8 v = *reinterpret_cast<const V8*>(sC + row * CS_STRIDE + c * 16);
-            if (Rp) {
-                // f16: one v_pk_add_f16 per two values - the same number as (f16)((float)a + (float)b), which never rounds twice
-                // (tests/test_f16_add_equivalence.py); bf16 (VAE decoder) keeps the f32 form
-                if constexpr (std::is_same<T, half_t>::value) v = v + rv[u];
-                else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = (T)((float)v[e] + (float)rv[u][e]);
-                }
-            }
-            if (ok[u]) *reinterpret_cast<V8*>(reinterpret_cast<T*>(p.C) + mrow[u] * p.ldc + ncol[u]) = v;
-            if (p.gn_partial && ok[u]) gn_accumulate(v, gs, gq);
-        }
-    }
-    if (p.gn_partial) gn_emit(p, gs, gq, smem + 128 * CS_STRIDE, tid, b, ty * tiles_x + tx, n0);
+    conv_halo_epilogue8<T>(p, acc, smem, tid, wm, wn, l31, lhi, b, oy0, ox0, n0, ty * tiles_x + tx);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -302,6 +311,201 @@ __global__ __launch_bounds__(256, 3) void conv_halo_kernel(const GemmParams p) {
 // while the co-resident block computes.
 // ---------------------------------------------------------------------------------------------------------------
 static_assert(128 * CS_STRIDE + 4096 <= PROWS * 128 + BN * 128, "conv_halo_kernel: staging tile + GroupNorm partials exceed its LDS");
+
+// ---------------------------------------------------------------------------------------------------------------
+// Small-grid variant of the 8 x 16 kernel (round 6): the same tile (8 x 16 output pixels x 128 channels, 4 waves), but the W
+// k-tiles go through a RING of three 16-KiB buffers (two k-tiles in flight) and the halo patch is double-buffered, so one block
+// ALONE on a CU never waits out a DMA round trip per k-tile.  Why: conv_halo_kernel hides its single W buffer's latency behind
+// the two other blocks of the CU (3 per CU); at UNet batch 2 the 1280-channel level is 160 blocks - one per CU on 160 CUs -
+// and every one of its 180 k-tiles costs a full L2 round trip: 175 us per convolution, 344 TFLOP/s, a third of the batch-2
+// forward's convolution time in thirteen launches (profiles/r06_conv_deep_ab_b2.txt).  One barrier per k-tile, at its LAST
+// k-step: every fragment of the k-tile is in registers by then (they are requested one k-step ahead, two register sets, as in
+// conv_halo256_kernel), so: counted vmcnt (W(kt+1) has landed; W(kt+2) and - for two k-tiles per slice - the next slice's patch
+// stay in flight), barrier, W(kt+3) into the buffer k-tile kt has just left, the first fragments of k-tile kt+1, the last four
+// MFMAs of k-tile kt.  (First version: all sixteen fragment reads at the top of a k-tile, then its sixteen MFMAs - with one wave
+// per SIMD nothing overlapped the reads: 120.6 us per 1280 -> 1280 convolution at batch 2 instead of 175.8; this form: see
+// profiles/r06_conv_deep_ab_b2.txt.)
+// LDS: 2 x 24 KiB patch + 3 x 16 KiB W = 96 KiB -> one block per CU: chosen only for grids of at most one block per CU.
+// (Ring depth, measured per 1280 -> 1280 convolution at UNet batch 2 against the single-buffer kernel on the same box: three
+// buffers 115.5 vs 176.7 us (0.65), five buffers - 64 KiB in flight - 130.4 vs 178.6 (0.73): more in flight does not help, the
+// k-tile is not waiting for its DMA any more; DEEP_NW stays a constant of the source.)
+// Same products in the same order as conv_halo_kernel: bit-identical results (tests/test_gpu_ops.py).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int DEEP_NW = 3;                            // W buffers in the ring: DEEP_NW - 1 k-tiles (32 KiB) in flight per CU
+constexpr int DEEP_W0 = 2 * PROWS * 128;              // byte offset of the W ring
+constexpr int DEEP_LDS = DEEP_W0 + DEEP_NW * BN * 128;  // 96 KiB
+
+template <int N>
+__device__ __forceinline__ void deep_wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 1) void conv_halo_deep_kernel(const GemmParams p) {
+    typedef typename Elt<T>::v8 V8;
+    typedef typename Elt<T>::v4 V4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int lrow = lane >> 3, slot = lane & 7;
+
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    int tm, tn;
+    tile_coords(tile, p.tiles_m, p.tiles_n, tm, tn);
+    const int tiles_x = (p.Wout + PW - 1) / PW, tiles_y = (p.Hout + PH - 1) / PH;
+    const int tx = tm % tiles_x, ty = (tm / tiles_x) % tiles_y, b = tm / (tiles_x * tiles_y);
+    const int oy0 = ty * PH, ox0 = tx * PW, n0 = tn * BN;
+
+    int poff[6];  // element offset of the lane's 16-byte chunk at channel 0, or -1: zero page (halo / pad rows)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int q = (wave * 6 + j) * 8 + lrow;
+        const int qy = q / HWD, qx = q - qy * HWD;
+        const int uy = oy0 - 1 + qy, ux = ox0 - 1 + qx;
+        const bool ok = (q < HROWS) & (uy >= 0) & (uy < p.Hout) & (ux >= 0) & (ux < p.Wout);
+        const int iy = p.upsample ? nearest_src(uy, p.up_sy, p.Hin) : uy, ix = p.upsample ? nearest_src(ux, p.up_sx, p.Win) : ux;
+        const int chunk = slot ^ ((qx >> 1) & 7);  // swizzle by patch COLUMN (see the file header)
+        poff[j] = ok ? ((b * p.Hin + iy) * p.Win + ix) * p.Cin + chunk * 8 : -1;
+    }
+    int woff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = (wave * 4 + j) * 8 + lrow;
+        const int chunk = slot ^ ((row >> 1) & 7);
+        const int n = min(n0 + row, p.N - 1);
+        woff[j] = n * (int)p.ldw + chunk * 8;
+    }
+    const unsigned lds0 = (unsigned)(size_t)(lds_void*)smem;
+    auto issue_patch = [&](int ci0, int pbuf) {
+        const unsigned d = lds0 + pbuf * (PROWS * 128) + wave * 6 * 1024;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const void* src = poff[j] >= 0 ? (const void*)(p.A + poff[j] + ci0) : (const void*)g_halo_zero_page;
+            lds_dma16_v(src, d + j * 1024);
+        }
+    };
+    auto issue_w = [&](int k0, int wbuf) {
+        const unsigned d = lds0 + DEEP_W0 + wbuf * (BN * 128) + wave * 4 * 1024;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lds_dma16_v(p.W + k0 + woff[j], d + j * 1024);
+    };
+
+    int q0[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) q0[mi] = (wm * 4 + mi * 2 + (l31 >> 4)) * HWD + (l31 & 15);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int slices = p.Cin / 64;
+    const int nkt = slices * 9;
+    auto w_k0 = [&](int kt) {   // k-tile kt = (slice, tap): column offset of its W tile (k = tap * Cin + ci)
+        const int sl = kt / 9, tp = kt - sl * 9;
+        return tp * p.Cin + sl * 64;
+    };
+    auto set_abase = [&](int (&ab)[2], int tp) {
+        const int ky = tp / 3, kx = tp - 3 * ky;
+        const int shift = ky * HWD + kx;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const int q = q0[mi] + shift;
+            ab[mi] = q * 128 + ((lhi ^ ((((l31 & 15) + kx) >> 1) & 7)) << 4);
+        }
+    };
+    auto load = [&](V8 (&af)[2], V8 (&bf)[2], const int (&ab)[2], const char* cp, const char* cw, int kk) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) af[mi] = *reinterpret_cast<const V8*>(cp + (ab[mi] ^ (kk << 5)));
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int r = wn * 64 + ni * 32 + l31;
+            bf[ni] = *reinterpret_cast<const V8*>(cw + r * 128 + swz(r, kk * 2 + lhi));
+        }
+    };
+    auto mfmas = [&](const V8 (&af)[2], const V8 (&bf)[2]) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = Elt<T>::mfma(bf[ni], af[mi], acc[mi][ni]);
+    };
+    // counted wait: everything older than the `w` newest W k-tiles (4 pieces per wave each) and - if `pn` - the patch issued
+    // among them (6 pieces) has landed; vmcnt retires in issue order, so the count is exact
+    auto wait_newer = [&](int w, bool pn) {
+        static_assert(DEEP_NW <= 6, "wait_newer covers up to five newer W k-tiles");
+        switch (w * 2 + (pn ? 1 : 0)) {
+            case 0: deep_wait_vm<0>(); break;
+            case 1: deep_wait_vm<6>(); break;
+            case 2: deep_wait_vm<4>(); break;
+            case 3: deep_wait_vm<10>(); break;
+            case 4: deep_wait_vm<8>(); break;
+            case 5: deep_wait_vm<14>(); break;
+            case 6: deep_wait_vm<12>(); break;
+            case 7: deep_wait_vm<18>(); break;
+            case 8: deep_wait_vm<16>(); break;
+            case 9: deep_wait_vm<22>(); break;
+            case 10: deep_wait_vm<20>(); break;
+            default: deep_wait_vm<26>(); break;
+        }
+    };
+    // ---- prologue: patch(0), W(0) .. W(NW - 1), patch(1) - the order every later slice repeats (its patch goes out behind the
+    // W k-tile that is NW ahead of the previous slice's last k-tile)
+    issue_patch(0, 0);
+#pragma unroll
+    for (int j = 0; j < DEEP_NW; ++j) issue_w(w_k0(j), j);          // nkt >= 9 > NW
+    if (slices > 1) issue_patch(64, 1);
+    wait_newer(DEEP_NW - 1, slices > 1);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    int s = 0, tap = 0, wb = 0;   // slice, tap, W buffer of k-tile kt
+    int abase[2];
+    set_abase(abase, 0);
+    const char* cP = smem;
+    const char* cW = smem + DEEP_W0;
+    V8 af[2][2], bf[2][2];
+    load(af[0], bf[0], abase, cP, cW, 0);
+    // ---- k-loop: the fragments of k-step kk + 1 are requested BEFORE the MFMAs of k-step kk (two register sets); at the tile's
+    // last k-step every fragment of the tile is in registers, so its W buffer goes to the k-tile three ahead and the first
+    // fragments of the next k-tile load under the last four MFMAs of this one.  ONE barrier per k-tile.
+    for (int kt = 0; kt < nkt; ++kt) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            if (kk < 3) {
+                load(af[(kk + 1) & 1], bf[(kk + 1) & 1], abase, cP, cW, kk + 1);
+            } else if (kt + 1 < nkt) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every fragment read of this k-tile has returned
+                // W(kt + 1) has landed: newer = W(kt + 2) .. W(kt + NW - 1) and, at taps 0 .. NW - 2 of a slice that has a successor,
+                // that successor's patch (issued behind W(first k-tile of the slice + NW - 1))
+                wait_newer(max(0, min(DEEP_NW - 2, nkt - 2 - kt)), tap <= DEEP_NW - 2 && s + 1 < slices);
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (kt + DEEP_NW < nkt) issue_w(w_k0(kt + DEEP_NW), wb);   // the buffer this k-tile has just left
+                const int ntap = tap == 8 ? 0 : tap + 1, ns = tap == 8 ? s + 1 : s;
+                // entering slice ns: its successor's patch goes out now, behind W(first k-tile of ns + 2) - the prologue's order -,
+                // into the buffer the slice just finished has left
+                if (ntap == 0 && ns + 1 < slices) issue_patch((ns + 1) * 64, (ns + 1) & 1);
+                tap = ntap;
+                s = ns;
+                wb = wb == DEEP_NW - 1 ? 0 : wb + 1;
+                cP = smem + (s & 1) * (PROWS * 128);
+                cW = smem + DEEP_W0 + wb * (BN * 128);
+                set_abase(abase, tap);
+                load(af[0], bf[0], abase, cP, cW, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);   // the reads go out FIRST
+            mfmas(af[kk & 1], bf[kk & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    __syncthreads();
+    conv_halo_epilogue8<T>(p, acc, smem, tid, wm, wn, l31, lhi, b, oy0, ox0, n0, ty * tiles_x + tx);
+}
+
 constexpr int PH2 = 16;
 constexpr int HROWS2 = (PH2 + 2) * HWD;   // 324 patch pixels
 constexpr int NPIECE2 = (HROWS2 + 7) / 8;  // 41 LDS-DMA pieces of 8 rows
@@ -569,11 +773,13 @@ __global__ __launch_bounds__(256, 2) void conv_halo256_kernel(const GemmParams p
     if (p.gn_partial) gn_emit(p, gs, gq, smem + 256 * CS_STRIDE, tid, b, ty * tiles_x + tx, n0);
 }
 
-static thread_local int g_halo_variant = 0;  // 0 auto, 1 force the 8 x 16 kernel, 2 force the 16 x 16 kernel (where its shape rule holds)
+static thread_local int g_deep_max_blocks_per_cu = 1;   // ring-buffered 8 x 16 kernel for grids of <= this many blocks per CU (A/B: "conv_deep_blocks")
+static thread_local int g_halo_variant = 0;  // 0 auto, 1 force the 8 x 16 kernel, 2 force the 16 x 16 kernel (where its shape rule holds), 3 force the ring-buffered 8 x 16 kernel, 4 never use it
 
 }  // namespace
 
 void ds_conv_halo_set_variant(int v) { g_halo_variant = v; }
+void ds_conv_halo_set_deep_blocks(int v) { g_deep_max_blocks_per_cu = v; }
 
 // Shapes the kernel takes: stride 1 (optionally the fused x2 upsample), Cin % 64 == 0, plain epilogue, an input small
 // enough for 32-bit element offsets; any output height / width (edge patches are masked).
@@ -589,7 +795,7 @@ static bool halo_big(const GemmParams& p) {
     const int batch = p.M / (p.Hout * p.Wout);
     const int ty16 = (p.Hout + PH2 - 1) / PH2, txs = (p.Wout + PW - 1) / PW;
     const long tiles256 = (long)batch * ty16 * txs * ((p.N + BN - 1) / BN);
-    return g_halo_variant == 2 || (g_halo_variant == 0 && tiles256 >= 1024);
+    return g_halo_variant == 2 || ((g_halo_variant == 0 || g_halo_variant == 4) && tiles256 >= 1024);
 }
 
 // Pixel tiles per image of the variant ds_launch_conv_halo runs on this problem = partial-sum chunks the GroupNorm behind it
@@ -629,6 +835,26 @@ int ds_launch_conv_halo(const GemmParams& p0, hipStream_t stream) {
         return 0;
     }
     p.tiles_m = batch * ty8 * txs;
+    // Grids of at most one 8 x 16 block per CU (UNet batch 2 at the 1280-channel level: 160 blocks): the ring-buffered variant -
+    // nothing else on the CU hides the single-buffer kernel's DMA round trip per k-tile.  f16 only (the bf16 VAE decoder never
+    // has such a grid).  Same bits out.
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        DS_HIP(hipGetDevice(&dev));
+        DS_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        if (cus <= 0) cus = 256;
+    }
+    const long blocks8 = (long)p.tiles_m * p.tiles_n;
+    if (p.dtype == DS_DTYPE_F16 && (g_halo_variant == 3 || (g_halo_variant == 0 && blocks8 <= g_deep_max_blocks_per_cu * (long)cus))) {
+        static unsigned long long attr_devs_deep = 0;
+        if (ds_first_on_device(attr_devs_deep))
+            DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_deep_kernel<half_t>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)DEEP_LDS));
+        hipLaunchKernelGGL(conv_halo_deep_kernel<half_t>, dim3(p.tiles_m * p.tiles_n), dim3(256), (size_t)DEEP_LDS, stream, p);
+        DS_LAUNCH_CHECK();
+        return 0;
+    }
     const size_t lds = PROWS * 128 + BN * 128;  // 40 KiB; the 128 x 272 B epilogue tile (34 KiB) + 4 KiB of GroupNorm partials fit inside
     dim3 grid(p.tiles_m * p.tiles_n);
     if (p.dtype == DS_DTYPE_BF16) hipLaunchKernelGGL(conv_halo_kernel<bf16_t>, grid, dim3(256), lds, stream, p);

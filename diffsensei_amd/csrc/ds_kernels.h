@@ -57,7 +57,8 @@ int ds_launch_gemm_pp(const GemmParams& p, int batch, hipStream_t stream);
 bool ds_conv_halo_applicable(const GemmParams& p);  // conv_halo.hip: halo-patch 3x3 convolution takes this shape
 int ds_launch_conv_halo(const GemmParams& p, hipStream_t stream);
 int ds_conv_halo_gn_chunks(const GemmParams& p);  // pixel tiles per image of the variant ds_launch_conv_halo would run; 0: no statistics (too many tiles / not applicable)
-void ds_conv_halo_set_variant(int v);  // 0 auto, 1 8x16-pixel blocks, 2 16x16-pixel blocks
+void ds_conv_halo_set_variant(int v);  // 0 auto, 1 8x16-pixel blocks, 2 16x16-pixel blocks, 3 ring-buffered 8x16 blocks, 4 auto without the ring-buffered kernel
+void ds_conv_halo_set_deep_blocks(int v);  // the ring-buffered 8x16 kernel takes grids of <= v blocks per CU (default 1)
 const char* ds_gemm_kernel_name(const GemmParams& p, int batch);  // the instantiation ds_launch_gemm dispatches to
 void ds_gemm_set_debug(int v);
 void ds_gemm_set_ring(int v);     // 0 auto (ring-buffered kernel for small grids), 1 never

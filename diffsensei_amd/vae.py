@@ -300,11 +300,7 @@ class VaeDecoderEngine:
         if z.dim() != 4 or z.shape[1] != self.config.latent_channels:
             raise ValueError(f"expected latents [B,{self.config.latent_channels},h,w], got {tuple(z.shape)}")
         B, _, h, w = z.shape
-        # the conv kernel addresses its input with 32-bit element offsets: the widest full-resolution activation
-        # ([chunk, 8h, 8w, C1]) bounds how many images go through one launch sequence (7 at 1024^2 -> chunks of 4)
-        per_image = (8 * h) * (8 * w) * max(self.config.block_out_channels[1], self.config.block_out_channels[0])
-        chunk = max(1, min(B, (2 ** 31 - 1) // per_image))
-        chunk = 1 << (chunk.bit_length() - 1)
+        chunk = self.decode_chunk(h, w, B)
         if B > chunk:
             parts = [self.decode(z[i:i + chunk], False, generator, scaling_factor, denormalize, latents_affine)[0]
                      for i in range(0, B, chunk)]
@@ -327,6 +323,13 @@ class VaeDecoderEngine:
         x = self._gn(x, "decoder.conv_norm_out", True)
         img = ops.vae_conv_out(x, self.w["decoder.conv_out.weight"], self.w["decoder.conv_out.bias"], denormalize)
         return DecoderOutput(img) if return_dict else (img,)
+
+    def decode_chunk(self, h: int, w: int, B: int) -> int:
+        """Images that go through one launch sequence: the conv kernel addresses its input with 32-bit element offsets, so the
+        widest full-resolution activation ([chunk, 8h, 8w, C1]) bounds it (7 at 1024^2 -> chunks of 4)."""
+        per_image = (8 * h) * (8 * w) * max(self.config.block_out_channels[1], self.config.block_out_channels[0])
+        chunk = max(1, min(B, (2 ** 31 - 1) // per_image))
+        return 1 << (chunk.bit_length() - 1)
 
     # ---- plumbing the reference pipeline touches
     def to(self, *a, **k):

@@ -44,8 +44,11 @@ int ds_device_info(int* cu_count, int* lds_bytes, char* arch_name, int arch_name
  *                        0 one block per CU with a partial last round
  *   "gemm_ring"          0 (default) grids of <= 512 64x128 blocks (num_samples 1) use the ring-buffered
  *                        gemm_glds_kernel<64,false,3|4> | 1 never (A/B: profiles/r02_ring_in_pipeline_ab.txt)
- *   "conv_halo_variant"  0 auto (16x16-pixel blocks from 1024 blocks on) | 1 force conv_halo_kernel (8x16 pixels) |
- *                        2 force conv_halo256_kernel (16x16 pixels)
+ *   "conv_halo_variant"  0 auto (16x16-pixel blocks from 1024 blocks on; the ring-buffered 8x16 kernel for grids of at most
+ *                        "conv_deep_blocks" blocks per CU) | 1 force conv_halo_kernel (8x16 pixels) | 2 force conv_halo256_kernel
+ *                        (16x16 pixels) | 3 force conv_halo_deep_kernel (8x16 pixels, W ring of three buffers: small grids) |
+ *                        4 auto without conv_halo_deep_kernel (A/B)
+ *   "conv_deep_blocks"   grids of <= this many 8x16 blocks per CU run conv_halo_deep_kernel (default 1; 0 = never)
  *   "attn_variant"       0 auto (>= 128 blocks of 256 query rows: the software-pipelined self_attn_sp_kernel - every UNet shape
  *                        at every batch; smaller grids: self_attn_kernel<1>) | 1 force self_attn_kernel<1> (32 rows per wave) |
  *                        2 force self_attn_kernel<2> (64 rows per wave) | 3 force self_attn_sp_kernel | 4 the same with the

@@ -25,7 +25,8 @@ def _run(lib, op):
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,variant", [(2, 32, 32, 1280, 1280, 0), (2, 32, 32, 640, 320, 2), (3, 18, 13, 64, 320, 1),
-                                                    (16, 32, 32, 320, 640, 2), (2, 64, 64, 320, 320, 0), (1, 40, 24, 128, 192, 2)])
+                                                    (16, 32, 32, 320, 640, 2), (2, 64, 64, 320, 320, 0), (1, 40, 24, 128, 192, 2),
+                                                    (2, 32, 32, 1280, 1280, 3), (2, 32, 32, 1280, 1280, 1)])
 def test_groupnorm_from_conv_partials(hip_lib, B, H, W, Cin, Cout, variant):
     from diffsensei_amd import _lib, ops
     from diffsensei_amd.engine import make_op

@@ -325,7 +325,9 @@ def _conv_case(g, B, H, W, Cin, Cout, up, dtype=torch.float16):
 def test_conv_halo256_forced_variant(hip_lib, B, H, W, Cin, Cout, up):
     """`conv_halo256_kernel<half>` (16x16-pixel blocks; the variant the benchmark's batch-32 forward dispatches to) forced
     with conv_halo_variant 2 on shapes whose grids are far below its automatic threshold, incl. ragged edge patches and the
-    fused x2 upsample: vs F.conv2d in fp32, and bit-identical to `conv_halo_kernel` (8x16 pixels, variant 1)."""
+    fused x2 upsample: vs F.conv2d in fp32, and bit-identical to `conv_halo_kernel` (8x16 pixels, variant 1) - and so is
+    `conv_halo_deep_kernel` (variant 3: the ring-buffered 8x16 kernel small grids dispatch to since round 6; one to twenty
+    channel slices, ragged patches, the fused upsample, per-image bias + residual)."""
     from diffsensei_amd import _lib
     ops = _ops(hip_lib)
     lib = _lib.load()
@@ -337,7 +339,7 @@ def test_conv_halo256_forced_variant(hip_lib, B, H, W, Cin, Cout, up):
     res_d = res.permute(0, 2, 3, 1).contiguous().to(DEV)
     out = {}
     try:
-        for v in (1, 2):
+        for v in (1, 2, 3, 0):
             assert lib.ds_set_option(b"conv_halo_variant", v) == 0
             out[v] = (ops.conv3x3(x, w, b, upsample=up),
                       ops.conv3x3(x, w, b, upsample=up, rowbias=rb.to(DEV), residual=res_d))
@@ -345,7 +347,10 @@ def test_conv_halo256_forced_variant(hip_lib, B, H, W, Cin, Cout, up):
         lib.ds_set_option(b"conv_halo_variant", 0)
     _close(out[2][0].permute(0, 3, 1, 2), ref, what="halo256")
     _close(out[2][1].permute(0, 3, 1, 2), ref2, what="halo256+rowbias+res")
+    _close(out[3][0].permute(0, 3, 1, 2), ref, what="halo deep")
     assert torch.equal(out[1][0], out[2][0]) and torch.equal(out[1][1], out[2][1]), "16x16 and 8x16 halo kernels differ"
+    assert torch.equal(out[1][0], out[3][0]) and torch.equal(out[1][1], out[3][1]), "ring-buffered and single-buffer 8x16 kernels differ"
+    assert torch.equal(out[1][0], out[0][0]) and torch.equal(out[1][1], out[0][1]), "automatic dispatch differs"
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,up", [(8, 128, 128, 320, 320, False), (16, 32, 32, 640, 640, True)])

@@ -272,3 +272,27 @@ def test_wide_attention_f16_at_decode_size(hip_lib):
         rel = ((got - ref).norm() / ref.norm()).item()
         print(f"wide_attn_kernel<half> N = {N}, n_valid = {nv or N}: rel-L2 {rel:.3e}")
         assert rel <= 2e-3, rel
+
+
+def test_pipelined_pil_postprocess_equals_one_shot(hip_lib, monkeypatch):
+    """`DiffSenseiPipeline._postprocess(output_type="pil")` for several images decodes chunk by chunk and wraps chunk i into PIL
+    images while chunk i + 1 is on the GPU (reference pipeline_diffsensei.py:359-367): the bytes must be those of the one-shot
+    path (one image at a time goes through it), in order, whatever the chunking."""
+    import numpy as np
+    from diffsensei_amd.pipeline import DiffSenseiPipeline
+    from diffsensei_amd.vae import VaeConfig, VaeDecoderEngine, random_state_dict
+    cfg = VaeConfig()
+    eng = VaeDecoderEngine.from_state_dict(random_state_dict(cfg, 5), cfg, DEV)
+    pipe = object.__new__(DiffSenseiPipeline)
+    pipe.vae = eng
+    g = torch.Generator().manual_seed(2)
+    lat = (torch.randn(5, 4, 16, 24, generator=g) * 0.13025).half().to(DEV)
+    monkeypatch.setattr(VaeDecoderEngine, "decode_chunk", lambda self, h, w, B: min(B, 2))     # 5 images -> chunks 2, 2, 1
+    many = pipe._postprocess(lat, "pil")
+    assert len(many) == 5 and all(im.size == (24 * 8, 16 * 8) for im in many)
+    for i in range(5):
+        one = pipe._postprocess(lat[i:i + 1], "pil")       # B = 1: the one-shot path
+        assert len(one) == 1 and np.array_equal(np.asarray(one[0]), np.asarray(many[i])), i
+    pt = pipe._postprocess(lat, "pt")
+    u8 = (pt.permute(0, 2, 3, 1).float().cpu().numpy() * 255).round().astype("uint8")
+    assert all(np.array_equal(u8[i], np.asarray(many[i])) for i in range(5))
