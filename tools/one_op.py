@@ -4,6 +4,8 @@
     python tools/one_op.py conv   [reps]     conv_halo256_kernel: B=32, 32x32, 1280 -> 1280 channels (a level-2 ResNet conv)
     python tools/one_op.py attn   [reps]     self_attn_kernel<2>: B=32, 10 heads, N=4096 (level-1 self-attention)
     python tools/one_op.py attn1k [reps]     self_attn_kernel<1>: B=32, 20 heads, N=1024 (level-2 self-attention)
+    python tools/one_op.py conv_b2 [reps]    conv_halo_deep_kernel: B=2, 32x32, 1280 -> 1280 (the level-2 conv of a batch-1 request)
+    python tools/one_op.py t160 [reps]       gemm_t160_kernel: M=2048, N=1280, K=1280 + bias + residual
 """
 import os
 import sys
@@ -18,11 +20,16 @@ reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 _lib.load()
 g = torch.Generator(device="cuda").manual_seed(0)
 R = lambda *s: (torch.randn(*s, generator=g, device="cuda") * 0.5).half()
-if what == "conv":
-    B, H, C = 32, 32, 1280
+if what in ("conv", "conv_b2"):
+    B, H, C = (32 if what == "conv" else 2), 32, 1280
     x, w, b = R(B, H, H, C), R(C, 3, 3, C) * ((9 * C) ** -0.5) * 2, R(C)
     fn = lambda: ops.conv3x3(x, w, b)
     flop = 2.0 * B * H * H * C * C * 9
+elif what == "t160":
+    M, N, K = 2048, 1280, 1280
+    x, w, b, r = R(M, K), R(N, K) * (K ** -0.5), R(N), R(M, N)
+    fn = lambda: ops.gemm(x, w, b, r)
+    flop = 2.0 * M * N * K
 else:
     B, heads, N = (32, 10, 4096) if what == "attn" else (32, 20, 1024)
     C = heads * 64
