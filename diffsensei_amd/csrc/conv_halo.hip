@@ -328,7 +328,11 @@ static_assert(128 * CS_STRIDE + 4096 <= PROWS * 128 + BN * 128, "conv_halo_kerne
 // LDS: 2 x 24 KiB patch + 3 x 16 KiB W = 96 KiB -> one block per CU: chosen only for grids of at most one block per CU.
 // (Ring depth, measured per 1280 -> 1280 convolution at UNet batch 2 against the single-buffer kernel on the same box: three
 // buffers 115.5 vs 176.7 us (0.65), five buffers - 64 KiB in flight - 130.4 vs 178.6 (0.73): more in flight does not help, the
-// k-tile is not waiting for its DMA any more; DEEP_NW stays a constant of the source.)
+// k-tile is not waiting for its DMA any more; DEEP_NW stays a constant of the source.  Eight waves per block (4 x 2, 32 pixels x
+// 64 channels each, two per SIMD) measured the same again: 116.7 vs 177.7 us (profiles/r06_conv_deep_8waves_ab_b2.txt).  What is
+// left is the CU's fill path itself: 18.7 KiB per k-tile in 0.64 us = 29 GB/s, between the 21-25 GB/s a CU draws from HBM and
+// the 35-45 it draws from the Infinity Cache / L2 whatever is in flight (tools/ubench/lds_fill_rate.hip) - the weights of a
+// batch-1 request are read cold.)
 // Same products in the same order as conv_halo_kernel: bit-identical results (tests/test_gpu_ops.py).
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int DEEP_NW = 3;                            // W buffers in the ring: DEEP_NW - 1 k-tiles (32 KiB) in flight per CU
