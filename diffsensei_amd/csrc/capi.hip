@@ -92,6 +92,11 @@ int ds_set_option(const char* key, int value) {
         ds_gemm_set_ring(value);
         return 0;
     }
+    if (strcmp(key, "gemm_pp_narrow") == 0) {
+        DS_REQUIRE(value >= 0 && value <= 1, "gemm_pp_narrow must be 0 (auto) or 1 (N, K <= 640 never on gemm_pp_kernel)");
+        ds_gemm_set_pp_narrow(value);
+        return 0;
+    }
     if (strcmp(key, "gemm_pp_even") == 0) {
         ds_gemm_pp_set_even(value);
         return 0;

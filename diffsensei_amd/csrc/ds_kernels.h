@@ -62,6 +62,7 @@ void ds_conv_halo_set_deep_blocks(int v);  // the ring-buffered 8x16 kernel take
 const char* ds_gemm_kernel_name(const GemmParams& p, int batch);  // the instantiation ds_launch_gemm dispatches to
 void ds_gemm_set_debug(int v);
 void ds_gemm_set_ring(int v);     // 0 auto (ring-buffered kernel for small grids), 1 never
+void ds_gemm_set_pp_narrow(int v);  // 0 auto, 1: N, K <= 640 projections never on gemm_pp_kernel (A/B)
 void ds_gemm_pp_set_even(int v);  // experiment: 1 = persistent grid shrunk so that every round of tiles is full
 void ds_gemm_set_variant(int v);  // 0 auto, 1 register staging only, 2 glds (BM <= 128), 3 glds, BM = 256 when large
 // gemm_t160.hip: 64 x 160 tiles, one block per CU, for the small-batch projections of the 1280-channel level

@@ -25,6 +25,8 @@ static thread_local int g_gemm_variant = 0;  // 0 auto; A/B: 1 register staging,
 void ds_gemm_set_variant(int v) { g_gemm_variant = v; }
 static thread_local int g_gemm_ring = 0;  // 0 auto, 1 never use the ring-buffered small-grid kernel (A/B)
 void ds_gemm_set_ring(int v) { g_gemm_ring = v; }
+static thread_local int g_pp_narrow = 0;  // 0 auto, 1: the N, K <= 640 projections never run gemm_pp_kernel (the rule until round 6; A/B)
+void ds_gemm_set_pp_narrow(int v) { g_pp_narrow = v; }
 static thread_local int g_gemm_debug = 0;  // ablation switches, see GemmParams::debug
 void ds_gemm_set_debug(int v) { g_gemm_debug = v; }
 
@@ -839,7 +841,9 @@ Choice choose(const GemmParams& p, int batch) {
         //     long K (>= 4096: the FF down-projection at 320 tiles: 229 us vs 244 us); N = 640 counts its 17 % column padding;
         //   * a single partial round: >= 144 tiles with K, N >= 1280 (num_samples 4: 160 tiles, 111 us vs 145 us; 120 tiles
         //     lose: 115 us vs 90 us);
-        //   * never the short-K, narrow-N projection (N, K <= 640: +6..20 % for the 128 x 128 kernels).
+        //   * the short-K, narrow-N projection (N, K <= 640) only where its ragged third tile column takes the branch-free
+        //     epilogue (plain epilogue, N % 64 == 0, whole 256-row tiles: gemm_pp.hip `strips_ok`, round 6).  On the generic
+        //     epilogue it lost 6..20 % to the 128 x 128 kernels (rounds 1-5); knob "gemm_pp_narrow" 1 restores that rule (A/B).
         // Batched problems (the V^T projections, one GEMM per image with a shared A = Wv): their items are folded into the
         // kernel's tile walk, so the rules apply to the whole batch (round 3: 20 tiles x 32 images = 2.5 rounds run as 3).
         if (ds_gemm_pp_applicable(p)) {
@@ -848,7 +852,9 @@ Choice choose(const GemmParams& p, int batch) {
             const double useful = (double)p.M * p.N * batch / ((double)rounds * 256 * 65536);
             const bool multi = t > 256 && (useful >= 0.75 || (p.K >= 4096 && useful >= 0.6));
             const bool single = t >= 144 && t <= 256 && p.K >= 1280 && p.N >= 1280;
-            if ((multi || single) && !(p.N <= 640 && p.K <= 640)) {
+            const bool strips = g_pp_narrow != 1 && p.N % 64 == 0 && p.M % 256 == 0 && p.epi == EPI_NONE && !p.rowbias &&
+                                (g_gemm_debug & 4096) == 0;
+            if ((multi || single) && (!(p.N <= 640 && p.K <= 640) || strips)) {
                 c.kind = K_PP;
                 c.bm = 256;
             }
@@ -873,10 +879,13 @@ int ds_gemm_ln_kind(int M, int N, int K, int batch, int epi) {
     GemmParams p;
     p.M = M; p.N = N; p.K = K; p.lda = K; p.ldw = K; p.ldc = N; p.epi = epi; p.K1 = K;
     if (M <= 0 || N <= 0 || K <= 0 || batch < 1 || (epi != EPI_NONE && epi != EPI_GEGLU)) return 0;
-    if (g_gemm_variant == 3) return (M % 256 == 0 && N % 256 == 0 && ds_gemm_pp_applicable(p)) ? 1 : 0;
+    // gemm_pp_kernel's fused epilogues: whole 256-row tiles; whole 256-column tiles, or - plain epilogue, unbatched (the batched
+    // problem is the operand-swapped consumer, whose statistics run along the tile columns) - whole 64-column strips
+    const bool cols_ok = N % 256 == 0 || (N % 64 == 0 && epi == EPI_NONE && batch == 1 && (g_gemm_debug & 4096) == 0);
+    if (g_gemm_variant == 3) return (M % 256 == 0 && cols_ok && ds_gemm_pp_applicable(p)) ? 1 : 0;
     if (g_gemm_variant != 0) return 0;
     const Kind k = choose(p, batch).kind;
-    if (k == K_PP) return (M % 256 == 0 && N % 256 == 0) ? 1 : 0;
+    if (k == K_PP) return (M % 256 == 0 && cols_ok) ? 1 : 0;
     if ((k == K_GLDS1 || k == K_GLDS2 || k == K_RING || k == K_T160) && K % 64 == 0) return 2;   // (a PRODUCER also needs N % 128 == 0 and no batch)
     return 0;
 }
@@ -936,7 +945,8 @@ int ds_launch_gemm(const GemmParams& p_in, int batch, hipStream_t stream) {
         //   consumer of partial sums: the 128-wide kernels (shared epilogue of this file);
         //   producer: the consumer's family if the call is both, else what the dispatch picks, else whichever can.
         DS_REQUIRE(!conv && p.dtype == DS_DTYPE_F16 && !p.A2 && !p.rowbias, "gemm: fused LayerNorm is a plain f16 GEMM feature");
-        const bool pp_ok = ds_gemm_pp_applicable(p) && (p.ln_swapped || (p.M % 256 == 0 && p.N % 256 == 0));
+        const bool pp_ok = ds_gemm_pp_applicable(p) &&
+                           (p.ln_swapped || (p.M % 256 == 0 && (p.N % 256 == 0 || (p.N % 64 == 0 && p.epi == EPI_NONE && (g_gemm_debug & 4096) == 0))));
         const bool wide_ok = batch == 1 && p.N % 128 == 0 && p.K % 64 == 0;
         const bool wide_kind = c.kind == K_GLDS1 || c.kind == K_GLDS2 || c.kind == K_RING || c.kind == K_T160;
         auto force_wide = [&]() {

@@ -262,9 +262,15 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
         stage(1, 1, 1, 1, IC<0>{});
     };
 
-    // Interior tiles without a per-row bias or activation take the branch-free epilogues (all tiles of the UNet's shapes)
+    // Interior tiles without a per-row bias or activation take the branch-free epilogues (all tiles of the UNet's shapes).
+    // Round 6: so do the plain tiles of a ragged last tile COLUMN when N is a multiple of 64 (the 640-channel level: 2.5 tile
+    // columns) - a wave owns 64 adjacent columns, so it is wholly inside the problem (it runs the branch-free epilogue) or
+    // wholly outside (it stores nothing and only pads its vector-memory count, `wave_cols_in`).  Until then those tiles took
+    // the generic epilogue (a branch and an s_waitcnt vmcnt(0) per 4 values: 4-8 us per tile), which is why the N, K <= 640
+    // projections stayed on the 128 x 128 kernels.  gemm_debug bit 12 (4096): ragged tiles on the generic epilogue (A/B).
+    const bool strips_ok = !geglu && (p.N & 63) == 0 && (p.debug & 4096) == 0;
     auto is_fast = [&](int tm0, int tn0) -> bool {
-        return tm0 + 256 <= p.M && tn0 + 256 <= p.N && !p.rowbias && (geglu || p.epi == EPI_NONE);
+        return tm0 + 256 <= p.M && (tn0 + 256 <= p.N || strips_ok) && !p.rowbias && (geglu || p.epi == EPI_NONE);
     };
     char* const ep = smem + 8 * HT + wave * 4096;  // wave-private transposition tile of the epilogue
     // One LDS-DMA piece: the bias values of the wave's 64 output columns (GEGLU: 32 hidden | their 32 gates) -> bytes
@@ -272,7 +278,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     // still uses `ep`), so it is one of the EX_TAIL instructions and has landed long before the epilogue reads it.
     auto stage_bias = [&](int tn0) {
         const int l7 = lane_id() & 7;
-        const int col = geglu ? tn0 + (wc >> 1) * 128 + (wc & 1) * 32 + (l7 >> 2) * 64 + (l7 & 3) * 8 : tn0 + wc * 64 + l7 * 8;
+        int col = geglu ? tn0 + (wc >> 1) * 128 + (wc & 1) * 32 + (l7 >> 2) * 64 + (l7 & 3) * 8 : tn0 + wc * 64 + l7 * 8;
+        if (col >= p.N) col = 0;   // a wave outside a ragged tile column: a harmless piece, its count stays the same
         __builtin_amdgcn_global_load_lds((glb_void*)(p.bias + col), (lds_void*)ep, 16, 0, 0);
     };
     auto pad_tail = [&](auto nc) {  // harmless pieces into the idle last KiB of `ep` (KiB 1 and 2 hold the LayerNorm pieces)
@@ -298,7 +305,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
             __builtin_amdgcn_global_load_lds((glb_void*)(p.ln_c + 4 * (long)row), (lds_void*)(ep + 2048), 16, 0, 0);
         } else {
             const int L = ln & 15;
-            const int col = geglu ? tn0 + (wc >> 1) * 128 + (wc & 1) * 32 + (L >> 3) * 64 + (L & 7) * 4 : tn0 + wc * 64 + L * 4;
+            int col = geglu ? tn0 + (wc >> 1) * 128 + (wc & 1) * 32 + (L >> 3) * 64 + (L & 7) * 4 : tn0 + wc * 64 + L * 4;
+            if (col >= p.N) col = 0;   // (see stage_bias)
             __builtin_amdgcn_global_load_lds((glb_void*)(p.ln_c + 2 * (long)col), (lds_void*)(ep + 1024), 16, 0, 0);
             const int row = tm0 + (ln >> 5) * 128 + wr * 64 + (ln & 31) * 2;
             __builtin_amdgcn_global_load_lds((glb_void*)(p.ln_stats + 2 * (long)row), (lds_void*)(ep + 2048), 16, 0, 0);
@@ -531,6 +539,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
         // (the lane-derived epilogue constants are rebuilt from an opaque copy so they are not kept live - spilled -
         // across the main loop)
         bool fast = true;
+        bool wave_cols_in = true;   // false: this wave's 64 columns lie past N (ragged last tile column): nothing to store
         // DBG 128 (ablation build only): NO epilogue - the accumulators are only marked as used, nothing is converted, staged or
         // stored.  time(DBG 0) - time(DBG 128) is everything a perfect overlap of the tile boundary with MFMAs could recover
         // (tools/pp_boundary_ablation.py, profiles/r06_pp_boundary_ablation.txt).
@@ -827,7 +836,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
             // epilogue above - was built and measured for these plain tiles too: 128-byte rows leave as four 32-byte pieces from four
             // instructions and the residual rows arrive the same way: +4 % on the plain shapes, +15 % with a residual
             // (profiles/r05_pp_direct_epilogue_ab.txt).  Only the 64-byte rows of the GEGLU tiles go direct.)
-            if (__builtin_amdgcn_readfirstlane((int)(Rg != nullptr))) plain(IC<1>{});
+            wave_cols_in = nwp < p.N;   // wave-uniform (N % 64 == 0: all of the wave's 64 columns or none)
+            if (!wave_cols_in) {
+            } else if (__builtin_amdgcn_readfirstlane((int)(Rg != nullptr))) plain(IC<1>{});
             else plain(IC<0>{});
         } else if constexpr (FUSE != 0) {
         } else if (geglu) {
@@ -956,7 +967,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
         gA[0] = nA[0], gA[1] = nA[1], gB[0] = nB[0], gB[1] = nB[1];
         if (p.bias && is_fast(m0, n0)) stage_bias(n0);
         if constexpr ((FUSE & 5) != 0) stage_ln(m0, n0, bz);
-        if (!fast) pad_tail(IC<EX_TAIL>{});             // generic epilogue: its store count depends on the tile's edges
+        if (!fast || !wave_cols_in) pad_tail(IC<EX_TAIL>{});   // generic epilogue: its store count depends on the tile's edges; a wave outside a ragged column: no store
         else if (FUSE == 0 && geglu) pad_tail(IC<(EX_TAIL > 8 ? EX_TAIL - 8 : 0)>{});   // unfused GEGLU tile: 8 stores
         derive_stage();
         derive_frag();
@@ -995,8 +1006,9 @@ int ds_launch_gemm_pp(const GemmParams& p0, int batch, hipStream_t stream) {
     GemmParams p = p0;
     DS_REQUIRE(ds_gemm_pp_applicable(p), "gemm_pp: shape M=%d N=%d K=%d not supported", p.M, p.N, p.K);
     if (p.ln_stats || p.ln_c || p.stats_out) {  // fused LayerNorm: only the branch-free epilogues implement it
-        DS_REQUIRE(p.M % 256 == 0 && p.N % 256 == 0 && !p.rowbias && (p.epi == EPI_NONE || p.epi == EPI_GEGLU),
-                   "gemm_pp: fused LayerNorm needs whole 256 x 256 tiles and no row bias (M=%d N=%d epi=%d)", p.M, p.N, p.epi);
+        DS_REQUIRE(p.M % 256 == 0 && (p.N % 256 == 0 || (p.N % 64 == 0 && p.epi == EPI_NONE && !p.ln_swapped && (p.debug & 4096) == 0)) &&
+                       !p.rowbias && (p.epi == EPI_NONE || p.epi == EPI_GEGLU),
+                   "gemm_pp: fused LayerNorm needs whole 256-row tiles, whole 256-column tiles (plain epilogue: whole 64-column strips) and no row bias (M=%d N=%d epi=%d)", p.M, p.N, p.epi);
         DS_REQUIRE(batch == 1 || (p.ln_swapped && p.ln_stats), "gemm_pp: only the operand-swapped fused consumer is batched");
         DS_REQUIRE((p.ln_stats != nullptr) == (p.ln_c != nullptr), "gemm_pp: ln_stats and ln_c come as a pair");
         DS_REQUIRE(!p.ln_stats || p.ln_swapped || p.bias, "gemm_pp: the fused-LayerNorm consumer takes b' = bias + W beta as its bias");

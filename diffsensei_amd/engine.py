@@ -531,7 +531,7 @@ class UNetEngine:
         # form: gemm_pp_kernel needs whole tiles of tokens, the 128-wide kernels take any count)
         k_qk, k_ffd, k_v = kind(M, 2 * Cc, Cc), kind(M, Cc, 4 * Cc), kind(Cc, Np, Cc, 0, B)
         fuse1 = (fuse and f"{p}.transformer_blocks.0.attn1.qk.weight_ln" in w and pays(k_qk) and pays(k_ffd) and pays(k_v)
-                 and (k_v == 2 or (Np == N and can(Cc, N, Cc, 0, B))))
+                 and (k_v == 2 or (Np == N and N % 256 == 0 and can(Cc, N, Cc, 0, B))))   # (operand-swapped: whole tile columns)
         # Statistics entries per row: one per 64 columns, or three per 160 columns where the producers of this level (N = Cc,
         # K = Cc | 4 Cc: proj_in, both out-projections, the FF down-projection) run gemm_t160_kernel - its 160-column tiles hold no
         # whole 64-column strips (csrc/gemm_t160.hip; the rule does not depend on K, so every producer of a level emits one format)

@@ -44,6 +44,9 @@ int ds_device_info(int* cu_count, int* lds_bytes, char* arch_name, int arch_name
  *                        0 one block per CU with a partial last round
  *   "gemm_ring"          0 (default) grids of <= 512 64x128 blocks (num_samples 1) use the ring-buffered
  *                        gemm_glds_kernel<64,false,3|4> | 1 never (A/B: profiles/r02_ring_in_pipeline_ab.txt)
+ *   "gemm_pp_narrow"     0 (default) the N, K <= 640 projections run gemm_pp_kernel where its ragged last tile column takes the
+ *                        branch-free epilogue (plain epilogue, N % 64 == 0, M % 256 == 0) | 1 never: the 128x128 kernels, the
+ *                        rule of rounds 1-5 (A/B: profiles/r06_pp_narrow_ab.txt)
  *   "conv_halo_variant"  0 auto (16x16-pixel blocks from 1024 blocks on; the ring-buffered 8x16 kernel for grids of at most
  *                        "conv_deep_blocks" blocks per CU) | 1 force conv_halo_kernel (8x16 pixels) | 2 force conv_halo256_kernel
  *                        (16x16 pixels) | 3 force conv_halo_deep_kernel (8x16 pixels, W ring of three buffers: small grids) |

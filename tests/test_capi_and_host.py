@@ -260,9 +260,16 @@ def test_plan_folds_every_layernorm_into_the_gemms_around_it(hip_lib, monkeypatc
     # SDXL at UNet batch 2 (BASELINE configs[1]): everything on the 128-wide kernels except the 64 x 64-token GEGLU projections
     assert [kind(2048, 1280, 1280, 0, 1), kind(2048, 2560, 1280, 0, 1), kind(2048, 1280, 5120, 0, 1), kind(2048, 10240, 1280, 1, 1),
             kind(1280, 1024, 1280, 0, 2), kind(8192, 640, 640, 0, 1), kind(8192, 5120, 640, 1, 1)] == [2, 2, 2, 2, 2, 2, 1]
-    # ... and at batch 64 (the metric line): the 1280-channel level on gemm_pp_kernel, the 640-channel out-projections 128-wide
+    # ... and at batch 64 (the metric line): the 1280-channel level on gemm_pp_kernel, and since round 6 the 640-channel
+    # out-projections too (whole 64-column strips of their ragged third tile column); gemm_pp_narrow 1: 128-wide, as until round 5
     assert [kind(65536, 1280, 1280, 0, 1), kind(65536, 10240, 1280, 1, 1), kind(1280, 1024, 1280, 0, 64), kind(262144, 640, 640, 0, 1),
-            kind(262144, 5120, 640, 1, 1)] == [1, 1, 1, 2, 1]
+            kind(262144, 5120, 640, 1, 1)] == [1, 1, 1, 1, 1]
+    assert kind(262144, 640, 2560, 0, 1) == 1 and kind(640, 4096, 640, 0, 64) == 0     # (the operand-swapped V^T: ragged tile ROWS)
+    try:
+        assert hip_lib.ds_set_option(b"gemm_pp_narrow", 1) == 0
+        assert kind(262144, 640, 640, 0, 1) == 2
+    finally:
+        hip_lib.ds_set_option(b"gemm_pp_narrow", 0)
     assert kind(2048, 1280, 1288, 0, 1) == 0 and kind(0, 1280, 1280, 0, 1) == 0 and kind(2048, 1280, 1280, 2, 1) == 0
 
 

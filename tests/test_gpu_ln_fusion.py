@@ -27,7 +27,8 @@ def _relmax(got, ref):
     return ((got - ref).abs().max() / ref.abs().max().clamp_min(1e-6)).item()
 
 
-@pytest.mark.parametrize("M,N,K,res", [(512, 1280, 1280, True), (1024, 256, 128, False), (2048, 1280, 5120, True)])
+@pytest.mark.parametrize("M,N,K,res", [(512, 1280, 1280, True), (1024, 256, 128, False), (2048, 1280, 5120, True),
+                                       (1024, 640, 640, True), (768, 320, 256, False), (32768, 640, 640, True)])
 def test_producer_row_statistics(hip_lib, M, N, K, res):
     """The +residual projection that writes the residual stream also emits, per row and 64-column strip, the (sum, sum of
     squares) of the f16 values it stores; `ln_finalize` turns them into (mean, rstd).  The stored output itself must be
@@ -37,11 +38,11 @@ def test_producer_row_statistics(hip_lib, M, N, K, res):
     x, w, b = _r((M, K), g), _r((N, K), g, 1 / math.sqrt(K)), _r((N,), g)
     r = (_r((M, N), g) * 3 + 1.5).half() if res else None
     dv = lambda t: None if t is None else t.to(DEV)
-    y, part = ops.gemm_ln(dv(x), dv(w), dv(b), residual=dv(r), emit_stats=True)
-    assert part.shape == (N // 64, M, 2)
     lib = __import__("diffsensei_amd._lib", fromlist=["x"]).load()
-    lib.ds_set_option(b"gemm_variant", 3)
+    lib.ds_set_option(b"gemm_variant", 3)   # (N % 256 != 0: whole 64-column strips of a ragged last tile column, round 6)
     try:
+        y, part = ops.gemm_ln(dv(x), dv(w), dv(b), residual=dv(r), emit_stats=True)
+        assert part.shape == (N // 64, M, 2)
         y0 = ops.gemm(dv(x), dv(w), dv(b), dv(r))
     finally:
         lib.ds_set_option(b"gemm_variant", 0)
@@ -61,7 +62,8 @@ def _pack(w, bias, gamma, beta):
     return pack_ln_fused(w.to(DEV), None if bias is None else bias.to(DEV), gamma.to(DEV), beta.to(DEV))
 
 
-@pytest.mark.parametrize("M,N,K,offset", [(512, 1280, 1280, 0.0), (256, 256, 128, 0.0), (1024, 2560, 1280, 0.3), (512, 1280, 1280, 8.0)])
+@pytest.mark.parametrize("M,N,K,offset", [(512, 1280, 1280, 0.0), (256, 256, 128, 0.0), (1024, 2560, 1280, 0.3), (512, 1280, 1280, 8.0),
+                                          (1024, 640, 640, 0.3), (24576, 640, 640, 0.0), (512, 192, 128, 0.0)])
 def test_consumer_plain_vs_layernorm_linear(hip_lib, M, N, K, offset):
     """y = rstd (x gw^T - mean c) + b' on the raw x  ==  Linear(LayerNorm(x)); `offset`: row mean in standard deviations
     (the rank-1 term is carried as an f16 (hi, lo) pair, so a large mean must not cost accuracy)."""
@@ -133,7 +135,8 @@ def test_fused_chain_producer_finalize_consumer_and_refusals(hip_lib):
         assert torch.equal(h2, h) and torch.equal(part2, part) and torch.equal(q2, q)
     # what the dispatch gives a shape: 1 = the 256 x 256 kernel, 2 = the 128-wide kernels (small batches, 640 channels), 0 = none
     assert ops.gemm_ln_fusable(65536, 1280, 1280) == 1 and ops.gemm_ln_fusable(65536, 10240, 1280, geglu=True) == 1
-    assert ops.gemm_ln_fusable(2048, 1280, 1280) == 2 and ops.gemm_ln_fusable(65536, 640, 640) == 2
+    assert ops.gemm_ln_fusable(2048, 1280, 1280) == 2 and ops.gemm_ln_fusable(8192, 640, 640) == 2
+    assert ops.gemm_ln_fusable(65536, 640, 640) == 1    # round 6: whole 64-column strips of the ragged third tile column
     assert ops.gemm_ln_fusable(2048, 1280, 1288) == 0                # K not a multiple of 64: the register-staged fallback
     with pytest.raises(_lib.DiffSenseiHipError):          # a producer needs whole 64-column strips per 128-column tile
         ops.gemm_ln(dv(a), dv(wo[:1160]), dv(bo[:1160]), residual=dv(h0[:, :1160].contiguous()), emit_stats=True)

@@ -201,6 +201,60 @@ def test_gemm_pingpong_tile_handover(hip_lib, M, N, K, mode):
     _close(drained, ref, what=f"pingpong hand-over {mode}")
 
 
+@pytest.mark.parametrize("M,N,K,mode", [(32768, 640, 640, "res"), (24576, 640, 640, "bias"), (16384, 320, 256, "none"),
+                                        (1024, 192, 128, "res"), (65536, 640, 2560, "res")])
+def test_gemm_pingpong_ragged_column_strips(hip_lib, M, N, K, mode):
+    """Round 6: the ragged last tile COLUMN of an N % 64 == 0 problem (the 640-channel level: 2.5 tile columns) runs the
+    branch-free epilogue wave by wave - a wave's 64 columns are wholly inside N or the wave stores nothing and only pads its
+    vector-memory count (gemm_pp.hip `strips_ok` / `wave_cols_in`).  Bit-identical to the same tiles on the generic epilogue
+    (gemm_debug 4096), to the drained hand-over (256) and to the 128 x 128 kernel; repeated, because a mis-counted wait shows up
+    as a rare wrong tile; the columns behind N in the (wider) output buffer must stay untouched; the automatic dispatch now
+    gives the N = K = 640 projection at a large M to this kernel (knob gemm_pp_narrow 1: the 128 x 128 kernels, same bits)."""
+    from diffsensei_amd import _lib
+    ops = _ops(hip_lib)
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M + N + K + 1)
+    x, w = _r((M, K), g).to(DEV), _r((N, K), g, 1 / math.sqrt(K)).to(DEV)
+    b = None if mode == "none" else _r((N,), g).to(DEV)
+    res = _r((M, N), g).to(DEV) if mode == "res" else None
+    try:
+        assert lib.ds_set_option(b"gemm_variant", 3) == 0
+        assert lib.ds_set_option(b"gemm_debug", 4096) == 0
+        generic = ops.gemm(x, w, b, residual=res).clone()
+        assert lib.ds_set_option(b"gemm_debug", 256) == 0
+        drained = ops.gemm(x, w, b, residual=res).clone()
+        assert lib.ds_set_option(b"gemm_debug", 0) == 0
+        for _ in range(10):
+            assert torch.equal(ops.gemm(x, w, b, residual=res), generic)
+        assert torch.equal(drained, generic)
+        # a wider output buffer: the waves outside N must not store (ldc = N + 128, canary behind the columns)
+        wide = torch.full((M, N + 128), 7.0, dtype=torch.float16, device=DEV)
+        rc = lib.ds_gemm_f16(ops._p(x), K, None, 0, K, ops._p(w), K, ops._p(b), ops._p(res), N, ops._p(wide), N + 128, M, N, K, 0,
+                             ops._stream())
+        _lib.check(rc, "ds_gemm_f16 (ldy = N + 128)")
+        assert torch.equal(wide[:, :N], generic) and bool((wide[:, N:] == 7.0).all())
+        assert lib.ds_set_option(b"gemm_variant", 8) == 0
+        assert torch.equal(ops.gemm(x, w, b, residual=res), generic)
+    finally:
+        lib.ds_set_option(b"gemm_debug", 0)
+        lib.ds_set_option(b"gemm_variant", 0)
+    ref = x.float() @ w.float().t()
+    if b is not None:
+        ref = ref + b.float()
+    ref = ref.half().float() + (res.float() if res is not None else 0)
+    _close(generic, ref, what="pingpong ragged column strips")
+    if (M, N, K) == (32768, 640, 640):
+        from diffsensei_amd.ops import gemm_ln_fusable
+        assert gemm_ln_fusable(65536, 640, 640) == 1 and gemm_ln_fusable(262144, 640, 640) == 1
+        assert torch.equal(ops.gemm(x, w, b, residual=res), generic)     # automatic dispatch
+        try:
+            assert lib.ds_set_option(b"gemm_pp_narrow", 1) == 0
+            assert gemm_ln_fusable(65536, 640, 640) == 2
+            assert torch.equal(ops.gemm(x, w, b, residual=res), generic)
+        finally:
+            lib.ds_set_option(b"gemm_pp_narrow", 0)
+
+
 @pytest.mark.parametrize("M,N,K", [(2048, 1280, 1280), (2048, 2560, 1280), (2048, 1280, 5120), (8192, 640, 640),
                                    (200, 136, 256), (64, 128, 320), (1000, 640, 2560), (4096, 1280, 1280)])
 def test_gemm_ring_buffered_small_grid_kernel(hip_lib, M, N, K):
