@@ -288,6 +288,15 @@ constexpr int VSTR = 200;  // bytes per V^T row in LDS (96 keys * 2 B + 8 pad): 
 // rows as well (16 bytes per lane, 4 instructions instead of 8).  Same arithmetic in the same order: bit-identical to RING = false.
 constexpr int IP_PANEL_BYTES = 2 * LP * 128 + 2 * 64 * VSTR;   // sKt | sKi | sVt | sVi
 constexpr int IP_SLOT = 4096;                                  // one wave's 32 x 64 f16 tile
+#ifndef IP_DIRECT_STORE
+#define IP_DIRECT_STORE 1
+#endif
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+template <int V>
+struct IPC {
+    static constexpr int value = V;
+};
 
 template <int NW, bool RING>
 __global__ __launch_bounds__(NW * 64, 2) void ip_attn_kernel(const IPAttnParams p, int qt) {
@@ -335,32 +344,56 @@ __global__ __launch_bounds__(NW * 64, 2) void ip_attn_kernel(const IPAttnParams 
     } else {
         load_q(0);
     }
-    // ---- stage the four panels once
+    // (the boxes are requested here, ahead of the panel loads, and broadcast behind the barrier below: one more round trip that
+    // used to sit on its own between the staging and the first tile)
+    float bv[4] = {2.f, 2.f, -1.f, -1.f};
     {
+        const float* bbox_b = p.bbox + (long)b * p.max_ips * 4;
+        if (lane < p.max_ips) {
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) bv[c4] = bbox_b[4 * lane + c4];
+        }
+    }
+    // ---- stage the four panels once.  All 4 x ITER global loads are REQUESTED first, then the LDS writes (round 6): as two
+    // rolled loops of {load, load, wait, write, write} the staging cost a block 6 memory round trips back to back - fitted from the
+    // grid-rule sweep of profiles/r06_ipattn_microbench.txt (time = rounds x (S + tiles T)): S = 7-9 us per block against
+    // T = 4 us per query tile, i.e. a fifth of the kernel at UNet batch 64 and most of it at batch 2 (one tile per block).
+    {
+        constexpr int ITER = (LP * 8 + NW * 64 - 1) / (NW * 64);   // LP * 8 == 64 * 12 == 768 sixteen-byte pieces per panel
         const half_t* ktp = p.kt + (long)b * p.sk + h * 64;
         const half_t* kip = p.ki + (long)b * p.sk + h * 64;
-        for (int id = tid; id < LP * 8; id += NW * 64) {
-            const int row = id >> 3, c = id & 7;
-            *reinterpret_cast<h8*>(&sKt[row * 128 + swz(row, c)]) =
-                *reinterpret_cast<const h8*>(ktp + (long)row * p.ldk + c * 8);
-            *reinterpret_cast<h8*>(&sKi[row * 128 + swz(row, c)]) =
-                *reinterpret_cast<const h8*>(kip + (long)row * p.ldk + c * 8);
-        }
         const half_t* vtp = p.vtt + (long)b * p.sv + (long)(h * 64) * LP;
         const half_t* vip = p.vti + (long)b * p.sv + (long)(h * 64) * LP;
-        for (int id = tid; id < 64 * 12; id += NW * 64) {
-            const int row = id / 12, c = id - row * 12;
-            const h8 a = *reinterpret_cast<const h8*>(vtp + (long)row * LP + c * 8);
-            const h8 bb = *reinterpret_cast<const h8*>(vip + (long)row * LP + c * 8);
-            h4 lo, hi;
-            lo[0] = a[0]; lo[1] = a[1]; lo[2] = a[2]; lo[3] = a[3];
-            hi[0] = a[4]; hi[1] = a[5]; hi[2] = a[6]; hi[3] = a[7];
-            *reinterpret_cast<h4*>(&sVt[row * VSTR + c * 16]) = lo;
-            *reinterpret_cast<h4*>(&sVt[row * VSTR + c * 16 + 8]) = hi;
-            lo[0] = bb[0]; lo[1] = bb[1]; lo[2] = bb[2]; lo[3] = bb[3];
-            hi[0] = bb[4]; hi[1] = bb[5]; hi[2] = bb[6]; hi[3] = bb[7];
-            *reinterpret_cast<h4*>(&sVi[row * VSTR + c * 16]) = lo;
-            *reinterpret_cast<h4*>(&sVi[row * VSTR + c * 16 + 8]) = hi;
+        h8 rk[ITER][2], rv[ITER][2];
+#pragma unroll
+        for (int j = 0; j < ITER; ++j) {
+            const int id = min(tid + j * NW * 64, LP * 8 - 1);
+            const int row = id >> 3, c = id & 7;
+            rk[j][0] = *reinterpret_cast<const h8*>(ktp + (long)row * p.ldk + c * 8);
+            rk[j][1] = *reinterpret_cast<const h8*>(kip + (long)row * p.ldk + c * 8);
+            const int vrow = id / 12, vc = id - vrow * 12;
+            rv[j][0] = *reinterpret_cast<const h8*>(vtp + (long)vrow * LP + vc * 8);
+            rv[j][1] = *reinterpret_cast<const h8*>(vip + (long)vrow * LP + vc * 8);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < ITER; ++j) {
+            const int id = tid + j * NW * 64;
+            if (id >= LP * 8) continue;
+            const int row = id >> 3, c = id & 7;
+            *reinterpret_cast<h8*>(&sKt[row * 128 + swz(row, c)]) = rk[j][0];
+            *reinterpret_cast<h8*>(&sKi[row * 128 + swz(row, c)]) = rk[j][1];
+            const int vrow = id / 12, vc = id - vrow * 12;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const h8 a = rv[j][t];
+                char* const sV = t ? sVi : sVt;
+                h4 lo, hi;
+                lo[0] = a[0]; lo[1] = a[1]; lo[2] = a[2]; lo[3] = a[3];
+                hi[0] = a[4]; hi[1] = a[5]; hi[2] = a[6]; hi[3] = a[7];
+                *reinterpret_cast<h4*>(&sV[vrow * VSTR + vc * 16]) = lo;
+                *reinterpret_cast<h4*>(&sV[vrow * VSTR + vc * 16 + 8]) = hi;
+            }
         }
     }
     __syncthreads();
@@ -372,12 +405,6 @@ __global__ __launch_bounds__(NW * 64, 2) void ip_attn_kernel(const IPAttnParams 
     // which no grid point (x in [0, 1]) satisfies.
     float box[8][4];
     {
-        const float* bbox_b = p.bbox + (long)b * p.max_ips * 4;
-        float bv[4] = {2.f, 2.f, -1.f, -1.f};
-        if (lane < p.max_ips) {
-#pragma unroll
-            for (int c4 = 0; c4 < 4; ++c4) bv[c4] = bbox_b[4 * lane + c4];
-        }
 #pragma unroll
         for (int k = 0; k < 8; ++k)
 #pragma unroll
@@ -454,30 +481,74 @@ __global__ __launch_bounds__(NW * 64, 2) void ip_attn_kernel(const IPAttnParams 
 #pragma unroll
         for (int kb = 0; kb < 3; ++kb)
             act_ip[kb] = p.n_dummy == 0 || __builtin_amdgcn_ballot_w64(open_ip[kb] != 0u) != 0;
-#pragma unroll
-        for (int part = 0; part < 2; ++part) {  // 0: text keys, 1: IP keys
+        // Round 6: every LDS fragment of a phase is REQUESTED before the phase's first MFMA.  Left to the compiler the tile loop was
+        // a chain of {ds_read, s_waitcnt lgkmcnt(0), v_mfma} triples - the registers of one fragment reused for the next - i.e. ~60
+        // exposed LDS round trips per query tile with two waves per SIMD to hide them (ISA of the round-5 kernel; PMC: 47 % of the
+        // wave cycles in s_waitcnt, profiles/r05_pmc_conv_ip_attn_summary.txt).  Now per part: the K fragments of the active key
+        // blocks (up to 12 ds_read_b128) -> one wait -> the S^T MFMAs; the V^T fragments (up to 24 ds_read_b64 pairs) are requested
+        // right behind them and land under the softmax's VALU work; the IP part's K fragments are requested before the text part's
+        // P V MFMAs.  The scheduling barriers keep the compiler from sinking the reads back to their uses.  Same products in the
+        // same order per accumulator: bit-identical to the round-5 kernel.
+        // The loads are unconditional (a fragment of a skipped key block is read and never used: cheaper than a value that is
+        // defined under one branch and used under another - the compiler cannot correlate the two and keeps ~100 registers alive).
+        auto run_part = [&](auto partc) {
+        h8 kf[3][4], vf[3][2][2];
+        f32x16 st[3];
+        auto load_k = [&](auto partc, auto kb0c, auto kb1c) {
+            constexpr int part = decltype(partc)::value;
             const char* sK = part ? sKi : sKt;
-            const char* sV = part ? sVi : sVt;
-            const int L = part ? p.Li : p.Lt;
-            f32x16 st[3];
+#pragma unroll
+            for (int kb = decltype(kb0c)::value; kb < decltype(kb1c)::value; ++kb) {
+                const int row = kb * 32 + l31;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) kf[kb][kk] = *reinterpret_cast<const h8*>(sK + row * 128 + swz(row, kk * 2 + lhi));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto qk = [&](auto partc) {
+            constexpr int part = decltype(partc)::value;
 #pragma unroll
             for (int kb = 0; kb < 3; ++kb) {
+                if (kb == 0) load_k(partc, IPC<2>{}, IPC<3>{});   // the last block's fragments land under the first two blocks' MFMAs
                 if (part && !act_ip[kb]) continue;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
-                const int row = kb * 32 + l31;
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    const h8 kf = *reinterpret_cast<const h8*>(sK + row * 128 + swz(row, kk * 2 + lhi));
-                    st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[kk], st[kb], 0, 0, 0);
-                }
+                for (int kk = 0; kk < 4; ++kk) st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb][kk], qf[kk], st[kb], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            // scale + additive region mask (-10000, like the reference) + padding keys removed, then softmax.  The whole
-            // core is VALU bound (192 scores per query row against 48 MFMAs), so the per-score work is kept to packed
-            // fp32 ops: s = fma(raw, scale, bias) with a per-REGISTER bias.  Register r of key block kb is key
-            // 32 kb + (r&3) + 8 (r>>2) + 4 lhi, i.e. 16-key group 2 kb + (r>>3) on every lane; when the dummy / per-
-            // character token counts are multiples of 16 (the model's: 16 / 16) a group is open or closed as a whole
-            // and six per-lane biases replace 96 bit tests.  Unmasked scores are bit-identical to raw*scale.
+        };
+        auto load_v = [&](auto partc, auto kb0c, auto kb1c) {
+            constexpr int part = decltype(partc)::value;
+            const char* sV = part ? sVi : sVt;
+#pragma unroll
+            for (int kb = decltype(kb0c)::value; kb < decltype(kb1c)::value; ++kb) {
+#pragma unroll
+                for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                    for (int db = 0; db < 2; ++db) {
+                        const int row = db * 32 + l31;
+                        const int koff = (kb * 32 + hb * 16) * 2 + 8 * lhi;  // byte offset of this lane's first 4 keys
+                        const h4 v0 = *reinterpret_cast<const h4*>(sV + row * VSTR + koff);
+                        const h4 v1 = *reinterpret_cast<const h4*>(sV + row * VSTR + koff + 16);
+                        h8 v;
+                        v[0] = v0[0]; v[1] = v0[1]; v[2] = v0[2]; v[3] = v0[3];
+                        v[4] = v1[0]; v[5] = v1[1]; v[6] = v1[2]; v[7] = v1[3];
+                        vf[kb][hb][db] = v;
+                    }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        // scale + additive region mask (-10000, like the reference) + padding keys removed, then softmax.  The whole
+        // core is VALU bound (192 scores per query row against 48 MFMAs), so the per-score work is kept to packed
+        // fp32 ops: s = fma(raw, scale, bias) with a per-REGISTER bias.  Register r of key block kb is key
+        // 32 kb + (r&3) + 8 (r>>2) + 4 lhi, i.e. 16-key group 2 kb + (r>>3) on every lane; when the dummy / per-
+        // character token counts are multiples of 16 (the model's: 16 / 16) a group is open or closed as a whole
+        // and six per-lane biases replace 96 bit tests.  Unmasked scores are bit-identical to raw*scale.
+        // A masked key's probability is exactly 0 (see act_ip above).  The probabilities are left in st[], normalised and weighted.
+        auto softmax = [&](auto partc) {
+            constexpr int part = decltype(partc)::value;
+            const int L = part ? p.Li : p.Lt;
             const bool grouped = (p.n_dummy % 16 == 0) && (p.tok_per_ip % 16 == 0) && L > 64;
             float mloc = NEG_BIG;
             if (grouped) {
@@ -554,27 +625,31 @@ __global__ __launch_bounds__(NW * 64, 2) void ip_attn_kernel(const IPAttnParams 
                     }
                 }
             }
-            // O^T += V^T P^T
+        };
+        // O^T += V^T P^T
+        auto pv = [&](auto partc) {
+            constexpr int part = decltype(partc)::value;
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int kb = 0; kb < 3; ++kb) {
+                if (kb == 0) load_v(partc, IPC<(RING ? 0 : 1)>{}, IPC<3>{});   // land under the first block's four MFMAs
                 if (part && !act_ip[kb]) continue;
 #pragma unroll
                 for (int hb = 0; hb < 2; ++hb) {
                     const h8 pf = pack8(st[kb], hb * 8);
 #pragma unroll
-                    for (int db = 0; db < 2; ++db) {
-                        const int row = db * 32 + l31;
-                        const int koff = (kb * 32 + hb * 16) * 2 + 8 * lhi;  // byte offset of this lane's first 4 keys
-                        const h4 v0 = *reinterpret_cast<const h4*>(sV + row * VSTR + koff);
-                        const h4 v1 = *reinterpret_cast<const h4*>(sV + row * VSTR + koff + 16);
-                        h8 vf;
-                        vf[0] = v0[0]; vf[1] = v0[1]; vf[2] = v0[2]; vf[3] = v0[3];
-                        vf[4] = v1[0]; vf[5] = v1[1]; vf[6] = v1[2]; vf[7] = v1[3];
-                        ot[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, ot[db], 0, 0, 0);
-                    }
+                    for (int db = 0; db < 2; ++db) ot[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[kb][hb][db], pf, ot[db], 0, 0, 0);
                 }
             }
-        }
+        };
+        load_k(partc, IPC<0>{}, IPC<2>{});
+        qk(partc);
+        load_v(partc, IPC<0>{}, IPC<(RING ? 0 : 1)>{});   // (more of them ahead of the softmax spills: 244 registers as it is; the ring variant has none to spare)
+        softmax(partc);
+        pv(partc);
+        };
+        run_part(IPC<0>{});
+        run_part(IPC<1>{});
         if constexpr (RING) {
             // O^T -> the tile's own (consumed) Q slot, rows of 128 bytes with the same chunk swizzle, -> whole rows out
             char* ep = ring + (it % 3) * IP_SLOT;
@@ -596,17 +671,46 @@ __global__ __launch_bounds__(NW * 64, 2) void ip_attn_kernel(const IPAttnParams 
                 // store instructions per tile and wave, and a store whose lanes are all masked off is branched around
                 *reinterpret_cast<h8*>(p.o + ((long)b * p.N + q0 + row) * p.ldo + h * 64 + ch * 8) = v;
             }
-        } else if (q0 + l31 < p.N) {
-            half_t* op = p.o + ((long)b * p.N + q0 + l31) * p.ldo + h * 64;
+        } else if constexpr (IP_DIRECT_STORE == 0) {   // build-time A/B: eight 8-byte stores per row (rounds 1-5)
+            if (q0 + l31 < p.N) {
+                half_t* op = p.o + ((long)b * p.N + q0 + l31) * p.ldo + h * 64;
 #pragma unroll
-            for (int db = 0; db < 2; ++db)
+                for (int db = 0; db < 2; ++db)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        h4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = (half_t)ot[db][4 * g + e];
+                        *reinterpret_cast<h4*>(op + db * 32 + 8 * g + 4 * lhi) = o;
+                    }
+            }
+        } else {
+            // A lane holds columns 8g + 4 lhi + {0..3} of its query row; its partner lane ^ 32 the other four of every group of
+            // eight.  One v_permlane32_swap per dword and group pair leaves the lower lane with columns 16j .. 16j+7 and the upper one
+            // with 16j+8 .. 16j+15: 16-byte stores, four per wave and 32-dim block instead of eight 8-byte ones (the hand-over of
+            // gemm_pp_kernel's GEGLU epilogue, cdna_hip_programming.md T21).  The swaps run on every lane (rows past N included);
+            // only the stores are masked.
+            half_t* op = p.o + ((long)b * p.N + min(q0 + l31, p.N - 1)) * p.ldo + h * 64 + lhi * 8;
+            const bool row_ok = q0 + l31 < p.N;
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                unsigned og[4][2];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     h4 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = (half_t)ot[db][4 * g + e];
-                    *reinterpret_cast<h4*>(op + db * 32 + 8 * g + 4 * lhi) = o;
+                    const u32x2_t t = __builtin_bit_cast(u32x2_t, o);
+                    og[g][0] = t[0], og[g][1] = t[1];
                 }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(og[2 * j][0]), "+v"(og[2 * j + 1][0]));
+                    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(og[2 * j][1]), "+v"(og[2 * j + 1][1]));
+                    const u32x4_t v = {og[2 * j][0], og[2 * j][1], og[2 * j + 1][0], og[2 * j + 1][1]};
+                    if (row_ok) *reinterpret_cast<u32x4_t*>(op + db * 32 + j * 16) = v;
+                }
+            }
         }
     }
 }
@@ -717,6 +821,7 @@ int ds_launch_ip_attn(const IPAttnParams& p0, hipStream_t stream) {
     DS_REQUIRE(p.max_ips >= 1 && p.max_ips <= 8 && p.tok_per_ip > 0, "ip_attn: bad ip token layout");
     DS_REQUIRE(p.n_dummy + p.max_ips * p.tok_per_ip == p.Li, "ip_attn: Li (%d) != n_dummy + max_ips*tok_per_ip", p.Li);
     DS_REQUIRE(p.mask_h * p.mask_w == p.N, "ip_attn: mask grid %dx%d != N %d", p.mask_h, p.mask_w, p.N);
+    DS_REQUIRE(p.ldq % 8 == 0 && p.ldo % 8 == 0, "ip_attn: ldq (%ld) and ldo (%ld) must be multiples of 8 (16-byte row pieces)", (long)p.ldq, (long)p.ldo);
     // walk several query tiles per block once there are plenty of blocks (amortises the K/V panel staging)
     // The 8-wave LDS-DMA ring variant, 256 query rows per block and tile: g_ip_variant 2 only (see below).
     {
