@@ -882,10 +882,12 @@ int ds_gemm_ln_kind(int M, int N, int K, int batch, int epi) {
     // gemm_pp_kernel's fused epilogues: whole 256-row tiles; whole 256-column tiles, or - plain epilogue, unbatched (the batched
     // problem is the operand-swapped consumer, whose statistics run along the tile columns) - whole 64-column strips
     const bool cols_ok = N % 256 == 0 || (N % 64 == 0 && epi == EPI_NONE && batch == 1 && (g_gemm_debug & 4096) == 0);
-    if (g_gemm_variant == 3) return (M % 256 == 0 && cols_ok && ds_gemm_pp_applicable(p)) ? 1 : 0;
+    // (rows: whole tiles; the operand-swapped consumer - the batched problem - skips 32-row pieces past M)
+    const bool rows_ok = M % 256 == 0 || (batch > 1 && M % 32 == 0);
+    if (g_gemm_variant == 3) return (rows_ok && cols_ok && ds_gemm_pp_applicable(p)) ? 1 : 0;
     if (g_gemm_variant != 0) return 0;
     const Kind k = choose(p, batch).kind;
-    if (k == K_PP) return (M % 256 == 0 && cols_ok) ? 1 : 0;
+    if (k == K_PP) return (rows_ok && cols_ok) ? 1 : 0;
     if ((k == K_GLDS1 || k == K_GLDS2 || k == K_RING || k == K_T160) && K % 64 == 0) return 2;   // (a PRODUCER also needs N % 128 == 0 and no batch)
     return 0;
 }

@@ -301,7 +301,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
             //              statistics of the row form.
             const long col = (long)tbz * p.ln_bstride + tn0 + wc * 64 + (ln & 31) * 2;
             __builtin_amdgcn_global_load_lds((glb_void*)(p.ln_stats + 2 * col), (lds_void*)(ep + 1024), 16, 0, 0);
-            const int row = tm0 + (ln >> 5) * 128 + wr * 64 + (ln & 31) * 2;
+            int row = tm0 + (ln >> 5) * 128 + wr * 64 + (ln & 31) * 2;
+            if (row >= p.M) row = 0;   // ragged last tile ROW (M % 32 == 0, the 640-channel level): rows never stored
             __builtin_amdgcn_global_load_lds((glb_void*)(p.ln_c + 4 * (long)row), (lds_void*)(ep + 2048), 16, 0, 0);
         } else {
             const int L = ln & 15;
@@ -540,6 +541,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
         // across the main loop)
         bool fast = true;
         bool wave_cols_in = true;   // false: this wave's 64 columns lie past N (ragged last tile column): nothing to store
+        bool rows_short = false;    // true: some 32-row piece of this wave lies past M (operand-swapped consumer only): fewer stores
         // DBG 128 (ablation build only): NO epilogue - the accumulators are only marked as used, nothing is converted, staged or
         // stored.  time(DBG 0) - time(DBG 128) is everything a perfect overlap of the tile boundary with MFMAs could recover
         // (tools/pp_boundary_ablation.py, profiles/r06_pp_boundary_ablation.txt).
@@ -747,6 +749,15 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi) {
                     const int mb = cm0 + (mi >> 1) * 128 + wr * 64 + (mi & 1) * 32;
+                    if constexpr (FUSE == 4) {
+                        // Operand-swapped consumer (V^T = Wv LN(X_b)^T): the tile ROWS are the output channels, 640 = 2.5 tiles at
+                        // the 640-channel level (round 6).  A 32-row piece is wholly inside M or wholly outside (M % 32 == 0,
+                        // wave-uniform); an outside piece stores nothing, the hand-over pads the wave's vector-memory count.
+                        if (mb >= p.M) {
+                            rows_short = true;
+                            continue;
+                        }
+                    }
 #pragma unroll
                     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
@@ -967,7 +978,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
         gA[0] = nA[0], gA[1] = nA[1], gB[0] = nB[0], gB[1] = nB[1];
         if (p.bias && is_fast(m0, n0)) stage_bias(n0);
         if constexpr ((FUSE & 5) != 0) stage_ln(m0, n0, bz);
-        if (!fast || !wave_cols_in) pad_tail(IC<EX_TAIL>{});   // generic epilogue: its store count depends on the tile's edges; a wave outside a ragged column: no store
+        if (!fast || !wave_cols_in || rows_short) pad_tail(IC<EX_TAIL>{});   // generic epilogue: its store count depends on the tile's edges; a wave outside a ragged column: no store
         else if (FUSE == 0 && geglu) pad_tail(IC<(EX_TAIL > 8 ? EX_TAIL - 8 : 0)>{});   // unfused GEGLU tile: 8 stores
         derive_stage();
         derive_frag();
@@ -1006,9 +1017,10 @@ int ds_launch_gemm_pp(const GemmParams& p0, int batch, hipStream_t stream) {
     GemmParams p = p0;
     DS_REQUIRE(ds_gemm_pp_applicable(p), "gemm_pp: shape M=%d N=%d K=%d not supported", p.M, p.N, p.K);
     if (p.ln_stats || p.ln_c || p.stats_out) {  // fused LayerNorm: only the branch-free epilogues implement it
-        DS_REQUIRE(p.M % 256 == 0 && (p.N % 256 == 0 || (p.N % 64 == 0 && p.epi == EPI_NONE && !p.ln_swapped && (p.debug & 4096) == 0)) &&
+        DS_REQUIRE((p.ln_swapped ? p.M % 32 == 0 : p.M % 256 == 0) &&
+                       (p.N % 256 == 0 || (p.N % 64 == 0 && p.epi == EPI_NONE && !p.ln_swapped && (p.debug & 4096) == 0)) &&
                        !p.rowbias && (p.epi == EPI_NONE || p.epi == EPI_GEGLU),
-                   "gemm_pp: fused LayerNorm needs whole 256-row tiles, whole 256-column tiles (plain epilogue: whole 64-column strips) and no row bias (M=%d N=%d epi=%d)", p.M, p.N, p.epi);
+                   "gemm_pp: fused LayerNorm needs whole 256-row tiles (operand-swapped: whole 32-row pieces), whole 256-column tiles (plain epilogue: whole 64-column strips) and no row bias (M=%d N=%d epi=%d)", p.M, p.N, p.epi);
         DS_REQUIRE(batch == 1 || (p.ln_swapped && p.ln_stats), "gemm_pp: only the operand-swapped fused consumer is batched");
         DS_REQUIRE((p.ln_stats != nullptr) == (p.ln_c != nullptr), "gemm_pp: ln_stats and ln_c come as a pair");
         DS_REQUIRE(!p.ln_stats || p.ln_swapped || p.bias, "gemm_pp: the fused-LayerNorm consumer takes b' = bias + W beta as its bias");

@@ -264,7 +264,8 @@ def test_plan_folds_every_layernorm_into_the_gemms_around_it(hip_lib, monkeypatc
     # out-projections too (whole 64-column strips of their ragged third tile column); gemm_pp_narrow 1: 128-wide, as until round 5
     assert [kind(65536, 1280, 1280, 0, 1), kind(65536, 10240, 1280, 1, 1), kind(1280, 1024, 1280, 0, 64), kind(262144, 640, 640, 0, 1),
             kind(262144, 5120, 640, 1, 1)] == [1, 1, 1, 1, 1]
-    assert kind(262144, 640, 2560, 0, 1) == 1 and kind(640, 4096, 640, 0, 64) == 0     # (the operand-swapped V^T: ragged tile ROWS)
+    assert kind(262144, 640, 2560, 0, 1) == 1 and kind(640, 4096, 640, 0, 64) == 1     # (the operand-swapped V^T: 2.5 tile ROWS, whole 32-row pieces)
+    assert kind(648, 4096, 640, 0, 64) != 1          # (no whole 32-row pieces: the 128-wide kernels)
     try:
         assert hip_lib.ds_set_option(b"gemm_pp_narrow", 1) == 0
         assert kind(262144, 640, 640, 0, 1) == 2

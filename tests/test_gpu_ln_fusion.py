@@ -146,13 +146,16 @@ def test_fused_chain_producer_finalize_consumer_and_refusals(hip_lib):
         ops.gemm_ln(dv(a), gw, None, c2, st)
 
 
-def test_consumer_swapped_vs_layernorm_linear(hip_lib):
+@pytest.mark.parametrize("Z,N,C", [(3, 512, 256), (3, 512, 640), (2, 1024, 384), (5, 256, 1280)])
+def test_consumer_swapped_vs_layernorm_linear(hip_lib, Z, N, C):
     """norm1 -> attn1.to_v, produced transposed per image: out[z] = Wv LN(x[z])^T (operand-swapped form: the statistics run
-    along the output columns, c and b' along its rows, batch items folded into the persistent tile walk)."""
+    along the output columns, c and b' along its rows, batch items folded into the persistent tile walk).  C = 640 / 384: the
+    output channels are the tile ROWS, 2.5 / 1.5 tiles - 32-row pieces past C are skipped (round 6); the rows behind the last
+    image's C rows must stay untouched, and repeated launches give the same bits (the skipped pieces' stores are padded in the
+    counted waits of the tile hand-over)."""
     from diffsensei_amd import ops
     from diffsensei_amd.engine import pack_ln_fused
-    g = torch.Generator().manual_seed(21)
-    Z, N, C = 3, 512, 256
+    g = torch.Generator().manual_seed(21 + C)
     x = ((torch.randn((Z, N, C), generator=g) + 0.4) * (1.0 + torch.rand((Z, N, 1), generator=g) * 3)).half()
     wv, gamma, beta = _r((C, C), g, 1 / math.sqrt(C)), (1 + 0.2 * torch.randn(C, generator=g)).half(), _r((C,), g, 0.3)
     ref = torch.einsum("ck,znk->zcn", wv.float(), F.layer_norm(x.float(), (C,), gamma.float(), beta.float(), 1e-5))
@@ -163,7 +166,11 @@ def test_consumer_swapped_vs_layernorm_linear(hip_lib):
     xs = x.float().view(Z * N, C // 64, 64)
     part = torch.stack([xs.sum(-1).t(), (xs * xs).sum(-1).t()], dim=-1).contiguous().to(DEV)
     st = ops.ln_finalize(part, C, 1e-5)
-    got = ops.gemm_ln_swapped(gw, x.to(DEV), st, cb)
+    buf = torch.full((Z * C * N + 4096,), 3.0, dtype=torch.float16, device=DEV)     # canary behind the last image's rows
+    got = ops.gemm_ln_swapped(gw, x.to(DEV), st, cb, out=buf[:Z * C * N].view(Z, C, N))
+    assert bool((buf[Z * C * N:] == 3.0).all())
+    for _ in range(5):
+        assert torch.equal(ops.gemm_ln_swapped(gw, x.to(DEV), st, cb), got)
     tn = ops.layernorm(x.view(Z * N, C).to(DEV), gamma.to(DEV), beta.to(DEV), 1e-5).view(Z, N, C)
     unfused = ops.gemm_batched_nt(wv.to(DEV), tn)
     e_f, e_u = _relmax(got, ref), _relmax(unfused, ref)
