@@ -114,6 +114,51 @@ __global__ __launch_bounds__(NWAVES * 64, 1) void gemm_t160_kernel(const GemmPar
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
 
+    // ---- the epilogue's operands are REQUESTED HERE, ahead of the first DMA piece (round 6): bias, the residual rows of the
+    // thread's stage-2 pieces, and - consumer form - the first 24 partial-sum entries of the lane's rows and its c values.  With
+    // one block per CU nothing else hides them: requested in the epilogue they were two memory round trips back to back (bias /
+    // partial sums, then - behind a barrier - the residual) of a launch that lasts 21 us.  They are OLDER than every DMA piece, and
+    // vmcnt retires in issue order, so the counted waits of the k-loop ("all but the newest pieces") are unchanged; C == residual
+    // (the in-place h += ...) is safe: the block reads exactly the tile it writes later.
+    const int nw = n0 + wave * 32;                       // stage 1: the wave's 32-column strip (compute waves)
+    const int c20 = tid % 20, r16 = tid / 20;            // stage 2: thread t takes 16-byte chunk t % 20 of rows t / 20 + 16 j
+    const int n2 = n0 + c20 * 8;
+    const bool ln_in = p.ln_stats != nullptr;
+    const int strips = p.ln_nstrips > 0 ? p.ln_nstrips : (p.K >> 6);
+    constexpr int JJ = 6;   // 24 entries (a gemm_t160_kernel producer at N = 1280) in one round of loads
+    h4 bq[4];
+    h8 rv[4], cq[4];
+    f32x2 t0[2][2][JJ];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bq[g] = h4{0, 0, 0, 0};
+    if (compute) {
+        if (p.bias) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const h4*>(p.bias + nw + 8 * g + 4 * lhi);
+        }
+        if (p.residual) {   // (tid < 320 == the compute waves)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int m = min(m0 + r16 + 16 * j, p.M - 1);
+                rv[j] = *reinterpret_cast<const h8*>(p.residual + (long)m * p.ldr + n2);
+            }
+        }
+        if (ln_in) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const int m = min(m0 + mi * 32 + l31, p.M - 1);
+                const f32x2* part = reinterpret_cast<const f32x2*>(p.ln_stats) + m;
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+                    for (int jj = 0; jj < JJ; ++jj) t0[mi][cc][jj] = part[(long)min(2 * lhi + cc + 4 * jj, strips - 1) * p.M];
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) cq[g] = *reinterpret_cast<const h8*>(p.ln_c + 2 * (nw + 8 * g + 4 * lhi));
+        }
+    }
+    asm volatile("" ::: "memory");   // (the requests stay in front of the DMA prologue)
+
     const int nk = p.K / 64;
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s)
@@ -164,24 +209,13 @@ __global__ __launch_bounds__(NWAVES * 64, 1) void gemm_t160_kernel(const GemmPar
     // D layout (operands swapped): register r of a block is tile column (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of the wave's strip.
     char* const sC = smem;
     if (compute) {
-    const int nw = n0 + wave * 32;
-    h4 bq[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) bq[g] = h4{0, 0, 0, 0};
-    if (p.bias) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const h4*>(p.bias + nw + 8 * g + 4 * lhi);
-    }
-    const bool ln_in = p.ln_stats != nullptr;
     float ln_mean[2] = {0.f, 0.f}, ln_rstd[2] = {1.f, 1.f};
-    h8 cq[4];
     if (ln_in) {
-        // consumer: (mean, rstd) of the lane's two rows from the producer's partial sums, every load in flight at once; the
-        // summation order is the one of gemm.hip's consumer / ln_finalize_kernel (four interleaved chains, (0 + 1) + (2 + 3)):
-        // the two half-waves hold the same rows and take two chains each
-        const int strips = p.ln_nstrips > 0 ? p.ln_nstrips : (p.K >> 6);
+        // consumer: (mean, rstd) of the lane's two rows from the producer's partial sums, every load in flight at once (the first
+        // 24 entries - all of them at K = 1280 - since the top of the kernel); the summation order is the one of gemm.hip's
+        // consumer / ln_finalize_kernel (four interleaved chains, (0 + 1) + (2 + 3)): the two half-waves hold the same rows and
+        // take two chains each
         float sa[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, qa[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-        constexpr int JJ = 6;   // 24 entries (a gemm_t160_kernel producer at N = 1280) in one round of loads
         for (int base = 0; base < strips; base += 4 * JJ) {
             f32x2 t[2][2][JJ];
 #pragma unroll
@@ -193,7 +227,8 @@ __global__ __launch_bounds__(NWAVES * 64, 1) void gemm_t160_kernel(const GemmPar
 #pragma unroll
                     for (int jj = 0; jj < JJ; ++jj) {
                         const int j = base + 2 * lhi + cc + 4 * jj;
-                        t[mi][cc][jj] = part[(long)min(j, strips - 1) * p.M];
+                        if (base == 0) t[mi][cc][jj] = t0[mi][cc][jj];
+                        else t[mi][cc][jj] = part[(long)min(j, strips - 1) * p.M];
                     }
             }
 #pragma unroll
@@ -215,8 +250,6 @@ __global__ __launch_bounds__(NWAVES * 64, 1) void gemm_t160_kernel(const GemmPar
             ln_mean[mi] = s * inv_c;
             ln_rstd[mi] = rsqrtf(fmaxf(fmaf(-ln_mean[mi], ln_mean[mi], q * inv_c), 0.f) + p.ln_eps);
         }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) cq[g] = *reinterpret_cast<const h8*>(p.ln_c + 2 * (nw + 8 * g + 4 * lhi));
     }
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
@@ -243,17 +276,8 @@ __global__ __launch_bounds__(NWAVES * 64, 1) void gemm_t160_kernel(const GemmPar
     }   // compute waves
     __syncthreads();
     // ---- stage 2: thread t takes 16-byte chunk t % 20 of rows t / 20 + 16 j: 320-byte row segments per 20 lanes
-    const int c = tid % 20, r16 = tid / 20;
-    const int n = n0 + c * 8;
+    const int c = c20, n = n2;
     if (tid < NCOMP * 64) {
-    h8 rv[4];
-    if (p.residual) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int m = min(m0 + r16 + 16 * j, p.M - 1);
-            rv[j] = *reinterpret_cast<const h8*>(p.residual + (long)m * p.ldr + n);
-        }
-    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int row = r16 + 16 * j, m = m0 + row;
