@@ -26,6 +26,8 @@ static thread_local int g_ip_variant = 0;  // ip_attn: 0 auto, 1 force the 4-wav
 void ds_ip_attn_set_variant(int v) { g_ip_variant = v; }
 
 namespace {
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float NEG_BIG = -1.0e30f;
@@ -218,17 +220,30 @@ __global__ __launch_bounds__(256, 2) void self_attn_kernel(const SelfAttnParams 
         const float l = l_part[qb] + __shfl_xor(l_part[qb], 32, 64);
         const float inv = 1.0f / l;
         const int qrow = q0 + qb * 32 + l31;
-        if (qrow < p.Nq) {
-            half_t* op = p.o + (long)b * p.so + (long)qrow * p.ldo + h * 64;
+        // 16-byte stores (round 6; the store shape was measured on ip_attn_kernel below): a lane holds columns 8g + 4 lhi + {0..3}
+        // of its query row, lane ^ 32 the other four of every group of eight; one v_permlane32_swap per dword and group pair
+        // leaves the lower lane with columns 16j .. 16j+7, the upper one with 16j+8 .. 16j+15.  The swaps run on every lane
+        // (clamped row address past Nq); only the stores are masked.
+        half_t* op = p.o + (long)b * p.so + (long)min(qrow, p.Nq - 1) * p.ldo + h * 64 + lhi * 8;
+        const bool row_ok = qrow < p.Nq;
 #pragma unroll
-            for (int db = 0; db < 2; ++db)
+        for (int db = 0; db < 2; ++db) {
+            unsigned og[4][2];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    h4 o;
+            for (int g = 0; g < 4; ++g) {
+                h4 o;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = (half_t)(ot[qb][db][4 * g + e] * inv);
-                    *reinterpret_cast<h4*>(op + db * 32 + 8 * g + 4 * lhi) = o;
-                }
+                for (int e = 0; e < 4; ++e) o[e] = (half_t)(ot[qb][db][4 * g + e] * inv);
+                const u32x2_t t2 = __builtin_bit_cast(u32x2_t, o);
+                og[g][0] = t2[0], og[g][1] = t2[1];
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(og[2 * j][0]), "+v"(og[2 * j + 1][0]));
+                asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(og[2 * j][1]), "+v"(og[2 * j + 1][1]));
+                const u32x4_t v = {og[2 * j][0], og[2 * j][1], og[2 * j + 1][0], og[2 * j + 1][1]};
+                if (row_ok) *reinterpret_cast<u32x4_t*>(op + db * 32 + j * 16) = v;
+            }
         }
     }
 }
@@ -291,8 +306,6 @@ constexpr int IP_SLOT = 4096;                                  // one wave's 32 
 #ifndef IP_DIRECT_STORE
 #define IP_DIRECT_STORE 1
 #endif
-typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 template <int V>
 struct IPC {
     static constexpr int value = V;

@@ -38,6 +38,8 @@ constexpr float NEG_BIG = -1.0e30f;
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2_sp __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_sp __attribute__((ext_vector_type(4)));
 
 // Debug counter (ds_debug_counter("attn_sp_recentre")): how often the rare re-centring branch behind a step ran, per wave and
 // pair, since the last reset.  One atomic from one lane inside the rare branch - nothing in the steady state.  It exists so that
@@ -359,17 +361,30 @@ __global__ __launch_bounds__(256, 2) void self_attn_sp_kernel(const SelfAttnPara
         const float l = lsum[qb] + __shfl_xor(lsum[qb], 32, 64);
         const float inv = 1.0f / l;
         const int qrow = q0 + qb * 32 + l31;
-        if (qrow < p.Nq) {
-            half_t* op = p.o + (long)b * p.so + (long)qrow * p.ldo + h * 64;
+        // 16-byte stores (round 6, as in ip_attn_kernel where the store shape was measured: attention.hip): a lane holds columns
+        // 8g + 4 lhi + {0..3} of its query row, its partner lane ^ 32 the other four of every group of eight; one
+        // v_permlane32_swap per dword and group pair leaves the lower lane with columns 16j .. 16j+7, the upper one with 16j+8 ..
+        // 16j+15.  The swaps run on every lane (rows past Nq included); only the stores are masked.
+        half_t* op = p.o + (long)b * p.so + (long)min(qrow, p.Nq - 1) * p.ldo + h * 64 + lhi * 8;
+        const bool row_ok = qrow < p.Nq;
 #pragma unroll
-            for (int db = 0; db < 2; ++db)
+        for (int db = 0; db < 2; ++db) {
+            unsigned og[4][2];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    h4 o;
+            for (int g = 0; g < 4; ++g) {
+                h4 o;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = (half_t)(O[qb][db][4 * g + e] * inv);
-                    *reinterpret_cast<h4*>(op + db * 32 + 8 * g + 4 * lhi) = o;
-                }
+                for (int e = 0; e < 4; ++e) o[e] = (half_t)(O[qb][db][4 * g + e] * inv);
+                const u32x2_sp t2 = __builtin_bit_cast(u32x2_sp, o);
+                og[g][0] = t2[0], og[g][1] = t2[1];
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(og[2 * j][0]), "+v"(og[2 * j + 1][0]));
+                asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(og[2 * j][1]), "+v"(og[2 * j + 1][1]));
+                const u32x4_sp v = {og[2 * j][0], og[2 * j][1], og[2 * j + 1][0], og[2 * j + 1][1]};
+                if (row_ok) *reinterpret_cast<u32x4_sp*>(op + db * 32 + j * 16) = v;
+            }
         }
     }
 }
