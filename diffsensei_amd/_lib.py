@@ -36,6 +36,7 @@ SIGNATURES = {
     "ds_set_option": (i32, [C.c_char_p, i32]),
     "ds_debug_counter": (i32, [C.c_char_p, i32, C.POINTER(C.c_longlong)]),
     "ds_gemm_t160_fits": (i32, [i32, i32, i32, i32]),
+    "ds_gemm_g320_fits": (i32, [i32, i32, i32, i32]),
     "ds_conv3x3_gn_chunks": (i32, [i32, i32, i32, i32, i32]),
     "ds_gemm_f16": (i32, [vp, i64, vp, i64, i32, vp, i64, vp, vp, i64, vp, i64, i32, i32, i32, i32, vp]),
     "ds_gemm_ln_f16": (i32, [vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp, i32, i32, i32, i32, vp]),

@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libdiffsensei_hip.so")
-SOURCES = ["gemm.hip", "gemm_pp.hip", "gemm_t160.hip", "conv_halo.hip", "vae.hip", "norm.hip", "attention.hip", "attention_sp.hip", "elementwise.hip", "llm.hip", "preprocess.hip",
+SOURCES = ["gemm.hip", "gemm_pp.hip", "gemm_t160.hip", "gemm_g320.hip", "conv_halo.hip", "vae.hip", "norm.hip", "attention.hip", "attention_sp.hip", "elementwise.hip", "llm.hip", "preprocess.hip",
            "capi.hip"]
 HEADERS = ["ds_common.h", "ds_kernels.h", os.path.join("..", "..", "include", "diffsensei_hip.h")]
 # -ffast-math spelled out WITHOUT -fassociative-math and -ffinite-math-only (round 3): with reassociation

@@ -87,6 +87,11 @@ int ds_set_option(const char* key, int value) {
         ds_gemm_set_t160(value);
         return 0;
     }
+    if (strcmp(key, "gemm_g320") == 0) {
+        DS_REQUIRE(value >= 0 && value <= 1, "gemm_g320 must be 0 (auto) or 1 (off)");
+        ds_gemm_set_g320(value);
+        return 0;
+    }
     if (strcmp(key, "gemm_ring") == 0) {
         DS_REQUIRE(value >= 0 && value <= 1, "gemm_ring must be 0 (auto) or 1 (off)");
         ds_gemm_set_ring(value);
@@ -110,6 +115,7 @@ int ds_set_option(const char* key, int value) {
 }
 
 int ds_gemm_t160_fits(int M, int N, int K, int batch) { return ds_gemm_t160_shape(M, N, K, batch) ? 1 : 0; }
+int ds_gemm_g320_fits(int M, int N, int K, int batch) { return ds_gemm_g320_shape(M, N, K, batch) ? 1 : 0; }
 
 int ds_debug_counter(const char* name, int reset, long long* value) {
     DS_REQUIRE(name != nullptr, "ds_debug_counter: null name");
@@ -621,7 +627,7 @@ int ds_op_describe(const ds_op* op, char* name, int name_len, double* flops, dou
             const int batch = i[5] > 0 ? i[5] : 1;
             nm = ds_gemm_kernel_name(g, batch);
             fl = 2.0 * i[0] * (double)i[1] * i[2] * batch;
-            by = 2.0 * batch * ((double)i[0] * i[2] + (double)i[1] * i[2] + (double)i[0] * (i[4] == 1 ? i[1] / 2 : i[1]));
+            by = 2.0 * batch * ((double)i[0] * i[2] + (double)i[1] * i[2] + (double)i[0] * (i[4] == 1 || i[4] == 4 ? i[1] / 2 : i[1]));
             break;
         }
         case DS_OP_CONV3X3: {

@@ -2,7 +2,8 @@
 #pragma once
 #include "ds_common.h"
 
-enum { EPI_NONE = 0, EPI_GEGLU = 1, EPI_GELU = 2, EPI_QUICK_GELU = 3 };
+// EPI_GEGLU320: GEGLU whose packed W rows come in groups of 320 (160 hidden + their 160 gates): gemm_g320_kernel only
+enum { EPI_NONE = 0, EPI_GEGLU = 1, EPI_GELU = 2, EPI_QUICK_GELU = 3, EPI_GEGLU320 = 4 };
 
 struct GemmParams {
     const half_t* A = nullptr;   // plain: [M,K] rows (lda);  conv: NHWC input [B,Hin,Win,Cin]
@@ -71,6 +72,11 @@ bool ds_gemm_t160_possible(const GemmParams& p, int batch);        // what the k
 bool ds_gemm_t160_applicable(const GemmParams& p, int batch);      // possible && shape rule
 int ds_launch_gemm_t160(const GemmParams& p, hipStream_t stream);
 void ds_gemm_set_t160(int v);     // 0 auto, 1 never
+// gemm_g320.hip: 256 x 320 tiles, one block per CU, for the GEGLU projection of a small-batch request (epi == EPI_GEGLU320)
+bool ds_gemm_g320_shape(int M, int N, int K, int batch);           // the automatic dispatch rule (host logic only)
+bool ds_gemm_g320_possible(const GemmParams& p, int batch);
+int ds_launch_gemm_g320(const GemmParams& p, hipStream_t stream);
+void ds_gemm_set_g320(int v);     // 0 auto, 1 never
 
 // ---- VAE decoder only (vae.hip) ---------------------------------------------------------------------
 int ds_launch_wide_attn(const void* q, const void* k, const void* vt, void* o, int B, int N, int n_valid, int dtype,

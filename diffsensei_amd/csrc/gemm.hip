@@ -878,6 +878,8 @@ bool ds_gemm_pp_fast_path(int M, int N, int K, int batch, int epi) {
 int ds_gemm_ln_kind(int M, int N, int K, int batch, int epi) {
     GemmParams p;
     p.M = M; p.N = N; p.K = K; p.lda = K; p.ldw = K; p.ldc = N; p.epi = epi; p.K1 = K;
+    // the 320-packed GEGLU projection (gemm_g320_kernel) consumes partial sums like the 128-wide kernels
+    if (epi == EPI_GEGLU320) return (M > 0 && batch == 1 && N > 0 && N % 320 == 0 && K > 0 && K % 64 == 0) ? 2 : 0;
     if (M <= 0 || N <= 0 || K <= 0 || batch < 1 || (epi != EPI_NONE && epi != EPI_GEGLU)) return 0;
     // gemm_pp_kernel's fused epilogues: whole 256-row tiles; whole 256-column tiles, or - plain epilogue, unbatched (the batched
     // problem is the operand-swapped consumer, whose statistics run along the tile columns) - whole 64-column strips
@@ -893,6 +895,7 @@ int ds_gemm_ln_kind(int M, int N, int K, int batch, int epi) {
 }
 
 const char* ds_gemm_kernel_name(const GemmParams& p, int batch) {
+    if (p.epi == EPI_GEGLU320) return "gemm_g320_kernel";
     // the fused-LayerNorm instantiations of gemm_pp_kernel are kernels of their own in a rocprofv3 trace (template argument FUSE)
     if (p.ln_stats && !p.ln_partial) return p.ln_swapped ? "gemm_pp_kernel<0,4>" : p.epi == EPI_GEGLU ? "gemm_pp_kernel<0,9>" : "gemm_pp_kernel<0,1>";
     if (p.stats_out && ds_gemm_ln_kind(p.M, p.N, p.K, batch, p.epi) == 1) return "gemm_pp_kernel<0,2>";
@@ -937,6 +940,10 @@ int ds_launch_gemm(const GemmParams& p_in, int batch, hipStream_t stream) {
         DS_REQUIRE(p.A2 == nullptr || (p.K1 % 64 == 0 && p.lda2 % 8 == 0), "gemm: split-A needs K1 %% 64 == 0");
     }
     if (p.epi == EPI_GEGLU) DS_REQUIRE(p.N % 128 == 0, "geglu: packed N (%d) must be a multiple of 128", p.N);
+    if (p.epi == EPI_GEGLU320) {   // W packed in 320-row groups (engine.pack_geglu320): one kernel reads that layout
+        DS_REQUIRE(ds_gemm_g320_possible(p, batch), "geglu320: plain f16 GEMM, batch 1, N %% 320 == 0, K %% 64 == 0, no residual (M=%d N=%d K=%d)", p.M, p.N, p.K);
+        return ds_launch_gemm_g320(p, stream);
+    }
     Choice c = choose(p, batch);
     DS_REQUIRE(!p.gn_partial || (conv && c.kind == K_HALO && p.dtype == DS_DTYPE_F16),
                "conv3x3: GroupNorm statistics come out of the halo-patch kernels only (ask ds_conv3x3_gn_chunks first)");

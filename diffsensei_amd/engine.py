@@ -43,6 +43,21 @@ def pack_geglu(w: Tensor, b: Tensor) -> Tuple[Tensor, Tensor]:
     return wp.contiguous(), bp.contiguous()
 
 
+def unpack_geglu(t: Tensor) -> Tensor:
+    """Inverse of `pack_geglu` on its first axis: 128-row groups (64 hidden + 64 gates) -> [hidden rows | gate rows]."""
+    g = t.reshape(t.shape[0] // 128, 2, 64, *t.shape[1:])
+    return torch.cat([g[:, 0].reshape(-1, *t.shape[1:]), g[:, 1].reshape(-1, *t.shape[1:])], 0)
+
+
+def pack_geglu320(t: Tensor) -> Tensor:
+    """GEGLU rows [hidden | gate] (weight [8C,C], bias [8C] or the fused-LayerNorm c pairs [8C,2]) -> groups of 320 rows: 160
+    hidden rows followed by their 160 gate rows - the layout gemm_g320_kernel's 256 x 320 tiles read (csrc/gemm_g320.hip)."""
+    half = t.shape[0] // 2
+    assert half % 160 == 0, "GEGLU inner dim must be a multiple of 160"
+    g = half // 160
+    return torch.stack([t[:half].reshape(g, 160, *t.shape[1:]), t[half:].reshape(g, 160, *t.shape[1:])], dim=1).reshape(t.shape).contiguous()
+
+
 def pack_ln_fused(w: Tensor, bias: Optional[Tensor], gamma: Tensor, beta: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
     """LayerNorm folded into the linear that consumes it (csrc/gemm_pp.hip, "LayerNorm"):
     LN(x) W^T + b = rstd (x (gamma (.) W)^T - mean c) + b',  c_n = sum_k (gamma (.) W)_nk,  b' = b + W beta.
@@ -218,6 +233,19 @@ class PackedUNet:
         self.kv_total = off
         for name, lst in (("xattn.k_text", kt), ("xattn.v_text", vt), ("xattn.k_ip", ki), ("xattn.v_ip", vi)):
             put(name, torch.cat([t.to(device) for t in lst], 0))
+
+    def geglu320(self, t: str, ln: bool) -> Tuple[Tensor, Tensor, Optional[Tensor]]:
+        """(weight, bias, c) of transformer block `t`'s GEGLU projection re-packed in 320-row groups for gemm_g320_kernel - made
+        on first use (a plan asks only where ds_gemm_g320_fits says that kernel runs: the 1280-channel level of a batch-1
+        request; +26 MB per block) from the 128-row packing, which stays for every other batch."""
+        sfx = "_ln" if ln else ""
+        key = f"{t}.ff.net.0.proj.weight{sfx}.g320"
+        if key not in self.w:
+            self.w[key] = pack_geglu320(unpack_geglu(self.w[f"{t}.ff.net.0.proj.weight{sfx}"]))
+            self.w[f"{t}.ff.net.0.proj.bias{sfx}.g320"] = pack_geglu320(unpack_geglu(self.w[f"{t}.ff.net.0.proj.bias{sfx}"]))
+            if ln:
+                self.w[f"{t}.ff.net.0.proj.c_ln.g320"] = pack_geglu320(unpack_geglu(self.w[f"{t}.ff.net.0.proj.c_ln"]))
+        return self.w[key], self.w[f"{t}.ff.net.0.proj.bias{sfx}.g320"], (self.w[f"{t}.ff.net.0.proj.c_ln.g320"] if ln else None)
 
     def nbytes(self) -> int:
         return sum(t.numel() * t.element_size() for t in self.w.values())
@@ -449,7 +477,8 @@ class UNetEngine:
         stats_strip: statistics format the producer is asked for (0 / 64 = one entry per 64 columns; 160 = gemm_t160_kernel's three per tile),
         ln_nstrips: entries per row a consumer of partial sums adds up (0 = K / 64)."""
         n_out = N // 2 if geglu else N
-        ops.append(make_op("GEMM", i=(M, N, K, K1 if x2 is not None else K, int(geglu), 1, 0, 1, 0, int(ln_partial),
+        epi = 4 if geglu == 320 else int(bool(geglu))   # 4: W / bias / c packed in 320-row groups (PackedUNet.geglu320)
+        ops.append(make_op("GEMM", i=(M, N, K, K1 if x2 is not None else K, epi, 1, 0, 1, 0, int(ln_partial),
                                       int(ln_nstrips) if ln_stats is not None else 0, int(stats_strip) if stats_out is not None else 0),
                            f=(1e-5,),
                            l=(K1 if x2 is not None else K, (K - K1) if x2 is not None else 0, K, n_out, n_out),
@@ -523,7 +552,9 @@ class UNetEngine:
         can = lambda m, n, k, epi=0, batch=1: kind(m, n, k, epi, batch) == 1
         have = f"{p}.transformer_blocks.0.attn2.to_q.weight_ln" in w and ln_fusion_enabled()
         # norm2 / norm3: producers = the two out-projections (N = K = C), consumers = attn2.to_q and the GEGLU projection
-        k_proj, k_ff = kind(M, Cc, Cc), kind(M, 8 * Cc, Cc, 1)
+        # (the GEGLU projection of a small batch may run gemm_g320_kernel: 256 x 320 tiles, one block per CU, its own packing)
+        g320 = bool(int(lib.ds_gemm_g320_fits(M, 8 * Cc, Cc, 1)))
+        k_proj, k_ff = kind(M, Cc, Cc), kind(M, 8 * Cc, Cc, 4 if g320 else 1)
         pp_min, wide_max, all_pp_min = ln_fusion_limits()
         pays = lambda k: (k == 1 and M * Cc >= pp_min) or (k == 2 and M * Cc <= wide_max)
         fuse = have and pays(k_proj) and pays(k_ff) and not (k_proj == 1 and k_ff == 1 and M * Cc < all_pp_min)
@@ -593,13 +624,14 @@ class UNetEngine:
             if fuse:
                 if k_ff == 1:
                     ops.append(make_op("LN_FINALIZE", i=(M, nstr, Cc), f=(1e-5,), p=(part, st)))
-                self._gemm(ops, h, w[t + ".ff.net.0.proj.weight_ln"], ff, M, 8 * Cc, Cc, bias=w[t + ".ff.net.0.proj.bias_ln"],
-                           geglu=True, ln_stats=st if k_ff == 1 else part, ln_c=w[t + ".ff.net.0.proj.c_ln"], ln_partial=k_ff == 2,
-                           ln_nstrips=nstr)
+                gw, gb, gc = self.pk.geglu320(t, True) if g320 else (
+                    w[t + ".ff.net.0.proj.weight_ln"], w[t + ".ff.net.0.proj.bias_ln"], w[t + ".ff.net.0.proj.c_ln"])
+                self._gemm(ops, h, gw, ff, M, 8 * Cc, Cc, bias=gb, geglu=320 if g320 else True,
+                           ln_stats=st if k_ff == 1 else part, ln_c=gc, ln_partial=k_ff == 2, ln_nstrips=nstr)
             else:
                 ops.append(make_op("LAYERNORM", i=(M, Cc), f=(1e-5,), p=(h, tn, w[t + ".norm3.weight"], w[t + ".norm3.bias"])))
-                self._gemm(ops, tn, w[t + ".ff.net.0.proj.weight"], ff, M, 8 * Cc, Cc, bias=w[t + ".ff.net.0.proj.bias"],
-                           geglu=True)
+                gw, gb, _ = self.pk.geglu320(t, False) if g320 else (w[t + ".ff.net.0.proj.weight"], w[t + ".ff.net.0.proj.bias"], None)
+                self._gemm(ops, tn, gw, ff, M, 8 * Cc, Cc, bias=gb, geglu=320 if g320 else True)
             self._gemm(ops, ff, w[t + ".ff.net.2.weight"], h, M, Cc, 4 * Cc, bias=w[t + ".ff.net.2.bias"], residual=h,
                        stats_out=part if (fuse1 and k + 1 < a.depth) else None, stats_strip=sw)
         self._gemm(ops, h, w[p + ".proj_out.weight"], out, M, Cc, Cc, bias=w[p + ".proj_out.bias"], residual=x)

@@ -50,12 +50,23 @@ def _chk(*ts: Optional[Tensor], dtype=torch.float16) -> None:
 _EPILOGUES = {None: 0, "geglu": 1, "gelu": 2, "quick_gelu": 3}
 
 
+def _geglu_code(geglu) -> int:
+    """`geglu` argument of the GEMM wrappers -> epilogue code: False 0, True 1 (w / bias packed by `engine.pack_geglu`, 128-row
+    groups), 320 -> 4 (packed by `engine.pack_geglu320`: gemm_g320_kernel)."""
+    if geglu is True or geglu == 1:
+        return 1
+    if geglu == 320:
+        return 4
+    assert not geglu, geglu
+    return 0
+
+
 def gemm(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, residual: Optional[Tensor] = None,
          geglu: bool = False, out: Optional[Tensor] = None, x2: Optional[Tensor] = None,
          act: Optional[str] = None) -> Tensor:
     """y = act(cat([x, x2], -1) @ w.T + bias) (+residual);  geglu: w/bias packed by `pack_geglu`, y = h*gelu(g)."""
     _chk(x, w, bias, residual, x2)
-    epi = 1 if geglu else _EPILOGUES[act]
+    epi = _geglu_code(geglu) if geglu else _EPILOGUES[act]
     M, K1 = x.shape
     K = K1 + (x2.shape[1] if x2 is not None else 0)
     N = w.shape[0]
@@ -87,7 +98,7 @@ def gemm_ln(x: Tensor, gw: Tensor, bias_ln: Optional[Tensor] = None, ln_c: Optio
     part = torch.empty((N // 64, M, 2), dtype=torch.float32, device=x.device) if emit_stats else None
     L = _lib.load()
     check(L.ds_gemm_ln_f16(_p(x), K, _p(gw), K, _p(bias_ln), _p(ln_stats), _p(ln_c), _p(residual), n_out, _p(out), n_out,
-                           _p(part), M, N, K, 1 if geglu else 0, _stream()), "ds_gemm_ln_f16")
+                           _p(part), M, N, K, _geglu_code(geglu), _stream()), "ds_gemm_ln_f16")
     return (out, part) if emit_stats else out
 
 
@@ -103,7 +114,7 @@ def ln_finalize(partial: Tensor, C: int, eps: float = 1e-5) -> Tensor:
 def gemm_ln_fusable(M: int, N: int, K: int, geglu: bool = False, batch: int = 1) -> int:
     """Which fused-LayerNorm form the dispatch gives this GEMM: 1 = the 256 x 256 kernel (`gemm_ln` with finalised statistics),
     2 = the 128-wide kernels (`gemm_ln_partial` consumers, `gemm_ln` producers), 0 = none."""
-    return int(_lib.load().ds_gemm_ln_fusable(M, N, K, 1 if geglu else 0, batch))
+    return int(_lib.load().ds_gemm_ln_fusable(M, N, K, _geglu_code(geglu), batch))
 
 
 def gemm_ln_partial(x: Tensor, gw: Tensor, bias_ln: Optional[Tensor], ln_c: Tensor, partial: Tensor, eps: float = 1e-5,
@@ -121,7 +132,7 @@ def gemm_ln_partial(x: Tensor, gw: Tensor, bias_ln: Optional[Tensor], ln_c: Tens
         out = torch.empty((M, n_out), dtype=torch.float16, device=x.device)
     part = torch.empty((N // 64, M, 2), dtype=torch.float32, device=x.device) if emit_stats else None
     check(_lib.load().ds_gemm_ln_partial_f16(_p(x), K, _p(gw), K, _p(bias_ln), _p(partial), eps, _p(ln_c), _p(residual), n_out,
-                                             _p(out), n_out, _p(part), M, N, K, 1 if geglu else 0, _stream()),
+                                             _p(out), n_out, _p(part), M, N, K, _geglu_code(geglu), _stream()),
           "ds_gemm_ln_partial_f16")
     return (out, part) if emit_stats else out
 

@@ -40,6 +40,8 @@ int ds_device_info(int* cu_count, int* lds_bytes, char* arch_name, int arch_name
  *                        3 256x256 ping-pong (gemm_pp_kernel) | 10 halo-patch conv | 11 64x160 tiles (gemm_t160_kernel)
  *   "gemm_t160"          0 (default) small-batch projections whose 64x160 grid is one block per CU run gemm_t160_kernel |
  *                        1 never (A/B)
+ *   "gemm_g320"          0 (default) ds_gemm_g320_fits follows its shape rule | 1 it answers 0 (A/B: planners then keep the
+ *                        128-row GEGLU packing and the 128 x 128 / 256 x 256 kernels)
  *   "gemm_pp_even"       1 (default) gemm_pp_kernel's persistent grid = ceil(tiles / rounds) blocks, every round full |
  *                        0 one block per CU with a partial last round
  *   "gemm_ring"          0 (default) grids of <= 512 64x128 blocks (num_samples 1) use the ring-buffered
@@ -81,6 +83,13 @@ int ds_debug_counter(const char* name, int reset, long long* value);
  * 160-column tile - columns 0..63, 64..127, 128..159) and tells the consumers to add 3 N / 160 entries (i[10]); a direct
  * ds_gemm_ln_* call always gets the 64-column format. */
 int ds_gemm_t160_fits(int M, int N, int K, int batch);
+/* Host-side query of the dispatch rule (no GPU work): 1 when the GEGLU projection [M, N packed] x K of a small-batch request
+ * should run gemm_g320_kernel (256 x 320 tiles, exactly one block per CU: M = 2048, N = 10240, K = 1280 at UNet batch 2,
+ * 1024 x 1024 - diffusers' GEGLU [3P] reached from reference src/models/unet.py:244-338).  That kernel reads W / bias / c
+ * packed in groups of 320 rows (160 hidden rows, then their 160 gate rows) and is selected by epilogue code 4 (below);
+ * a planner asks BEFORE packing.  Epilogue codes of the GEMM entry points: 0 none, 1 GEGLU (128-row groups: 64 hidden + 64
+ * gates), 2 GELU, 3 QuickGELU, 4 GEGLU in 320-row groups. */
+int ds_gemm_g320_fits(int M, int N, int K, int batch);
 /* Host-side query: partial-sum chunks per image that a stride-1 3x3 convolution of this shape writes for the GroupNorm behind
  * it (DsOp CONV3X3 p[6] = the GroupNorm workspace; DsOp GROUPNORM i[6] = this number: the GroupNorm then skips its statistics
  * pass).  0: this convolution cannot (not a halo-patch kernel shape, or more than 128 pixel tiles per image).  Replaces the
