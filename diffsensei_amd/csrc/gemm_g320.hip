@@ -25,6 +25,15 @@
 // k-tile kt + 1 are issued three at a time between the MFMA groups of k-tile kt (its stage was read during kt - 1, and every
 // wave has passed the barrier at the top of kt since), the fragments of k-step kk + 1 are requested ahead of the MFMAs of k-step
 // kk (two register sets).  One barrier per k-tile.
+// (Measured alternative, same round: 32-wide k-tiles in 64-byte LDS rows - chunk c of row r at slot c ^ ((r >> 2) & 3), conflict-
+// free for ds_read_b128 - in a ring of FOUR 36-KiB stages with counted vmcnt waits, two k-tiles in flight beside the two being
+// read and the fragment read-ahead carried across the k-tile boundary: bit-identical and SLOWER, 63.4 vs 57.5 us back to back
+// (profiles/r06_g320_v2_ring4_k32_microbench.txt against r06_g320_v1_microbench.txt).  The two-stage loop is not waiting for
+// its DMA: 20 k-tiles in ~48 us = 2.4 us per 10.5 MFLOP = the matrix pipe ~0.6 busy at the clock this load sustains, the place
+// every matrix kernel of this library sits; twice the barriers and twice the DMA pieces per byte cost
+// more than the deeper ring hides.  Four schedule variants of THIS loop - s_setprio 1 around the MFMA groups, waves 4..7 issuing
+// their pieces one k-step later, the pieces between the halves of an MFMA group, static priority for waves 4..7 - all measured
+// 57.1-58.6 us against 57.2-57.5: profiles/r06_g320_schedule_variants.txt.)
 // The tile's bias and (-c hi, -c lo) slices are LDS-DMA pieces of the prologue; the consumer's row statistics (the producer's
 // partial sums, the format of gemm.hip / gemm_t160.hip) are summed in the prologue under the first k-tile's round trip - four
 // floats per lane live across the k-loop.
