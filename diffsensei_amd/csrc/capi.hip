@@ -83,7 +83,7 @@ int ds_set_option(const char* key, int value) {
         return 0;
     }
     if (strcmp(key, "gemm_t160") == 0) {
-        DS_REQUIRE(value >= 0 && value <= 1, "gemm_t160 must be 0 (auto) or 1 (off)");
+        DS_REQUIRE(value >= 0 && value <= 3, "gemm_t160 must be 0 (auto), 1 (off), 2 (no 128-row tiles) or 3 (128-row tiles wherever it runs)");
         ds_gemm_set_t160(value);
         return 0;
     }

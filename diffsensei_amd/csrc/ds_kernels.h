@@ -68,6 +68,7 @@ void ds_gemm_pp_set_even(int v);  // experiment: 1 = persistent grid shrunk so t
 void ds_gemm_set_variant(int v);  // 0 auto, 1 register staging only, 2 glds (BM <= 128), 3 glds, BM = 256 when large
 // gemm_t160.hip: 64 x 160 tiles, one block per CU, for the small-batch projections of the 1280-channel level
 bool ds_gemm_t160_shape(int M, int N, int K, int batch);           // the automatic dispatch rule (host logic only)
+int ds_gemm_t160_rows(int M, int N, int K, int batch);             // rows per tile the launcher uses there: 64 | 128 (0: the rule does not pick the kernel -> 64 when forced)
 bool ds_gemm_t160_possible(const GemmParams& p, int batch);        // what the kernel can run at all (gemm_variant 11)
 bool ds_gemm_t160_applicable(const GemmParams& p, int batch);      // possible && shape rule
 int ds_launch_gemm_t160(const GemmParams& p, hipStream_t stream);

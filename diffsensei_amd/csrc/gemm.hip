@@ -905,7 +905,7 @@ const char* ds_gemm_kernel_name(const GemmParams& p, int batch) {
         case K_PP: return "gemm_pp_kernel<0,0>";
         case K_HALO: return "conv_halo_kernel";
         case K_RING: return c.bm == 4 ? "gemm_glds_kernel<64,false,4>" : "gemm_glds_kernel<64,false,3>";
-        case K_T160: return "gemm_t160_kernel";
+        case K_T160: return ds_gemm_t160_rows(p.M, p.N, p.K, batch) == 128 ? "gemm_t160_kernel<128 rows>" : "gemm_t160_kernel";
         case K_GLDS1:
             if (c.bm == 128) return conv ? "gemm_glds_kernel<128,true,1>" : "gemm_glds_kernel<128,false,1>";
             return conv ? "gemm_glds_kernel<64,true,1>" : "gemm_glds_kernel<64,false,1>";

@@ -38,8 +38,8 @@ int ds_device_info(int* cu_count, int* lds_bytes, char* arch_name, int arch_name
  * re-associate a sum - self_attn_sp_kernel vs the flash kernels, gn_variant 1's chunking - are compared at a stated tolerance.
  *   "gemm_variant"       0 auto | 1 register-staged only | 2, 7 two-buffer LDS-DMA | 8, 9 one-buffer LDS-DMA |
  *                        3 256x256 ping-pong (gemm_pp_kernel) | 10 halo-patch conv | 11 64x160 tiles (gemm_t160_kernel)
- *   "gemm_t160"          0 (default) small-batch projections whose 64x160 grid is one block per CU run gemm_t160_kernel |
- *                        1 never (A/B)
+ *   "gemm_t160"          0 (default) small-batch projections whose 64x160 (or, failing that, 128x160) grid is one block per CU
+ *                        run gemm_t160_kernel | 1 never (A/B) | 2 never its 128-row tile | 3 128-row tiles wherever it runs (tests)
  *   "gemm_g320"          0 (default) ds_gemm_g320_fits follows its shape rule | 1 it answers 0 (A/B: planners then keep the
  *                        128-row GEGLU packing and the 128 x 128 / 256 x 256 kernels)
  *   "gemm_pp_even"       1 (default) gemm_pp_kernel's persistent grid = ceil(tiles / rounds) blocks, every round full |

@@ -88,8 +88,8 @@ def test_t160_is_the_automatic_choice_at_the_batch1_shapes_only(hip_lib):
     lib = _lib.load()
     fits = lambda m, n, k, b=1: int(lib.ds_gemm_t160_fits(m, n, k, b))
     assert fits(2048, 1280, 1280) and fits(2048, 1280, 5120)           # UNet batch 2 at 1024 x 1024, level 2
-    assert not fits(2048, 2560, 1280)                                   # q|k: 512 blocks of 64 x 160
-    assert not fits(8192, 640, 640) and not fits(65536, 1280, 1280)     # level 1; the benched batch
+    assert fits(2048, 2560, 1280)                                       # q|k: 512 blocks of 64 x 160 -> 256 blocks of 128 x 160
+    assert not fits(65536, 1280, 1280) and not fits(8192, 1280, 640)    # the benched batch; level-1 q|k of a batch-1 request (512 tall blocks)
     assert not fits(1024, 1280, 1280)                                   # 512 x 512: the 64 x 128 grid is already <= 256 blocks
     assert not fits(2048, 1280, 1280, 2) and not fits(2048, 1264, 1280)
     g = torch.Generator().manual_seed(1)
@@ -157,3 +157,69 @@ def test_t160_refuses_what_it_does_not_implement(hip_lib):
     yf = y.float().cpu().view(2048, 20, 64)
     assert torch.allclose(part[..., 0].t().cpu(), yf.sum(-1), rtol=1e-5, atol=1e-3)
     assert torch.equal(y, ops.gemm(x, w, b))
+
+
+@pytest.mark.parametrize("M,N,K,bias,res", [(2048, 2560, 1280, True, False), (2048, 1280, 1280, True, True), (1000, 320, 192, True, True),
+                                            (130, 160, 64, False, False), (4096, 1280, 5120, True, True)])
+def test_t160_tall_tiles_vs_fp32_and_vs_the_64_row_tiles(hip_lib, M, N, K, bias, res):
+    """The 128 x 160 instantiation (four ring stages; the q|k projection of a batch-1 request: M = 2048, N = 2560 -> 16 x 16 = 256
+    blocks), forced wherever the kernel runs: vs fp32 torch and bit-identical to the 64 x 160 tiles - same MFMA, same k order,
+    same epilogue arithmetic; whole and ragged row tiles."""
+    from diffsensei_amd import _lib, ops
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M * 5 + N + K)
+    x, w = _r((M, K), g), _r((N, K), g, 1 / math.sqrt(K))
+    b = _r((N,), g) if bias else None
+    r = (_r((M, N), g) * 2 + 0.5).half() if res else None
+    dv = lambda t: None if t is None else t.to(DEV)
+    ref = F.linear(x.float(), w.float(), None if b is None else b.float())
+    if r is not None:
+        ref = ref.half().float() + r.float()
+    assert lib.ds_set_option(b"gemm_t160", 3) == 0
+    try:
+        got = _forced(lib, 11, lambda: ops.gemm(dv(x), dv(w), dv(b), dv(r)))
+    finally:
+        lib.ds_set_option(b"gemm_t160", 0)
+    e = _relmax(got, ref)
+    print(f"gemm_t160 (128-row tiles) M={M} N={N} K={K}: max err / max|ref| {e:.2e}")
+    assert e <= 2e-3, e
+    assert lib.ds_set_option(b"gemm_t160", 2) == 0
+    try:
+        short = _forced(lib, 11, lambda: ops.gemm(dv(x), dv(w), dv(b), dv(r)))
+    finally:
+        lib.ds_set_option(b"gemm_t160", 0)
+    assert torch.equal(got, short), "the 128-row and the 64-row tiles of gemm_t160_kernel differ"
+
+
+def test_t160_tall_tiles_rule_and_fused_layernorm_chain(hip_lib):
+    """The rule picks 128-row tiles for the q|k projection of a batch-1 request only where the 64-row grid overflows the CUs;
+    producer (statistics, 160-column format) and consumer (partial sums) forms on 128-row tiles give the bits of the 64-row tiles."""
+    from diffsensei_amd import _lib
+    from diffsensei_amd.engine import pack_ln_fused
+    lib = _lib.load()
+    fits = lambda m, n, k, b=1: int(lib.ds_gemm_t160_fits(m, n, k, b))
+    assert fits(2048, 2560, 1280) == 1 and fits(2048, 1280, 1280) == 1 and fits(65536, 2560, 1280) == 0
+    g = torch.Generator().manual_seed(77)
+    M, Cc = 2048, 1280
+    a, wo, bo = _r((M, Cc), g).to(DEV), _r((Cc, Cc), g, 1 / math.sqrt(Cc)).to(DEV), _r((Cc,), g).to(DEV)
+    h0 = (_r((M, Cc), g) * 2 + 0.5).half().to(DEV)
+    wq, gamma, beta = _r((2 * Cc, Cc), g, 1 / math.sqrt(Cc)).to(DEV), (1 + 0.2 * torch.randn(Cc, generator=g)).half().to(DEV), _r((Cc,), g, 0.2).to(DEV)
+    gw, c2, b2 = pack_ln_fused(wq, None, gamma, beta)
+    outs = {}
+    for mode in (2, 3):
+        assert lib.ds_set_option(b"gemm_t160", mode) == 0 and lib.ds_set_option(b"gemm_variant", 11) == 0
+        try:
+            h, part, nm = _gemm_op(lib, a, wo, bias=bo, residual=h0, stats_strip=160)
+            y, _, nm2 = _gemm_op(lib, h, gw, bias=b2, ln_partial=part, ln_c=c2, ln_nstrips=24)
+        finally:
+            lib.ds_set_option(b"gemm_t160", 0)
+            lib.ds_set_option(b"gemm_variant", 0)
+        assert nm.startswith("gemm_t160_kernel") and nm2.startswith("gemm_t160_kernel"), (nm, nm2)
+        outs[mode] = (h, part, y)
+    for u, v in zip(outs[2], outs[3]):
+        assert torch.equal(u, v)
+    hr = ((a.float() @ wo.float().t() + bo.float()).half().float() + h0.float()).half().float()
+    ref = F.linear(F.layer_norm(hr, (Cc,), gamma.float(), beta.float(), 1e-5), wq.float())
+    assert _relmax(outs[3][2], ref) <= 3e-3
+    # automatic dispatch at the q|k shape of a batch-1 request
+    assert _gemm_op(lib, outs[3][0], gw, bias=b2, ln_partial=outs[3][1], ln_c=c2, ln_nstrips=24)[2] == "gemm_t160_kernel<128 rows>"
