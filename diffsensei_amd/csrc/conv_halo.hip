@@ -333,6 +333,12 @@ static_assert(128 * CS_STRIDE + 4096 <= PROWS * 128 + BN * 128, "conv_halo_kerne
 // left is the CU's fill path itself: 18.7 KiB per k-tile in 0.64 us = 29 GB/s, between the 21-25 GB/s a CU draws from HBM and
 // the 35-45 it draws from the Infinity Cache / L2 whatever is in flight (tools/ubench/lds_fill_rate.hip) - the weights of a
 // batch-1 request are read cold.)
+// (Later in round 6, three timing experiments on the 1280 -> 1280 convolution at UNet batch 2, 117 us: the same time with hot
+// weights - the launch repeated back to back - as inside the forward; half / a quarter of the W pieces issued (garbage results):
+// 113.6 / 110.0 us; ALL sixteen fragments of the next k-tile requested ahead of a k-tile's MFMAs (two 64-register sets, the last
+// k-tile peeled so the compiler keeps counted lgkmcnt waits): 114.7 us, bit-identical, not kept.  So neither cold weights, nor the
+// bytes, nor the LDS round trips hold the 0.64 us per k-tile against 0.24 us of MFMAs; what is left is the chain wait -> barrier ->
+// DMA issue -> landing of one block alone on its CU - the guide's "landing cadence 0.64 us per 16-KiB fill" of a single loader.)
 // Same products in the same order as conv_halo_kernel: bit-identical results (tests/test_gpu_ops.py).
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int DEEP_NW = 3;                            // W buffers in the ring: DEEP_NW - 1 k-tiles (32 KiB) in flight per CU
