@@ -263,11 +263,18 @@ def test_forward_flop_inventory_matches_survey(hip_lib):
     m = UNetMangaModel(sdxl_config(), device=DEV).init_random(0)
     eng = m.engine(2, 128, 128, 1.0)
     lib = _lib.load()
-    fl, by, name, tot = C.c_double(), C.c_double(), C.create_string_buffer(64), 0.0
+    from collections import Counter
+    fl, by, name, tot, names = C.c_double(), C.c_double(), C.create_string_buffer(64), 0.0, Counter()
     for op in eng.forward_ops:
         lib.ds_op_describe(C.byref(op), name, 64, C.byref(fl), C.byref(by))
         tot += fl.value
+        names[name.value.decode()] += 1
     assert abs(tot / 1e12 - (13.71 - 0.22)) < 0.05, tot / 1e12
+    # the reference's call shape runs the kernels built for it (round 6): the 60 GEGLU projections of the 1280-channel level on
+    # gemm_g320_kernel (256 x 320 tiles), its 60 q|k projections - and the 640-channel level's N = 640 projections - on the
+    # 128 x 160 tiles of gemm_t160_kernel, the other N = 1280 projections on its 64 x 160 tiles: the UNet-vs-oracle gates of
+    # tests/test_gpu_unet.py at this shape therefore cover them
+    assert names["gemm_g320_kernel"] == 60 and names["gemm_t160_kernel<128 rows>"] >= 60 and names["gemm_t160_kernel"] >= 240, names
     # 963 launches with every LayerNorm a launch of its own; at this batch all 210 are folded into the GEMMs around them (the
     # 128-wide kernels' fused epilogues) at the price of 10 finalize launches (the GEGLU projections of the 64 x 64-token level are
     # gemm_pp_kernel consumers): 763, + CFG/scheduler step + counter advance = 765 launches per denoise step
