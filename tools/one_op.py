@@ -6,6 +6,8 @@
     python tools/one_op.py attn1k [reps]     self_attn_kernel<1>: B=32, 20 heads, N=1024 (level-2 self-attention)
     python tools/one_op.py conv_b2 [reps]    conv_halo_deep_kernel: B=2, 32x32, 1280 -> 1280 (the level-2 conv of a batch-1 request)
     python tools/one_op.py t160 [reps]       gemm_t160_kernel: M=2048, N=1280, K=1280 + bias + residual
+    python tools/one_op.py t160tall [reps]   gemm_t160_kernel<4,4> (128 x 160 tiles): M=2048, N=2560, K=1280 + bias (q|k of a batch-1 request)
+    python tools/one_op.py g320 [reps]       gemm_g320_kernel: M=2048, N=10240 packed, K=1280 + bias, GEGLU (a batch-1 request's FF projection)
 """
 import os
 import sys
@@ -29,6 +31,17 @@ elif what == "t160":
     M, N, K = 2048, 1280, 1280
     x, w, b, r = R(M, K), R(N, K) * (K ** -0.5), R(N), R(M, N)
     fn = lambda: ops.gemm(x, w, b, r)
+    flop = 2.0 * M * N * K
+elif what == "t160tall":
+    M, N, K = 2048, 2560, 1280
+    x, w, b = R(M, K), R(N, K) * (K ** -0.5), R(N)
+    fn = lambda: ops.gemm(x, w, b)
+    flop = 2.0 * M * N * K
+elif what == "g320":
+    from diffsensei_amd.engine import pack_geglu320
+    M, N, K = 2048, 10240, 1280
+    x, w, b = R(M, K), pack_geglu320(R(N, K) * (K ** -0.5)), pack_geglu320(R(N))
+    fn = lambda: ops.gemm(x, w, b, geglu=320)
     flop = 2.0 * M * N * K
 else:
     B, heads, N = (32, 10, 4096) if what == "attn" else (32, 20, 1024)
