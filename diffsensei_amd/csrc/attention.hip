@@ -311,7 +311,11 @@ struct IPC {
     static constexpr int value = V;
 };
 
-template <int NW, bool RING>
+// T16 (round 6): both key counts lie in (64, 80] (the model's 77 text / 80 image keys), so keys 80..95 of the third 32-key block -
+// registers 8..15 of its score block on every lane - are padding for every row: their scale / maximum / exponential /
+// normalisation work, their V fragments and their P V MFMAs (probability exactly 0: bit-identical) are not issued at all -
+// a sixth of the VALU work per score and of the P V MFMAs of a kernel whose time IS that work (header above).
+template <int NW, bool RING, bool T16 = false>
 __global__ __launch_bounds__(NW * 64, 2) void ip_attn_kernel(const IPAttnParams p, int qt) {
     extern __shared__ __attribute__((aligned(16))) char ip_smem[];   // ONE LDS object (a second one de-pipelines LDS-DMA waits)
     char* const sKt = ip_smem;
@@ -537,7 +541,7 @@ __global__ __launch_bounds__(NW * 64, 2) void ip_attn_kernel(const IPAttnParams 
 #pragma unroll
             for (int kb = decltype(kb0c)::value; kb < decltype(kb1c)::value; ++kb) {
 #pragma unroll
-                for (int hb = 0; hb < 2; ++hb)
+                for (int hb = 0; hb < ((T16 && kb == 2) ? 1 : 2); ++hb)
 #pragma unroll
                     for (int db = 0; db < 2; ++db) {
                         const int row = db * 32 + l31;
@@ -574,7 +578,7 @@ __global__ __launch_bounds__(NW * 64, 2) void ip_attn_kernel(const IPAttnParams 
                 for (int kb = 0; kb < 3; ++kb) {
                     if (part && !act_ip[kb]) continue;
 #pragma unroll
-                    for (int r = 0; r < 16; r += 2) {
+                    for (int r = 0; r < ((T16 && kb == 2) ? 8 : 16); r += 2) {
                         const float g = gb[kb * 2 + (r >> 3)];
                         f32x2 v = {st[kb][r], st[kb][r + 1]};
                         v = __builtin_elementwise_fma(v, sc2, (f32x2){g, g});
@@ -593,7 +597,7 @@ __global__ __launch_bounds__(NW * 64, 2) void ip_attn_kernel(const IPAttnParams 
                 for (int kb = 0; kb < 3; ++kb) {
                     if (part && !act_ip[kb]) continue;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
+                    for (int r = 0; r < ((T16 && kb == 2) ? 8 : 16); ++r) {
                         const int kbit = (r & 3) + 8 * (r >> 2) + 4 * lhi;
                         const int key = kb * 32 + kbit;
                         float sv = fmaf(st[kb][r], p.qk_scale, (part && !((open_ip[kb] >> kbit) & 1u)) ? -10000.0f : 0.0f);
@@ -611,7 +615,7 @@ __global__ __launch_bounds__(NW * 64, 2) void ip_attn_kernel(const IPAttnParams 
                 for (int kb = 0; kb < 3; ++kb) {
                     if (part && !act_ip[kb]) continue;
 #pragma unroll
-                    for (int r = 0; r < 16; r += 2) {
+                    for (int r = 0; r < ((T16 && kb == 2) ? 8 : 16); r += 2) {
                         f32x2 v = {st[kb][r], st[kb][r + 1]};
                         v = __builtin_elementwise_fma(v, l2, m2);
                         const f32x2 e = {fast_exp2(v[0]), fast_exp2(v[1])};
@@ -630,7 +634,7 @@ __global__ __launch_bounds__(NW * 64, 2) void ip_attn_kernel(const IPAttnParams 
                 for (int kb = 0; kb < 3; ++kb) {
                     if (part && !act_ip[kb]) continue;
 #pragma unroll
-                    for (int r = 0; r < 16; r += 2) {
+                    for (int r = 0; r < ((T16 && kb == 2) ? 8 : 16); r += 2) {
                         f32x2 v = {st[kb][r], st[kb][r + 1]};
                         v *= w2;
                         st[kb][r] = v[0];
@@ -648,7 +652,7 @@ __global__ __launch_bounds__(NW * 64, 2) void ip_attn_kernel(const IPAttnParams 
                 if (kb == 0) load_v(partc, IPC<(RING ? 0 : 1)>{}, IPC<3>{});   // land under the first block's four MFMAs
                 if (part && !act_ip[kb]) continue;
 #pragma unroll
-                for (int hb = 0; hb < 2; ++hb) {
+                for (int hb = 0; hb < ((T16 && kb == 2) ? 1 : 2); ++hb) {
                     const h8 pf = pack8(st[kb], hb * 8);
 #pragma unroll
                     for (int db = 0; db < 2; ++db) ot[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[kb][hb][db], pf, ot[db], 0, 0, 0);
@@ -864,7 +868,10 @@ int ds_launch_ip_attn(const IPAttnParams& p0, hipStream_t stream) {
     int qt = 1;
     while (qt < 8 && (long)((tiles + 2 * qt - 1) / (2 * qt)) * p.B * p.heads >= g_ip_min_blocks) qt *= 2;
     dim3 grid((tiles + qt - 1) / qt, p.B * p.heads);
-    hipLaunchKernelGGL((ip_attn_kernel<4, false>), grid, dim3(256), (size_t)IP_PANEL_BYTES, stream, p, qt);
+    // keys 80..95 are padding for every row of both panels (the model's 77 / 80 keys): the T16 instantiation (ip_attn_variant 3: off, A/B)
+    const bool t16 = g_ip_variant != 3 && p.Lt > 64 && p.Lt <= 80 && p.Li > 64 && p.Li <= 80;
+    if (t16) hipLaunchKernelGGL((ip_attn_kernel<4, false, true>), grid, dim3(256), (size_t)IP_PANEL_BYTES, stream, p, qt);
+    else hipLaunchKernelGGL((ip_attn_kernel<4, false, false>), grid, dim3(256), (size_t)IP_PANEL_BYTES, stream, p, qt);
     DS_LAUNCH_CHECK();
     return 0;
 }

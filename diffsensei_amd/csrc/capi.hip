@@ -58,7 +58,7 @@ int ds_set_option(const char* key, int value) {
         return 0;
     }
     if (strcmp(key, "ip_attn_variant") == 0) {
-        DS_REQUIRE(value >= 0 && value <= 2, "ip_attn_variant must be 0 (auto), 1 (register-staged) or 2 (LDS-DMA ring)");
+        DS_REQUIRE(value >= 0 && value <= 3, "ip_attn_variant must be 0 (auto), 1 (register-staged), 2 (LDS-DMA ring) or 3 (register-staged, padding keys 80..95 not skipped)");
         ds_ip_attn_set_variant(value);
         return 0;
     }

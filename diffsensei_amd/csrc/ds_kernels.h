@@ -130,7 +130,7 @@ int ds_attn_sp_recentre_count(int reset, long long* value);   // debug counter o
 const char* ds_self_attn_kernel_name(int B, int heads, int Nq, int Nk);  // which kernel ds_launch_self_attn picks for this shape  // attention_sp.hip: software-pipelined variant
 void ds_attn_set_variant(int v);  // 0 auto, 1 force 32 query rows per wave, 2 force 64 rows per wave, 3 force the software-pipelined kernel
 void ds_ip_attn_set_min_blocks(int v);
-void ds_ip_attn_set_variant(int v);  // 0 auto, 1 four-wave register-staged kernel, 2 eight-wave LDS-DMA ring kernel (N % 256 == 0)
+void ds_ip_attn_set_variant(int v);  // 0 auto, 1 four-wave register-staged kernel, 2 eight-wave LDS-DMA ring kernel (N % 256 == 0), 3 four-wave without the T16 specialisation (A/B)
 
 struct IPAttnParams {
     const half_t* q = nullptr;     // [B,N,C] rows (ldq)

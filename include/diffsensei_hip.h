@@ -61,7 +61,9 @@ int ds_device_info(int* cu_count, int* lds_bytes, char* arch_name, int arch_name
  *   "ip_attn_min_blocks" grid size below which ip_attn_kernel stops doubling its query tiles per block (default 1024)
  *   "ip_attn_variant"    0 / 1 the register-staged ip_attn_kernel<4,false> | 2 force the 8-wave LDS-DMA ring kernel
  *                        ip_attn_kernel<8,true> where N % 256 == 0 - bit-identical results; faster back to back, slower inside the
- *                        UNet forward, so never automatic (A/B: profiles/r04_ipattn_ring_ab.txt, r04_forward_option_ab.txt)
+ *                        UNet forward, so never automatic (A/B: profiles/r04_ipattn_ring_ab.txt, r04_forward_option_ab.txt) |
+ *                        3 the register-staged kernel WITHOUT the round-6 specialisation that never issues the work of the padding
+ *                        keys 80..95 (taken automatically when both key counts lie in (64, 80]; bit-identical; A/B)
  *   "gn_variant"         0 (default) GroupNorm on 512-thread blocks with >= 64 rows per block | 1 the round-3 geometry
  *                        (256 threads, 8-row chunks; A/B: profiles/r04_gn_geometry_ab.txt)
  *   "llm_gemv_variant"   0 auto (software-pipelined persistent GEMV) | 1 one column per wavefront | 2 un-pipelined streaming GEMV
