@@ -369,7 +369,8 @@ int ds_resize_v_norm_u8(const uint8_t* tmp, int Ht, int Wt, const int32_t* first
  * ---------------------------------------------------------------------------------------------- */
 enum ds_opcode {
     DS_OP_GEMM = 1,          /* p: x, x2, w, y, bias, rowbias, residual, ln_stats, ln_c, stats_out (fused LayerNorm, see ds_gemm_ln_f16; i[8] = operand-swapped form, l[10] = ln_bstride; i[9] = ln_stats holds PARTIAL sums, f[0] = eps, l[11] = ln_rows: ds_gemm_ln_partial_f16 / ds_gemm_ln_swapped_partial_f16)   l: ldx ldx2 ldw ldy ldr sx sx2 sw sy sr
-                                i: M N K K1 epilogue batch rowbias_ld rows_per_group; i[10] = strips a consumer of partial sums adds per
+                                i: M N K K1 epilogue (0 none, 1 GEGLU in 128-row groups, 2 GELU, 3 QuickGELU, 4 GEGLU in 320-row groups: ds_gemm_g320_fits)
+                                batch rowbias_ld rows_per_group; i[10] = strips a consumer of partial sums adds per
                                 row (0 = K / 64), i[11] = statistics format a producer emits (0 = one entry per 64 columns; 160: ds_gemm_t160_fits) */
     DS_OP_CONV3X3 = 2,       /* p: x, w, y, bias, rowbias, residual, gn_partial (optional: GroupNorm workspace, see ds_conv3x3_gn_chunks)
                                 i: B H W Cin Cout stride upsample rowbias_ld Hout Wout (upsample only; 0 0 = 2H x 2W) */
