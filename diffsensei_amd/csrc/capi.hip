@@ -621,6 +621,7 @@ int ds_op_describe(const ds_op* op, char* name, int name_len, double* flops, dou
             GemmParams g;
             g.M = i[0]; g.N = i[1]; g.K = i[2];
             g.ln_stats = reinterpret_cast<const float*>(op->p[7]); g.stats_out = reinterpret_cast<float*>(op->p[9]);
+            g.ln_c = H(op->p[8]); g.residual = H(op->p[6]);
             g.ln_swapped = i[8]; g.epi = i[4]; g.ln_partial = i[9]; g.stats_strip = i[11];
             g.A2 = H(op->p[1]); g.rowbias = H(op->p[5]);
             g.lda = g.ldw = g.K1 = g.K; g.ldc = g.N;

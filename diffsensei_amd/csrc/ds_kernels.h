@@ -76,6 +76,7 @@ void ds_gemm_set_t160(int v);     // 0 auto, 1 never
 // gemm_g320.hip: 256 x 320 tiles, one block per CU, for the GEGLU projection of a small-batch request (epi == EPI_GEGLU320)
 bool ds_gemm_g320_shape(int M, int N, int K, int batch);           // the automatic dispatch rule (host logic only)
 bool ds_gemm_g320_possible(const GemmParams& p, int batch);
+bool ds_gemm_g320_plain_applicable(const GemmParams& p, int batch);   // the plain-epilogue form: possible && shape rule (q|k at M = 8192, N = 2560)
 int ds_launch_gemm_g320(const GemmParams& p, hipStream_t stream);
 void ds_gemm_set_g320(int v);     // 0 auto, 1 never
 

@@ -770,7 +770,7 @@ int launch_ring(const GemmParams& p0, int batch, hipStream_t stream) {
     return 0;
 }
 
-enum Kind { K_REG, K_GLDS2, K_GLDS1, K_PP, K_HALO, K_RING, K_T160 };
+enum Kind { K_REG, K_GLDS2, K_GLDS1, K_PP, K_HALO, K_RING, K_T160, K_G320 };
 struct Choice {
     Kind kind;
     int bm;   // rows of the block tile
@@ -823,6 +823,10 @@ Choice choose(const GemmParams& p, int batch) {
         // 64 x 160 tiles = exactly one block per CU where the 64 x 128 grid leaves a quarter of the CUs with two (gemm_t160.hip)
         c.kind = K_T160;
         c.bm = 64;
+    } else if (ds_gemm_g320_plain_applicable(p, batch)) {
+        // 256 x 320 tiles = one block per CU where the 256 x 256 grid is 1.25 rounds (gemm_g320.hip: q|k at M = 8192, N = 2560)
+        c.kind = K_G320;
+        c.bm = 256;
     } else if (small) {
         c.kind = K_GLDS1;
         // grids that leave a CU with at most two 64 x 128 blocks: nothing hides the DMA latency of the one-buffer kernel
@@ -890,7 +894,7 @@ int ds_gemm_ln_kind(int M, int N, int K, int batch, int epi) {
     if (g_gemm_variant != 0) return 0;
     const Kind k = choose(p, batch).kind;
     if (k == K_PP) return (rows_ok && cols_ok) ? 1 : 0;
-    if ((k == K_GLDS1 || k == K_GLDS2 || k == K_RING || k == K_T160) && K % 64 == 0) return 2;   // (a PRODUCER also needs N % 128 == 0 and no batch)
+    if ((k == K_GLDS1 || k == K_GLDS2 || k == K_RING || k == K_T160 || k == K_G320) && K % 64 == 0) return 2;   // (a PRODUCER also needs N % 128 == 0 and no batch)
     return 0;
 }
 
@@ -906,6 +910,7 @@ const char* ds_gemm_kernel_name(const GemmParams& p, int batch) {
         case K_HALO: return "conv_halo_kernel";
         case K_RING: return c.bm == 4 ? "gemm_glds_kernel<64,false,4>" : "gemm_glds_kernel<64,false,3>";
         case K_T160: return ds_gemm_t160_rows(p.M, p.N, p.K, batch) == 128 ? "gemm_t160_kernel<128 rows>" : "gemm_t160_kernel";
+        case K_G320: return "gemm_g320_kernel<plain>";
         case K_GLDS1:
             if (c.bm == 128) return conv ? "gemm_glds_kernel<128,true,1>" : "gemm_glds_kernel<128,false,1>";
             return conv ? "gemm_glds_kernel<64,true,1>" : "gemm_glds_kernel<64,false,1>";
@@ -957,7 +962,7 @@ int ds_launch_gemm(const GemmParams& p_in, int batch, hipStream_t stream) {
         const bool pp_ok = ds_gemm_pp_applicable(p) &&
                            (p.ln_swapped || (p.M % 256 == 0 && (p.N % 256 == 0 || (p.N % 64 == 0 && p.epi == EPI_NONE && (g_gemm_debug & 4096) == 0))));
         const bool wide_ok = batch == 1 && p.N % 128 == 0 && p.K % 64 == 0;
-        const bool wide_kind = c.kind == K_GLDS1 || c.kind == K_GLDS2 || c.kind == K_RING || c.kind == K_T160;
+        const bool wide_kind = c.kind == K_GLDS1 || c.kind == K_GLDS2 || c.kind == K_RING || c.kind == K_T160 || c.kind == K_G320;
         auto force_wide = [&]() {
             if (!wide_kind) { c.kind = K_GLDS1; c.bm = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) < 384 ? 64 : 128; }
         };
@@ -993,6 +998,7 @@ int ds_launch_gemm(const GemmParams& p_in, int batch, hipStream_t stream) {
         case K_HALO: return ds_launch_conv_halo(p, stream);
         case K_RING: return c.bm == 4 ? launch_ring<4>(p, batch, stream) : launch_ring<3>(p, batch, stream);
         case K_T160: return ds_launch_gemm_t160(p, stream);
+        case K_G320: return ds_launch_gemm_g320(p, stream);
         case K_GLDS1:
             if (c.bm == 128)
                 return conv ? launch_glds1<128, true>(p, batch, stream) : launch_glds1<128, false>(p, batch, stream);

@@ -61,6 +61,11 @@ struct IC3 {
     static constexpr int value = V;
 };
 
+// GEGLU = false (added at the end of round 6): the same main loop with a PLAIN epilogue (bias or the fused-LayerNorm consumer form,
+// 320 output columns per tile, natural weight order) for the one plain projection whose 256 x 320 grid is exactly one block per CU:
+// q|k at M = 8192, N = 2560 (UNet batch 8 at 1024 x 1024 = BASELINE configs[2]; batch 2 at 2048 x 2048 = configs[4]), 320 tiles of
+// 256 x 256 = 1.25 rounds otherwise (78 us on the 128 x 128 kernel).
+template <bool GEGLU>
 __global__ __launch_bounds__(NWAVES * 64, 1) void gemm_g320_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -248,6 +253,18 @@ __global__ __launch_bounds__(NWAVES * 64, 1) void gemm_g320_kernel(const GemmPar
                 }
         }
         __syncthreads();
+        if constexpr (!GEGLU) {
+            // stage 2, plain: thread t takes 16-byte chunk id % 40 of row id / 40, id = t + 512 j: 640-byte row segments
+#pragma unroll
+            for (int j = 0; j < 10; ++j) {
+                const int id = tid + NWAVES * 64 * j;
+                const int row = id / 40, c = id - row * 40;
+                const int m = m0 + pass * 128 + row;
+                const h8 v = *reinterpret_cast<const h8*>(sC + row * CS + c * 16);
+                if (m < p.M) *reinterpret_cast<h8*>(Cg + (long)m * p.ldc + n0 + c * 8) = v;
+            }
+            continue;
+        }
         // stage 2: thread t takes 16-byte output chunk id % 20 of row id / 20, id = t + 512 j
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
@@ -280,14 +297,20 @@ bool ds_gemm_g320_shape(int M, int N, int K, int batch) {
     return b320 <= 256 && b320 >= 160 && b256 > 256;
 }
 
-// what the kernel can run at all (the packed layout is the caller's promise: epi == EPI_GEGLU320)
+// what the kernel can run at all (GEGLU: the packed layout is the caller's promise, epi == EPI_GEGLU320; plain: epi == EPI_NONE)
 bool ds_gemm_g320_possible(const GemmParams& p, int batch) {
-    if (p.conv || p.A2 || p.rowbias || p.residual || p.stats_out || p.epi != EPI_GEGLU320 || p.dtype != DS_DTYPE_F16 || p.ln_swapped || batch != 1)
+    if (p.conv || p.A2 || p.rowbias || p.residual || p.stats_out || (p.epi != EPI_GEGLU320 && p.epi != EPI_NONE) || p.dtype != DS_DTYPE_F16 ||
+        p.ln_swapped || batch != 1)
         return false;
     if (p.M <= 0 || p.N % GN != 0 || p.K % 64 != 0 || p.K <= 0) return false;
     if (p.ln_stats && !(p.ln_partial && p.ln_c)) return false;   // finalised statistics are gemm_pp_kernel's consumer form
     if (p.lda * 255 + 64 >= (1L << 30) || p.ldw * 319 + 64 >= (1L << 30)) return false;   // 32-bit lane offsets
     return true;
+}
+
+// automatic dispatch of the PLAIN form (ds_launch_gemm's choice, gemm.hip): the shape rule above on a problem the kernel can run
+bool ds_gemm_g320_plain_applicable(const GemmParams& p, int batch) {
+    return p.epi == EPI_NONE && ds_gemm_g320_possible(p, batch) && ds_gemm_g320_shape(p.M, p.N, p.K, batch);
 }
 
 int ds_launch_gemm_g320(const GemmParams& p0, hipStream_t stream) {
@@ -296,9 +319,12 @@ int ds_launch_gemm_g320(const GemmParams& p0, hipStream_t stream) {
     p.tiles_m = (p.M + GM - 1) / GM;
     p.tiles_n = p.N / GN;
     static unsigned long long attr_devs = 0;
-    if (ds_first_on_device(attr_devs))
-        DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_g320_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_B));
-    hipLaunchKernelGGL(gemm_g320_kernel, dim3(p.tiles_m * p.tiles_n), dim3(NWAVES * 64), (size_t)LDS_B, stream, p);
+    if (ds_first_on_device(attr_devs)) {
+        DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_g320_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_B));
+        DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_g320_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_B));
+    }
+    if (p.epi == EPI_GEGLU320) hipLaunchKernelGGL(gemm_g320_kernel<true>, dim3(p.tiles_m * p.tiles_n), dim3(NWAVES * 64), (size_t)LDS_B, stream, p);
+    else hipLaunchKernelGGL(gemm_g320_kernel<false>, dim3(p.tiles_m * p.tiles_n), dim3(NWAVES * 64), (size_t)LDS_B, stream, p);
     DS_LAUNCH_CHECK();
     return 0;
 }

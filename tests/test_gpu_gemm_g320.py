@@ -130,3 +130,47 @@ def test_g320_dispatch_rule_and_refusals(hip_lib):
         ops.gemm(x, pack_geglu320(w), None, residual=torch.zeros((256, 320), dtype=torch.float16, device=DEV), geglu=320)
     with pytest.raises(Exception):
         ops.gemm(x, w[:384].contiguous(), None, geglu=320)
+
+
+def test_g320_plain_form_for_the_one_block_per_cu_qk_projection(hip_lib):
+    """The plain-epilogue instantiation: q|k at M = 8192, N = 2560, K = 1280 (UNet batch 8 at 1024 x 1024, batch 2 at 2048 x 2048:
+    8 x ... 32 x 8 = 256 tiles of 256 x 320) is dispatched to it automatically - bias form and fused-LayerNorm consumer form vs fp32
+    torch and bit-identical to the 128 x 128 kernel it replaces there (option gemm_g320 = 1 switches the rule off); other shapes
+    keep their kernels."""
+    from diffsensei_amd import _lib, ops
+    from diffsensei_amd.engine import make_op, pack_ln_fused
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(99)
+    M, N, K = 8192, 2560, 1280
+    x, w, b = _r((M, K), g).to(DEV), _r((N, K), g, 1 / math.sqrt(K)).to(DEV), _r((N,), g, 0.3).to(DEV)
+
+    def name_of(m, n, k):
+        y = torch.empty((8, 8), dtype=torch.float16, device=DEV)
+        op = make_op("GEMM", i=(m, n, k, k, 0, 1, 0, 1, 0, 0, 0, 0), f=(1e-5,), l=(k, 0, k, n, n), p=(x, None, w, y, None, None, None, None, None, None))
+        nm = C.create_string_buffer(128)
+        fl, by = C.c_double(), C.c_double()
+        assert lib.ds_op_describe(C.byref(op), nm, 128, C.byref(fl), C.byref(by)) == 0
+        return nm.value.decode()
+
+    assert name_of(M, N, K) == "gemm_g320_kernel<plain>"
+    assert name_of(65536, N, K) != "gemm_g320_kernel<plain>" and name_of(2048, N, K) != "gemm_g320_kernel<plain>"
+    got = ops.gemm(x, w, b)
+    ref = F.linear(x.float().cpu(), w.float().cpu(), b.float().cpu())
+    e = _relmax(got, ref)
+    print(f"gemm_g320 plain M={M} N={N} K={K}: {e:.2e}")
+    assert e <= 2e-3, e
+    gamma, beta = (1 + 0.2 * torch.randn(K, generator=g)).half().to(DEV), _r((K,), g, 0.2).to(DEV)
+    gw, c2, b2 = pack_ln_fused(w, None, gamma, beta)
+    xs = x.float().view(M, K // 64, 64)
+    part = torch.stack([xs.sum(-1).t(), (xs * xs).sum(-1).t()], dim=-1).contiguous()
+    got_ln = ops.gemm_ln_partial(x, gw, b2, c2, part)
+    ref_ln = F.linear(F.layer_norm(x.float().cpu(), (K,), gamma.float().cpu(), beta.float().cpu(), 1e-5), w.float().cpu())
+    e2 = _relmax(got_ln, ref_ln)
+    print(f"gemm_g320 plain, fused-LayerNorm consumer: {e2:.2e}")
+    assert e2 <= 3e-3, e2
+    assert lib.ds_set_option(b"gemm_g320", 1) == 0
+    try:
+        assert name_of(M, N, K) != "gemm_g320_kernel<plain>"
+        assert torch.equal(ops.gemm(x, w, b), got) and torch.equal(ops.gemm_ln_partial(x, gw, b2, c2, part), got_ln)
+    finally:
+        lib.ds_set_option(b"gemm_g320", 0)
