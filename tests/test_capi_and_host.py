@@ -319,3 +319,35 @@ def test_bench_mllm_request_path_contract():
     # tests/test_gpu_ops.py::test_layernorm covers C up to 8192, test_gpu_mllm.py runs both resamplers at these dims
     assert (cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads) == (5120, 13824, 40)
     assert max(cfg.hidden_size, 2048) <= 8192
+
+
+def test_one_block_per_cu_tile_rules_are_pure_host_logic(hip_lib):
+    """Round 6: the planner's host queries for the tile shapes built for the reference's own call shape (one request, batch 1;
+    reference scripts/demo/gradio_wo_mllm.py:45-62) answer without a GPU, are thread-local A/B switches, and pick exactly the
+    shapes whose grid is one block per CU on >= 5/8 of a 256-CU part:
+      ds_gemm_t160_fits   64 x 160 tiles (M = 2048, N = 1280), else 128 x 160 tiles (q|k: N = 2560; M = 4096, N = 1280)
+      ds_gemm_g320_fits   256 x 320 tiles (the GEGLU projection M = 2048, N = 10240 packed; plain q|k at M = 8192, N = 2560)."""
+    t160 = lambda m, n, k, b=1: int(hip_lib.ds_gemm_t160_fits(m, n, k, b))
+    g320 = lambda m, n, k, b=1: int(hip_lib.ds_gemm_g320_fits(m, n, k, b))
+    assert t160(2048, 1280, 1280) == 1 and t160(2048, 1280, 5120) == 1          # 32 x 8 = 256 blocks of 64 x 160
+    assert t160(2048, 2560, 1280) == 1 and t160(4096, 1280, 1280) == 1          # 16 x 16 / 32 x 8 = 256 blocks of 128 x 160
+    assert t160(8192, 2560, 1280) == 0 and t160(65536, 1280, 1280) == 0 and t160(1024, 1280, 1280) == 0
+    assert t160(2048, 1280, 1280, 2) == 0 and t160(2048, 1288, 1280) == 0 and t160(2048, 1280, 192) == 0
+    assert g320(2048, 10240, 1280) == 1 and g320(8192, 2560, 1280) == 1         # 8 x 32 / 32 x 8 = 256 blocks of 256 x 320
+    assert g320(1152, 10240, 1280) == 0                                          # 768 x 768, batch 1: its 5 x 40 tiles of 256 x 256 already fit one round
+    assert g320(4096, 10240, 1280) == 0 and g320(65536, 10240, 1280) == 0 and g320(6144, 2560, 1280) == 0   # > 256 blocks / one round of 256 x 256 tiles
+    assert g320(2048, 10240, 1280, 2) == 0 and g320(2048, 10240 + 64, 1280) == 0
+    for key, q, args in ((b"gemm_t160", t160, (2048, 1280, 1280)), (b"gemm_g320", g320, (2048, 10240, 1280))):
+        try:
+            assert hip_lib.ds_set_option(key, 1) == 0 and q(*args) == 0
+        finally:
+            hip_lib.ds_set_option(key, 0)
+        assert q(*args) == 1
+    try:
+        assert hip_lib.ds_set_option(b"gemm_t160", 2) == 0                      # 64-row tiles only
+        assert t160(2048, 1280, 1280) == 1 and t160(2048, 2560, 1280) == 0
+    finally:
+        hip_lib.ds_set_option(b"gemm_t160", 0)
+    # the fused-LayerNorm query follows: a consumer of partial sums on every one of these kernels
+    assert hip_lib.ds_gemm_ln_fusable(2048, 10240, 1280, 4, 1) == 2 and hip_lib.ds_gemm_ln_fusable(8192, 2560, 1280, 0, 1) == 2
+    assert hip_lib.ds_gemm_ln_fusable(2048, 2560, 1280, 0, 1) == 2 and hip_lib.ds_gemm_ln_fusable(2048, 10240, 1280, 4, 2) == 0
