@@ -65,6 +65,11 @@ struct IC3 {
 // 320 output columns per tile, natural weight order) for the one plain projection whose 256 x 320 grid is exactly one block per CU:
 // q|k at M = 8192, N = 2560 (UNet batch 8 at 1024 x 1024 = BASELINE configs[2]; batch 2 at 2048 x 2048 = configs[4]), 320 tiles of
 // 256 x 256 = 1.25 rounds otherwise (78 us on the 128 x 128 kernel).
+// (Measured and NOT kept: a 128 x 320 instantiation with +residual / LayerNorm-producer epilogues for the N = 1280 projections at
+// M = 8192 - 64 x 4 = 256 blocks where gemm_pp_kernel runs 160 tiles in one round on 62 % of the CUs.  Bit-identical tiles, and
+// slower: K = 5120 121.6 -> 128.8 us, K = 1280 43.1 -> 44.5 us, the consumer form 40.7 -> 43.4 us
+// (profiles/r06_g320_128row_tiles_forward_ab_b8.txt): 56 KiB of fill per 5.2 MFLOP k-tile is 1.6x this tile's bytes per flop - the
+// block is back on its CU's fill path - while 160 busy CUs clock higher than 256.)
 template <bool GEGLU>
 __global__ __launch_bounds__(NWAVES * 64, 1) void gemm_g320_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
